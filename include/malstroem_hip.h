@@ -1,0 +1,155 @@
+/*
+ * malstroem_hip.h -- C-ABI of libmalstroem_hip.so, the MI355X (gfx950) raster-hydrology core.
+ *
+ * Drop-in boundary: these entry points are what a malstroem maintainer binds with ctypes in
+ * place of the Cython `speedups` modules (reference malstroem/algorithms/speedups/__init__.py:37-77).
+ * The reference patches 8 per-sweep / per-cell functions; a GPU needs whole-stage granularity
+ * (SURVEY.md 8b), so each entry point below replaces one whole stage of malstroem.algorithms.
+ *
+ * Conventions
+ *   - return 0 on success, <0 on error (MHIP_E*); mhip_last_error() gives the message (thread local).
+ *   - rasters are C-contiguous row-major, H rows x W cols; host pointers are borrowed for the call
+ *     and never retained; the caller allocates every output.
+ *   - dtype contract of reference algorithms/dtypes.py:20-31: DEM/filled float32, no-flats surface
+ *     float64, flow direction uint8 (AGNPS codes 0..7, 8 = no direction), accumulation float64,
+ *     labels int32 (scipy.ndimage.label output dtype).
+ *   - record layouts are the packed NumPy dtypes of reference _label.pyx:22-28.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with MHIP_ENODEV.
+ */
+#ifndef MALSTROEM_HIP_H
+#define MALSTROEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHIP_OK 0
+#define MHIP_EINVAL (-1)   /* bad argument (NULL pointer, H/W < 1, label out of range ...) */
+#define MHIP_EHIP (-2)     /* HIP runtime error */
+#define MHIP_ENODEV (-3)   /* no HIP device visible */
+#define MHIP_ELIMIT (-4)   /* raster too large for the int32 label / local-index domain */
+#define MHIP_ENOTCONV (-5) /* iteration cap hit (flow cycle through an edge cell, see watersheds) */
+#define MHIP_ECOMM (-6)    /* RCCL error (multi-GPU context) */
+
+/* packed record of reference _label.pyx:22-24 == numpy [('min','<f8'),('max','<f8'),('sum','<f8'),('count','<i8')] */
+typedef struct { double min, max, sum; int64_t count; } mhip_stat_record;
+/* packed record of reference _label.pyx:26-28 == numpy [('value','<f8'),('row','<i8'),('col','<i8')] */
+typedef struct { double value; int64_t row, col; } mhip_index_record;
+
+/* ---- library / device ------------------------------------------------------------------------- */
+const char *mhip_last_error(void);
+const char *mhip_version(void);
+int mhip_device_count(void);                 /* number of HIP devices, 0 if none / runtime missing */
+int mhip_set_device(int device);             /* device used by the calling thread's later calls */
+
+/* ---- whole-stage entry points on HOST rasters (upload -> kernels -> download) ----------------- */
+
+/* fill.fill_terrain(dtm)  reference fill.py:112-171 (+ sweep _fill.pyx:28-70).
+ * Greatest fixed point of W = max(dtm, min(W, 8 nbrs)), border cells fixed to dtm.
+ * out_rounds (optional): number of tile rounds the device schedule needed. */
+int mhip_fill_f32(const float *dem, float *out_filled, int64_t H, int64_t W, int32_t *out_rounds);
+
+/* fill.fill_terrain_no_flats(dtm, short, diag)  reference fill.py:174-232 (+ _fill.pyx:72-124). */
+int mhip_fill_noflat_f64(const float *dem, double *out, int64_t H, int64_t W, double short_, double diag,
+                         int32_t *out_rounds);
+
+/* fill.minimum_safe_short_and_diag(dem)  reference fill.py:235-250. */
+int mhip_short_diag(const float *dem, int64_t n, double *short_, double *diag);
+
+/* depths = filled - dem  reference dem.py:71. */
+int mhip_depths_f32(const float *filled, const float *dem, float *out, int64_t n);
+
+/* flow.terrain_flowdirection(terrain, edges_flow_outward)  reference flow.py:142-167 ->
+ * _flow.pyx:98-176 (diagonal drop MULTIPLIED by 1/2**0.5) + flow.py:118-139. float64 input only. */
+int mhip_d8_f64(const double *z, uint8_t *out, int64_t H, int64_t W, int edges_outward);
+
+/* flow.accumulated_flow(flowdir)  reference _flow.pyx:225-273 (python flow.py:304-364). */
+int mhip_accum(const uint8_t *flowdir, double *out, int64_t H, int64_t W);
+
+/* label.connected_components(data)  reference label.py:19-40 -> scipy.ndimage.label(data, ones((3,3))):
+ * 8-connected, foreground = data != 0, labels 1..n ordered by first raster-scan pixel, int32. */
+int mhip_ccl8_f32(const float *data, int32_t *labels, int64_t H, int64_t W, int64_t *nlabels);
+int mhip_ccl8_u8(const uint8_t *data, int32_t *labels, int64_t H, int64_t W, int64_t *nlabels);
+
+/* label.keep_labels + second connected_components (reference label.py:78-98, bluespots.py:167-170)
+ * fused: rank = cumsum(keep)*keep with keep[0] forced false; labels[i] = rank[labels[i]] in place.
+ * keep has nlab+1 entries. nkept receives the number of surviving labels. */
+int mhip_relabel_keep(int32_t *labels, const uint8_t *keep, int64_t nlab, int64_t n, int64_t *nkept);
+/* label.keep_labels alone: mask[i] = keep[labels[i]]; the caller clears keep[background] first (label.py:91). */
+int mhip_keep_mask(const int32_t *labels, const uint8_t *keep, int64_t nlab, int64_t n, uint8_t *mask);
+
+/* label.label_stats(data, labelled, nlabels)  reference _label.pyx:68-97 (python label.py:43-75).
+ * records has nlab+1 entries (label 0 included). */
+int mhip_label_stats_f32(const float *data, const int32_t *labels, int64_t n, int64_t nlab,
+                         mhip_stat_record *records);
+
+/* label.label_min_index / label.label_max_index  reference _label.pyx:99-128, label.py:135-166:
+ * per label extreme value and its FIRST raster-order position (strict compare). nlab+1 records. */
+int mhip_label_argmin_f64(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab,
+                          mhip_index_record *records);
+int mhip_label_argmax_f64(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab,
+                          mhip_index_record *records);
+
+/* label.label_count(labelled) == np.bincount  reference label.py:169-180. counts has nlab+1 entries. */
+int mhip_label_count(const int32_t *labels, int64_t n, int64_t nlab, int64_t *counts);
+/* max(labelled) helper (the reference computes nlabels = np.max(labelled) when not given). */
+int mhip_label_max(const int32_t *labels, int64_t n, int32_t *out_max);
+
+/* flow.watersheds_from_labels(flowdir, labelled, unassigned)  reference flow.py:398-412 ->
+ * _flow.pyx:276-403. In place on labels. Terminates on flow cycles (reference does not). */
+int mhip_watersheds_i32(const uint8_t *flowdir, int32_t *labels_inout, int64_t H, int64_t W, int32_t unassigned);
+
+/* ---- device-resident pipeline (DemTool / BluespotTool sequences, reference dem.py:53-93,
+ *      bluespots.py:138-216): one upload, all stages in HBM, downloads only for the writers. ------- */
+typedef struct mhip_ctx mhip_ctx;
+
+enum mhip_stage {
+    MHIP_STAGE_FILL = 1 << 0,        /* filled f32 (+ depths f32 fused epilogue) */
+    MHIP_STAGE_NOFLAT = 1 << 1,      /* short/diag + no-flats surface f64 */
+    MHIP_STAGE_FLOWDIR = 1 << 2,     /* D8 on the no-flats surface, edges outward */
+    MHIP_STAGE_ACCUM = 1 << 3,       /* accumulated flow f64 */
+    MHIP_STAGE_LABEL = 1 << 4,       /* raw bluespot labels i32 + raw label_stats */
+    MHIP_STAGE_WATERSHED = 1 << 5,   /* watersheds i32 from (filtered) labels + label_count */
+    MHIP_STAGE_POURPOINTS = 1 << 6,  /* argmax(accum) or argmin(no-flats) per label */
+    MHIP_STAGE_ALL = 0x7f
+};
+
+enum mhip_raster {
+    MHIP_R_DEM = 0, MHIP_R_FILLED, MHIP_R_DEPTHS, MHIP_R_NOFLAT, MHIP_R_FLOWDIR, MHIP_R_ACCUM,
+    MHIP_R_LABELS, MHIP_R_WATERSHEDS, MHIP_R_COUNT_
+};
+
+/* Single-GPU context for an H x W raster on `device`. */
+int mhip_ctx_create(mhip_ctx **out, int64_t H, int64_t W, int device);
+/* Multi-GPU context: this rank owns rows [row0, row0+H_local) of a H_global x W raster; bands are
+ * contiguous in rank order.  nccl_unique_id is the 128-byte ncclUniqueId created by rank 0
+ * (mhip_comm_unique_id) and distributed by the host launcher. */
+int mhip_comm_unique_id(void *id128);
+int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t row0, int64_t H_local,
+                         int device, int rank, int nranks, const void *nccl_unique_id);
+int mhip_ctx_destroy(mhip_ctx *ctx);
+int mhip_ctx_upload_dem(mhip_ctx *ctx, const float *dem_band);       /* H_local x W host raster */
+int mhip_ctx_upload(mhip_ctx *ctx, int which, const void *host);     /* any raster (for sub-commands) */
+int mhip_ctx_download(mhip_ctx *ctx, int which, void *host);         /* H_local x W */
+int mhip_ctx_run(mhip_ctx *ctx, int stage_mask);                     /* asynchronous on the ctx stream */
+int mhip_ctx_sync(mhip_ctx *ctx);
+/* after mhip_ctx_sync: milliseconds (HIP events on the ctx stream) of `stage` (single bit) in the last run */
+int mhip_ctx_stage_ms(mhip_ctx *ctx, int stage, float *ms);
+/* milliseconds / launch count of one named kernel family in the last run ("d8", "fill_round", ...) */
+int mhip_ctx_kernel_ms(mhip_ctx *ctx, const char *kernel, float *ms_total, int32_t *launches);
+int mhip_ctx_get_i64(mhip_ctx *ctx, const char *key, int64_t *value); /* "nlabels_raw", "nlabels", "fill_rounds", ... */
+int mhip_ctx_get_f64(mhip_ctx *ctx, const char *key, double *value);  /* "short", "diag" */
+/* label filter between MHIP_STAGE_LABEL and MHIP_STAGE_WATERSHED (reference bluespots.py:165-172):
+ * download raw stats (nlabels_raw+1 records), decide on host, upload keep flags. */
+int mhip_ctx_raw_stats(mhip_ctx *ctx, mhip_stat_record *records);
+int mhip_ctx_apply_keep(mhip_ctx *ctx, const uint8_t *keep);          /* NULL = keep all */
+int mhip_ctx_stats(mhip_ctx *ctx, mhip_stat_record *records);         /* nlabels+1, after apply_keep */
+int mhip_ctx_watershed_counts(mhip_ctx *ctx, int64_t *counts);        /* nlabels+1 */
+int mhip_ctx_pourpoints(mhip_ctx *ctx, mhip_index_record *records);   /* nlabels+1 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MALSTROEM_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libmalstroem_hip.so (C-ABI declared in include/malstroem_hip.h).
+
+This is the only place that touches the shared library.  Loading never falls back to anything
+else: if the library (or a HIP device) is missing the stage functions raise ``RuntimeError``.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libmalstroem_hip.so"
+CSRC = _PKG / "csrc"
+
+STAT_DTYPE = np.dtype([("min", "<f8"), ("max", "<f8"), ("sum", "<f8"), ("count", "<i8")])   # _label.pyx:22-24
+INDEX_DTYPE = np.dtype([("value", "<f8"), ("row", "<i8"), ("col", "<i8")])                    # _label.pyx:26-28
+
+OK, EINVAL, EHIP, ENODEV, ELIMIT, ENOTCONV, ECOMM = 0, -1, -2, -3, -4, -5, -6
+
+STAGE_FILL, STAGE_NOFLAT, STAGE_FLOWDIR, STAGE_ACCUM = 1, 2, 4, 8
+STAGE_LABEL, STAGE_WATERSHED, STAGE_POURPOINTS, STAGE_ALL = 16, 32, 64, 0x7F
+R_DEM, R_FILLED, R_DEPTHS, R_NOFLAT, R_FLOWDIR, R_ACCUM, R_LABELS, R_WATERSHEDS = range(8)
+RASTER_DTYPE = {R_DEM: np.float32, R_FILLED: np.float32, R_DEPTHS: np.float32, R_NOFLAT: np.float64,
+                R_FLOWDIR: np.uint8, R_ACCUM: np.float64, R_LABELS: np.int32, R_WATERSHEDS: np.int32}
+
+# every symbol include/malstroem_hip.h declares (checked by tests/test_cabi.py)
+SYMBOLS = [
+    "mhip_last_error", "mhip_version", "mhip_device_count", "mhip_set_device",
+    "mhip_fill_f32", "mhip_fill_noflat_f64", "mhip_short_diag", "mhip_depths_f32", "mhip_d8_f64", "mhip_accum",
+    "mhip_ccl8_f32", "mhip_ccl8_u8", "mhip_relabel_keep", "mhip_keep_mask", "mhip_label_stats_f32",
+    "mhip_label_argmin_f64", "mhip_label_argmax_f64", "mhip_label_count", "mhip_label_max", "mhip_watersheds_i32",
+    "mhip_ctx_create", "mhip_comm_unique_id", "mhip_ctx_create_band", "mhip_ctx_destroy", "mhip_ctx_upload_dem",
+    "mhip_ctx_upload", "mhip_ctx_download", "mhip_ctx_run", "mhip_ctx_sync", "mhip_ctx_stage_ms",
+    "mhip_ctx_kernel_ms", "mhip_ctx_get_i64", "mhip_ctx_get_f64", "mhip_ctx_raw_stats", "mhip_ctx_apply_keep",
+    "mhip_ctx_stats", "mhip_ctx_watershed_counts", "mhip_ctx_pourpoints",
+]
+
+_lib = None
+_lock = threading.Lock()   # ctypes releases the GIL; the library keeps per-call state, so serialise calls
+
+
+def build(force=False):
+    """Compile libmalstroem_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")) + [_PKG.parent / "include" / "malstroem_hip.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", str(CSRC), "-j8"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library (no device needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError("libmalstroem_hip.so is not built (%s); run malstroem_amd._lib.build() -- "
+                               "there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(str(LIB_PATH))
+        lib.mhip_last_error.restype = ctypes.c_char_p
+        lib.mhip_version.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+def device_count():
+    try:
+        return int(load().mhip_device_count())
+    except (OSError, RuntimeError):
+        return 0
+
+
+def check(rc, what):
+    if rc == OK:
+        return
+    msg = load().mhip_last_error().decode("utf-8", "replace")
+    text = "%s: %s" % (what, msg)
+    if rc == EINVAL:
+        raise ValueError(text)
+    if rc == ELIMIT:
+        raise OverflowError(text)
+    raise RuntimeError(text)
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def call(name, *args):
+    lib = load()
+    with _lock:
+        rc = getattr(lib, name)(*args)
+    check(rc, name)

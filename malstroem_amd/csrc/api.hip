@@ -1,0 +1,736 @@
+// api.hip -- extern "C" boundary of libmalstroem_hip.so (declared in include/malstroem_hip.h).
+//
+// Two layers over the device-pointer stage implementations (fill.hip, d8.hip, accum.hip, ccl.hip,
+// label_ops.hip, watershed.hip):
+//   * host-raster entry points: upload -> stage -> download, one per malstroem.algorithms stage function;
+//   * mhip_ctx: device-resident DemTool/BluespotTool pipeline (reference dem.py:53-93, bluespots.py:138-216)
+//     with HIP-event timing per stage.
+// There is no CPU fallback anywhere in this file: without a HIP device every compute call returns MHIP_ENODEV.
+#include <cstdarg>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace mh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+// ---- caching device allocator -------------------------------------------------------------------
+// Freed blocks are kept per (device, rounded size) and handed out again; callers only release a block after
+// synchronising the stream that used it, so reuse needs no further ordering.
+namespace {
+std::mutex g_pool_mu;
+std::multimap<std::pair<int, size_t>, void *> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t POOL_CAP = 96ull << 30;  // MI355X has 288 GB of HBM3E; keep at most a third cached
+size_t round_size(size_t n) { return n < (1u << 20) ? ((n + 255) & ~size_t(255)) : ((n + (1u << 20) - 1) & ~size_t((1u << 20) - 1)); }
+}  // namespace
+
+int pool_alloc(void **p, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t rs = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool.find({dev, rs});
+        if (it != g_pool.end()) {
+            *p = it->second;
+            g_pool.erase(it);
+            g_pool_bytes -= rs;
+            return MHIP_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, rs);
+    if (e != hipSuccess) {  // drop the cache and retry once
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            for (auto &kv : g_pool) (void)hipFree(kv.second);
+            g_pool.clear();
+            g_pool_bytes = 0;
+        }
+        e = hipMalloc(p, rs);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        set_error("hipMalloc(%zu) failed: %s", rs, hipGetErrorString(e));
+        return MHIP_EHIP;
+    }
+    return MHIP_OK;
+}
+
+void pool_free(void *p, size_t bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t rs = round_size(bytes);
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool_bytes + rs > POOL_CAP) {
+        (void)hipFree(p);
+        return;
+    }
+    g_pool.emplace(std::make_pair(dev, rs), p);
+    g_pool_bytes += rs;
+}
+
+static int require_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (libmalstroem_hip has no CPU fallback)");
+        return MHIP_ENODEV;
+    }
+    return MHIP_OK;
+}
+
+static int upload(DevBuf &b, const void *host, size_t bytes, hipStream_t s)
+{
+    MH_TRY(b.alloc(bytes));
+    MH_HIP(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, s));
+    return MHIP_OK;
+}
+static int download(void *host, const DevBuf &b, size_t bytes, hipStream_t s)
+{
+    MH_HIP(hipMemcpyAsync(host, b.p, bytes, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
+}
+
+// rank LUT of label.keep_labels + second connected_components (bluespots.py:167-170):
+// rank = cumsum(keep) * keep with keep[0] forced False
+static int64_t build_rank_lut(const uint8_t *keep, int64_t nlab, std::vector<int32_t> &lut)
+{
+    lut.assign((size_t)nlab + 1, 0);
+    int32_t run = 0;
+    for (int64_t l = 1; l <= nlab; ++l)
+        if (!keep || keep[l]) lut[(size_t)l] = ++run;
+    return run;
+}
+
+}  // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+const char *mhip_last_error(void) { return get_error(); }
+const char *mhip_version(void) { return "malstroem_hip 0.1 (gfx950)"; }
+
+int mhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mhip_set_device(int device)
+{
+    MH_TRY(require_device());
+    MH_HIP(hipSetDevice(device));
+    return MHIP_OK;
+}
+
+int mhip_fill_f32(const float *dem, float *out, int64_t H, int64_t W, int32_t *out_rounds)
+{
+    MH_ARG(dem && out && H >= 1 && W >= 1, "fill_f32(dem, out, H>=1, W>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_dem, d_out;
+    MH_TRY(upload(d_dem, dem, n * 4, s));
+    MH_TRY(d_out.alloc(n * 4));
+    FillStats st;
+    MH_TRY(fill_plain_dev(d_dem.as<float>(), d_out.as<float>(), H, W, s, &st));
+    if (out_rounds) *out_rounds = st.rounds;
+    return download(out, d_out, n * 4, s);
+}
+
+int mhip_fill_noflat_f64(const float *dem, double *out, int64_t H, int64_t W, double short_, double diag,
+                         int32_t *out_rounds)
+{
+    MH_ARG(dem && out && H >= 1 && W >= 1, "fill_noflat_f64(dem, out, H>=1, W>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_dem, d_out;
+    MH_TRY(upload(d_dem, dem, n * 4, s));
+    MH_TRY(d_out.alloc(n * 8));
+    FillStats st;
+    MH_TRY(fill_noflat_dev(d_dem.as<float>(), d_out.as<double>(), H, W, short_, diag, s, &st));
+    if (out_rounds) *out_rounds = st.rounds;
+    return download(out, d_out, n * 8, s);
+}
+
+int mhip_short_diag(const float *dem, int64_t n, double *short_, double *diag)
+{
+    MH_ARG(dem && short_ && diag && n >= 1, "short_diag(dem, n>=1, short, diag)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf d_dem;
+    MH_TRY(upload(d_dem, dem, (size_t)n * 4, s));
+    return short_diag_dev(d_dem.as<float>(), n, short_, diag, s);
+}
+
+int mhip_depths_f32(const float *filled, const float *dem, float *out, int64_t n)
+{
+    MH_ARG(filled && dem && out && n >= 1, "depths_f32(filled, dem, out, n>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf a, b, o;
+    MH_TRY(upload(a, filled, (size_t)n * 4, s));
+    MH_TRY(upload(b, dem, (size_t)n * 4, s));
+    MH_TRY(o.alloc((size_t)n * 4));
+    MH_TRY(depths_dev(a.as<float>(), b.as<float>(), o.as<float>(), n, s));
+    return download(out, o, (size_t)n * 4, s);
+}
+
+int mhip_d8_f64(const double *z, uint8_t *out, int64_t H, int64_t W, int edges_outward)
+{
+    MH_ARG(z && out && H >= 1 && W >= 1, "d8_f64(z, out, H>=1, W>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_z, d_o;
+    MH_TRY(upload(d_z, z, n * 8, s));
+    MH_TRY(d_o.alloc(n));
+    MH_TRY(d8_dev(d_z.as<double>(), d_o.as<uint8_t>(), H, W, edges_outward, s));
+    return download(out, d_o, n, s);
+}
+
+int mhip_accum(const uint8_t *flowdir, double *out, int64_t H, int64_t W)
+{
+    MH_ARG(flowdir && out && H >= 1 && W >= 1, "accum(flowdir, out, H>=1, W>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_fd, d_o;
+    MH_TRY(upload(d_fd, flowdir, n, s));
+    MH_TRY(d_o.alloc(n * 8));
+    MH_TRY(accum_dev(d_fd.as<uint8_t>(), d_o.as<double>(), H, W, s));
+    return download(out, d_o, n * 8, s);
+}
+
+int mhip_ccl8_f32(const float *data, int32_t *labels, int64_t H, int64_t W, int64_t *nlabels)
+{
+    MH_ARG(data && labels && nlabels && H >= 1 && W >= 1, "ccl8_f32(data, labels, H>=1, W>=1, nlabels)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_d, d_l, d_t;
+    MH_TRY(upload(d_d, data, n * 4, s));
+    MH_TRY(d_l.alloc(n * 4));
+    MH_TRY(d_t.alloc(n * 4));
+    MH_TRY(ccl8_f32_dev(d_d.as<float>(), d_l.as<int32_t>(), d_t.as<int32_t>(), H, W, nlabels, s));
+    return download(labels, d_l, n * 4, s);
+}
+
+int mhip_ccl8_u8(const uint8_t *data, int32_t *labels, int64_t H, int64_t W, int64_t *nlabels)
+{
+    MH_ARG(data && labels && nlabels && H >= 1 && W >= 1, "ccl8_u8(data, labels, H>=1, W>=1, nlabels)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_d, d_l, d_t;
+    MH_TRY(upload(d_d, data, n, s));
+    MH_TRY(d_l.alloc(n * 4));
+    MH_TRY(d_t.alloc(n * 4));
+    MH_TRY(ccl8_u8_dev(d_d.as<uint8_t>(), d_l.as<int32_t>(), d_t.as<int32_t>(), H, W, nlabels, s));
+    return download(labels, d_l, n * 4, s);
+}
+
+int mhip_relabel_keep(int32_t *labels, const uint8_t *keep, int64_t nlab, int64_t n, int64_t *nkept)
+{
+    MH_ARG(labels && keep && nlab >= 0 && n >= 1, "relabel_keep(labels, keep, nlab>=0, n>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    std::vector<int32_t> lut;
+    const int64_t kept = build_rank_lut(keep, nlab, lut);
+    DevBuf d_l, d_lut;
+    MH_TRY(upload(d_l, labels, (size_t)n * 4, s));
+    MH_TRY(upload(d_lut, lut.data(), lut.size() * 4, s));
+    MH_TRY(relabel_lut_dev(d_l.as<int32_t>(), d_lut.as<int32_t>(), nlab, n, s));
+    if (nkept) *nkept = kept;
+    return download(labels, d_l, (size_t)n * 4, s);
+}
+
+int mhip_keep_mask(const int32_t *labels, const uint8_t *keep, int64_t nlab, int64_t n, uint8_t *mask)
+{
+    MH_ARG(labels && keep && mask && nlab >= 0 && n >= 1, "keep_mask(labels, keep, nlab>=0, n>=1, mask)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf d_l, d_k, d_m;
+    MH_TRY(upload(d_l, labels, (size_t)n * 4, s));
+    MH_TRY(upload(d_k, keep, (size_t)nlab + 1, s));
+    MH_TRY(d_m.alloc((size_t)n));
+    MH_TRY(keep_mask_dev(d_l.as<int32_t>(), d_k.as<uint8_t>(), nlab, n, d_m.as<uint8_t>(), s));
+    return download(mask, d_m, (size_t)n, s);
+}
+
+int mhip_label_stats_f32(const float *data, const int32_t *labels, int64_t n, int64_t nlab, mhip_stat_record *records)
+{
+    MH_ARG(data && labels && records && n >= 1 && nlab >= 0, "label_stats_f32(data, labels, n>=1, nlab>=0, records)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf d_d, d_l, d_r;
+    MH_TRY(upload(d_d, data, (size_t)n * 4, s));
+    MH_TRY(upload(d_l, labels, (size_t)n * 4, s));
+    MH_TRY(d_r.alloc(sizeof(mhip_stat_record) * (size_t)(nlab + 1)));
+    MH_TRY(label_stats_dev(d_d.as<float>(), d_l.as<int32_t>(), n, nlab, d_r.as<mhip_stat_record>(), s));
+    return download(records, d_r, sizeof(mhip_stat_record) * (size_t)(nlab + 1), s);
+}
+
+static int label_arg_host(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
+                          mhip_index_record *records)
+{
+    MH_ARG(data && labels && records && H >= 1 && W >= 1 && nlab >= 0, "label_arg(data, labels, H>=1, W>=1, nlab>=0, records)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_d, d_l, d_r;
+    MH_TRY(upload(d_d, data, n * 8, s));
+    MH_TRY(upload(d_l, labels, n * 4, s));
+    MH_TRY(d_r.alloc(sizeof(mhip_index_record) * (size_t)(nlab + 1)));
+    MH_TRY(label_arg_dev(d_d.as<double>(), d_l.as<int32_t>(), H, W, nlab, is_max, d_r.as<mhip_index_record>(), s));
+    return download(records, d_r, sizeof(mhip_index_record) * (size_t)(nlab + 1), s);
+}
+
+int mhip_label_argmin_f64(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab,
+                          mhip_index_record *records)
+{
+    return label_arg_host(data, labels, H, W, nlab, false, records);
+}
+int mhip_label_argmax_f64(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab,
+                          mhip_index_record *records)
+{
+    return label_arg_host(data, labels, H, W, nlab, true, records);
+}
+
+int mhip_label_count(const int32_t *labels, int64_t n, int64_t nlab, int64_t *counts)
+{
+    MH_ARG(labels && counts && n >= 1 && nlab >= 0, "label_count(labels, n>=1, nlab>=0, counts)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf d_l, d_c;
+    MH_TRY(upload(d_l, labels, (size_t)n * 4, s));
+    MH_TRY(d_c.alloc(8 * (size_t)(nlab + 1)));
+    MH_TRY(label_count_dev(d_l.as<int32_t>(), n, nlab, d_c.as<int64_t>(), s));
+    return download(counts, d_c, 8 * (size_t)(nlab + 1), s);
+}
+
+int mhip_label_max(const int32_t *labels, int64_t n, int32_t *out_max)
+{
+    MH_ARG(labels && out_max && n >= 1, "label_max(labels, n>=1, out)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf d_l;
+    MH_TRY(upload(d_l, labels, (size_t)n * 4, s));
+    return label_max_dev(d_l.as<int32_t>(), n, out_max, s);
+}
+
+int mhip_watersheds_i32(const uint8_t *flowdir, int32_t *labels, int64_t H, int64_t W, int32_t unassigned)
+{
+    MH_ARG(flowdir && labels && H >= 1 && W >= 1, "watersheds_i32(flowdir, labels, H>=1, W>=1)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    const size_t n = (size_t)(H * W);
+    DevBuf d_fd, d_l;
+    MH_TRY(upload(d_fd, flowdir, n, s));
+    MH_TRY(upload(d_l, labels, n * 4, s));
+    MH_TRY(watersheds_dev(d_fd.as<uint8_t>(), d_l.as<int32_t>(), H, W, unassigned, s));
+    return download(labels, d_l, n * 4, s);
+}
+
+/* ================================================================================================
+ * device-resident pipeline
+ * ================================================================================================ */
+
+struct mhip_ctx {
+    int64_t H = 0, W = 0;   // local band
+    int64_t H_global = 0, row0 = 0;
+    int device = 0, rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;
+    DevBuf r[MHIP_R_COUNT_];
+    bool have[MHIP_R_COUNT_] = {};
+    DevBuf tmp_i32;         // CCL parent scratch
+    DevBuf raw_stats, stats, ws_counts, pour;
+    int64_t nlabels_raw = -1, nlabels = -1;
+    bool labels_filtered = false;
+    double sh = 0, dg = 0;
+    int32_t fill_rounds = 0, noflat_rounds = 0;
+    std::map<int, std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::map<int, bool> ev_valid;
+};
+
+static size_t raster_elem(int which)
+{
+    switch (which) {
+    case MHIP_R_DEM: case MHIP_R_FILLED: case MHIP_R_DEPTHS: case MHIP_R_LABELS: case MHIP_R_WATERSHEDS: return 4;
+    case MHIP_R_NOFLAT: case MHIP_R_ACCUM: return 8;
+    case MHIP_R_FLOWDIR: return 1;
+    default: return 0;
+    }
+}
+
+static int ctx_raster(mhip_ctx *c, int which)
+{
+    if (!c->r[which].p) MH_TRY(c->r[which].alloc(raster_elem(which) * (size_t)(c->H * c->W)));
+    return MHIP_OK;
+}
+
+static int ctx_events(mhip_ctx *c, int stage, hipEvent_t **a, hipEvent_t **b)
+{
+    auto it = c->ev.find(stage);
+    if (it == c->ev.end()) {
+        hipEvent_t e0, e1;
+        MH_HIP(hipEventCreate(&e0));
+        MH_HIP(hipEventCreate(&e1));
+        it = c->ev.emplace(stage, std::make_pair(e0, e1)).first;
+    }
+    *a = &it->second.first;
+    *b = &it->second.second;
+    return MHIP_OK;
+}
+
+int mhip_comm_unique_id(void *id128)
+{
+    (void)id128;
+    set_error("multi-GPU bands are not built into this library yet");
+    return MHIP_ECOMM;
+}
+
+int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t row0, int64_t H_local, int device, int rank,
+                         int nranks, const void *nccl_unique_id)
+{
+    MH_ARG(out && H_global >= 1 && W >= 1 && H_local >= 1 && row0 >= 0 && row0 + H_local <= H_global, "ctx_create_band geometry");
+    (void)nccl_unique_id;
+    if (nranks != 1) {
+        set_error("multi-GPU bands are not built into this library yet");
+        return MHIP_ECOMM;
+    }
+    MH_TRY(require_device());
+    MH_HIP(hipSetDevice(device));
+    mhip_ctx *c = new mhip_ctx();
+    c->H = H_local; c->W = W; c->H_global = H_global; c->row0 = row0;
+    c->device = device; c->rank = rank; c->nranks = nranks;
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        set_error("hipStreamCreate failed");
+        return MHIP_EHIP;
+    }
+    *out = c;
+    return MHIP_OK;
+}
+
+int mhip_ctx_create(mhip_ctx **out, int64_t H, int64_t W, int device)
+{
+    return mhip_ctx_create_band(out, H, W, 0, H, device, 0, 1, nullptr);
+}
+
+int mhip_ctx_destroy(mhip_ctx *c)
+{
+    if (!c) return MHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->ev) {
+        (void)hipEventDestroy(kv.second.first);
+        (void)hipEventDestroy(kv.second.second);
+    }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return MHIP_OK;
+}
+
+int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
+{
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_, "ctx_upload(ctx, which, host)");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, which));
+    MH_HIP(hipMemcpyAsync(c->r[which].p, host, raster_elem(which) * (size_t)(c->H * c->W), hipMemcpyHostToDevice, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    c->have[which] = true;
+    if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; }
+    return MHIP_OK;
+}
+
+int mhip_ctx_upload_dem(mhip_ctx *c, const float *dem) { return mhip_ctx_upload(c, MHIP_R_DEM, dem); }
+
+int mhip_ctx_download(mhip_ctx *c, int which, void *host)
+{
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_, "ctx_download(ctx, which, host)");
+    MH_ARG(c->have[which], "raster has not been computed or uploaded");
+    MH_HIP(hipSetDevice(c->device));
+    MH_HIP(hipMemcpyAsync(host, c->r[which].p, raster_elem(which) * (size_t)(c->H * c->W), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+int mhip_ctx_sync(mhip_ctx *c)
+{
+    MH_ARG(c, "ctx");
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+static int ctx_ensure_labels_final(mhip_ctx *c)
+{
+    if (!c->labels_filtered) return mhip_ctx_apply_keep(c, nullptr);
+    return MHIP_OK;
+}
+
+static int ctx_label_max(mhip_ctx *c)
+{
+    if (c->nlabels < 0) {
+        int32_t m = 0;
+        MH_TRY(label_max_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, &m, c->stream));
+        c->nlabels = m < 0 ? 0 : m;
+    }
+    return MHIP_OK;
+}
+
+int mhip_ctx_run(mhip_ctx *c, int mask)
+{
+    MH_ARG(c, "ctx");
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t H = c->H, W = c->W, n = H * W;
+    hipEvent_t *e0, *e1;
+    for (auto &kv : c->ev_valid) kv.second = false;
+
+    if (mask & MHIP_STAGE_FILL) {
+        MH_ARG(c->have[MHIP_R_DEM], "FILL needs the DEM");
+        MH_TRY(ctx_raster(c, MHIP_R_FILLED));
+        MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
+        MH_TRY(ctx_events(c, MHIP_STAGE_FILL, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        FillStats st;
+        MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st));
+        MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(), n, s));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_FILL] = true;
+        c->fill_rounds = st.rounds;
+        c->have[MHIP_R_FILLED] = c->have[MHIP_R_DEPTHS] = true;
+    }
+    if (mask & MHIP_STAGE_NOFLAT) {
+        MH_ARG(c->have[MHIP_R_DEM], "NOFLAT needs the DEM");
+        MH_TRY(ctx_raster(c, MHIP_R_NOFLAT));
+        MH_TRY(ctx_events(c, MHIP_STAGE_NOFLAT, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), n, &c->sh, &c->dg, s));
+        FillStats st;
+        MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_NOFLAT] = true;
+        c->noflat_rounds = st.rounds;
+        c->have[MHIP_R_NOFLAT] = true;
+    }
+    if (mask & MHIP_STAGE_FLOWDIR) {
+        MH_ARG(c->have[MHIP_R_NOFLAT], "FLOWDIR needs the no-flats surface");
+        MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
+        MH_TRY(ctx_events(c, MHIP_STAGE_FLOWDIR, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), H, W, 1, s));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
+        c->have[MHIP_R_FLOWDIR] = true;
+    }
+    if (mask & MHIP_STAGE_ACCUM) {
+        MH_ARG(c->have[MHIP_R_FLOWDIR], "ACCUM needs flow directions");
+        MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
+        MH_TRY(ctx_events(c, MHIP_STAGE_ACCUM, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), H, W, s));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_ACCUM] = true;
+        c->have[MHIP_R_ACCUM] = true;
+    }
+    if (mask & MHIP_STAGE_LABEL) {
+        MH_ARG(c->have[MHIP_R_DEPTHS], "LABEL needs bluespot depths");
+        MH_TRY(ctx_raster(c, MHIP_R_LABELS));
+        if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)n));
+        MH_TRY(ctx_events(c, MHIP_STAGE_LABEL, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), H, W,
+                            &c->nlabels_raw, s));
+        MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
+        MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
+                               c->raw_stats.as<mhip_stat_record>(), s));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_LABEL] = true;
+        c->have[MHIP_R_LABELS] = true;
+        c->labels_filtered = false;
+        c->nlabels = c->nlabels_raw;
+    }
+    if (mask & MHIP_STAGE_WATERSHED) {
+        MH_ARG(c->have[MHIP_R_LABELS] && c->have[MHIP_R_FLOWDIR], "WATERSHED needs labels and flow directions");
+        MH_TRY(ctx_ensure_labels_final(c));
+        MH_TRY(ctx_label_max(c));
+        MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
+        MH_TRY(ctx_events(c, MHIP_STAGE_WATERSHED, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
+        MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s));
+        MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
+        MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_WATERSHED] = true;
+        c->have[MHIP_R_WATERSHEDS] = true;
+    }
+    if (mask & MHIP_STAGE_POURPOINTS) {
+        MH_ARG(c->have[MHIP_R_LABELS] && (c->have[MHIP_R_ACCUM] || c->have[MHIP_R_NOFLAT]),
+               "POURPOINTS needs labels and accumulated flow or the no-flats surface");
+        MH_TRY(ctx_ensure_labels_final(c));
+        MH_TRY(ctx_label_max(c));
+        MH_TRY(c->pour.alloc(sizeof(mhip_index_record) * (size_t)(c->nlabels + 1)));
+        MH_TRY(ctx_events(c, MHIP_STAGE_POURPOINTS, &e0, &e1));
+        MH_HIP(hipEventRecord(*e0, s));
+        // bluespots.py:195-206: max accumulated flow if available, else min of the no-flats surface
+        if (c->have[MHIP_R_ACCUM])
+            MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, true,
+                                 c->pour.as<mhip_index_record>(), s));
+        else
+            MH_TRY(label_arg_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, false,
+                                 c->pour.as<mhip_index_record>(), s));
+        MH_HIP(hipEventRecord(*e1, s));
+        c->ev_valid[MHIP_STAGE_POURPOINTS] = true;
+    }
+    return MHIP_OK;
+}
+
+int mhip_ctx_stage_ms(mhip_ctx *c, int stage, float *ms)
+{
+    MH_ARG(c && ms, "ctx_stage_ms(ctx, stage, ms)");
+    auto it = c->ev.find(stage);
+    MH_ARG(it != c->ev.end() && c->ev_valid[stage], "stage was not part of the last run");
+    MH_HIP(hipEventSynchronize(it->second.second));
+    MH_HIP(hipEventElapsedTime(ms, it->second.first, it->second.second));
+    return MHIP_OK;
+}
+
+int mhip_ctx_kernel_ms(mhip_ctx *c, const char *kernel, float *ms_total, int32_t *launches)
+{
+    MH_ARG(c && kernel && ms_total && launches, "ctx_kernel_ms(ctx, kernel, ms, launches)");
+    const std::string k(kernel);
+    if (k == "d8") {
+        *launches = 1;
+        return mhip_ctx_stage_ms(c, MHIP_STAGE_FLOWDIR, ms_total);
+    }
+    if (k == "fill_round") {
+        *launches = c->fill_rounds;
+        return mhip_ctx_stage_ms(c, MHIP_STAGE_FILL, ms_total);
+    }
+    if (k == "noflat_round") {
+        *launches = c->noflat_rounds;
+        return mhip_ctx_stage_ms(c, MHIP_STAGE_NOFLAT, ms_total);
+    }
+    set_error("unknown kernel family '%s'", kernel);
+    return MHIP_EINVAL;
+}
+
+int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
+{
+    MH_ARG(c && key && value, "ctx_get_i64(ctx, key, value)");
+    const std::string k(key);
+    if (k == "nlabels_raw") *value = c->nlabels_raw;
+    else if (k == "nlabels") *value = c->nlabels;
+    else if (k == "fill_rounds") *value = c->fill_rounds;
+    else if (k == "noflat_rounds") *value = c->noflat_rounds;
+    else if (k == "H") *value = c->H;
+    else if (k == "W") *value = c->W;
+    else {
+        set_error("unknown key '%s'", key);
+        return MHIP_EINVAL;
+    }
+    return MHIP_OK;
+}
+
+int mhip_ctx_get_f64(mhip_ctx *c, const char *key, double *value)
+{
+    MH_ARG(c && key && value, "ctx_get_f64(ctx, key, value)");
+    const std::string k(key);
+    if (k == "short") *value = c->sh;
+    else if (k == "diag") *value = c->dg;
+    else {
+        set_error("unknown key '%s'", key);
+        return MHIP_EINVAL;
+    }
+    return MHIP_OK;
+}
+
+int mhip_ctx_raw_stats(mhip_ctx *c, mhip_stat_record *records)
+{
+    MH_ARG(c && records && c->raw_stats.p && c->nlabels_raw >= 0, "ctx_raw_stats needs a LABEL run");
+    MH_HIP(hipMemcpyAsync(records, c->raw_stats.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1), hipMemcpyDeviceToHost,
+                          c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+int mhip_ctx_apply_keep(mhip_ctx *c, const uint8_t *keep)
+{
+    MH_ARG(c && c->have[MHIP_R_LABELS] && c->nlabels_raw >= 0 && !c->labels_filtered, "ctx_apply_keep needs a fresh LABEL run");
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t n = c->H * c->W;
+    if (keep) {
+        std::vector<int32_t> lut;
+        c->nlabels = build_rank_lut(keep, c->nlabels_raw, lut);
+        DevBuf d_lut;
+        MH_TRY(d_lut.alloc(lut.size() * 4));
+        MH_HIP(hipMemcpyAsync(d_lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, s));
+        MH_TRY(relabel_lut_dev(c->r[MHIP_R_LABELS].as<int32_t>(), d_lut.as<int32_t>(), c->nlabels_raw, n, s));
+        MH_TRY(c->stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1)));
+        MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels,
+                               c->stats.as<mhip_stat_record>(), s));
+    } else {
+        // keep everything (background excluded by construction): labels and stats are the raw ones
+        c->nlabels = c->nlabels_raw;
+        MH_TRY(c->stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1)));
+        MH_HIP(hipMemcpyAsync(c->stats.p, c->raw_stats.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1),
+                              hipMemcpyDeviceToDevice, s));
+    }
+    c->labels_filtered = true;
+    return MHIP_OK;
+}
+
+int mhip_ctx_stats(mhip_ctx *c, mhip_stat_record *records)
+{
+    MH_ARG(c && records && c->stats.p && c->labels_filtered, "ctx_stats needs LABEL + apply_keep");
+    MH_HIP(hipMemcpyAsync(records, c->stats.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+int mhip_ctx_watershed_counts(mhip_ctx *c, int64_t *counts)
+{
+    MH_ARG(c && counts && c->ws_counts.p, "ctx_watershed_counts needs a WATERSHED run");
+    MH_HIP(hipMemcpyAsync(counts, c->ws_counts.p, 8 * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+int mhip_ctx_pourpoints(mhip_ctx *c, mhip_index_record *records)
+{
+    MH_ARG(c && records && c->pour.p, "ctx_pourpoints needs a POURPOINTS run");
+    MH_HIP(hipMemcpyAsync(records, c->pour.p, sizeof(mhip_index_record) * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+}  // extern "C"

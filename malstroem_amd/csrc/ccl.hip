@@ -1,0 +1,225 @@
+// ccl.hip -- 8-connected component labelling with scipy.ndimage.label numbering (gfx950).
+//
+// Reference: label.connected_components (label.py:19-40) -> scipy.ndimage.label(data, structure=ones((3,3))):
+// foreground = data != 0 (NaN and negatives are foreground), background 0, int32 labels 1..n numbered in the
+// order of each component's FIRST pixel in raster scan.
+//
+// Device schedule: union-find over linear cell indices where the representative of a set is always its
+// minimum index (hooking larger root under smaller with atomicMin), so after flattening the roots are exactly
+// the components' first raster pixels; an exclusive prefix sum over the root flags gives the scipy rank.
+//   1. init   : parent[i] = i (foreground) / -1 (background)
+//   2. merge  : every foreground cell unites with the already-scanned neighbours that are not implied by
+//               another union (N; else W or NW, and NE)
+//   3. flatten: parent[i] = root(i)
+//   4. rank   : per-block root counts -> single-block scan -> roots get -(rank+1)
+//   5. emit   : labels[i] = rank of root(i), 0 for background
+#include "common.hpp"
+
+namespace mh {
+namespace {
+
+constexpr int SCAN_BLOCK = 1024;        // threads
+constexpr int SCAN_ITEMS = 4;           // cells per thread in the rank pass
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+template <typename T> __device__ __forceinline__ bool is_fg(T v) { return v != (T)0; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void ccl_init_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) parent[i] = is_fg(data[i]) ? (int32_t)i : -1;
+}
+
+__device__ __forceinline__ int32_t find_root(const int32_t *parent, int32_t x)
+{
+    int32_t p = parent[x];
+    while (p != x) {
+        x = p;
+        p = parent[x];
+    }
+    return x;
+}
+
+__device__ __forceinline__ void unite(int32_t *parent, int32_t a, int32_t b)
+{
+    for (;;) {
+        a = find_root(parent, a);
+        b = find_root(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            const int32_t t = a;
+            a = b;
+            b = t;
+        }
+        const int32_t old = atomicMin(&parent[a], b);  // hook the larger root under the smaller one
+        if (old == a) return;
+        a = old;  // somebody re-parented a meanwhile: continue from its new (smaller) parent
+    }
+}
+
+__global__ __launch_bounds__(256) void ccl_merge_kernel(int32_t *parent, int64_t H, int64_t W)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    if (parent[i] < 0) return;
+    const int64_t r = i / W, c = i - r * W;
+    const bool hasN = r > 0 && parent[i - W] >= 0;
+    if (hasN) {
+        unite(parent, (int32_t)i, (int32_t)(i - W));  // N is adjacent to W, NW and NE: one union covers them
+        return;
+    }
+    const bool hasW = c > 0 && parent[i - 1] >= 0;
+    const bool hasNW = r > 0 && c > 0 && parent[i - W - 1] >= 0;
+    const bool hasNE = r > 0 && c + 1 < W && parent[i - W + 1] >= 0;
+    if (hasW) unite(parent, (int32_t)i, (int32_t)(i - 1));  // W and NW are vertical neighbours of each other
+    else if (hasNW) unite(parent, (int32_t)i, (int32_t)(i - W - 1));
+    if (hasNE) unite(parent, (int32_t)i, (int32_t)(i - W + 1));
+}
+
+__global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t *parent, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = parent[i];
+    if (p < 0 || p == (int32_t)i) return;
+    parent[i] = find_root(parent, p);
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void ccl_count_roots_kernel(const int32_t *__restrict__ parent, int64_t n,
+                                                                    uint32_t *__restrict__ block_counts)
+{
+    __shared__ uint32_t wsum[SCAN_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        if (i < n) cnt += parent[i] == (int32_t)i;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) t += wsum[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of block_counts (nb entries) by ONE block; total written to *total
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(uint32_t *block_counts, int64_t nb, unsigned long long *total)
+{
+    __shared__ unsigned long long part[1024];
+    const int64_t per = (nb + 1023) / 1024;
+    const int64_t b0 = (int64_t)threadIdx.x * per, b1 = b0 + per < nb ? b0 + per : nb;
+    unsigned long long s = 0;
+    for (int64_t b = b0; b < b1; ++b) s += block_counts[b];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const unsigned long long v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int64_t b = b0; b < b1; ++b) {
+        const uint32_t v = block_counts[b];
+        block_counts[b] = (uint32_t)run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void ccl_rank_roots_kernel(int32_t *parent, int64_t n,
+                                                                   const uint32_t *__restrict__ block_offsets)
+{
+    __shared__ uint32_t wsum[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    bool root[SCAN_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = base + k;
+        root[k] = i < n && parent[i] == (int32_t)i;
+        cnt += root[k];
+    }
+    uint32_t incl = cnt;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    uint32_t rank = block_offsets[blockIdx.x] + woff + incl - cnt;  // roots before this thread
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (root[k]) {
+            ++rank;
+            parent[base + k] = -(int32_t)rank - 1;  // root -> -(label+1); background stays -1
+        }
+}
+
+__global__ __launch_bounds__(256) void ccl_emit_kernel(const int32_t *__restrict__ parent, int32_t *__restrict__ labels,
+                                                      int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t p = parent[i];
+    if (p >= 0) p = parent[p];  // non-root: its (flattened) parent is a ranked root
+    labels[i] = p == -1 ? 0 : -p - 1;
+}
+
+template <typename T>
+int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s)
+{
+    const int64_t n = H * W;
+    if (n >= (int64_t)INT32_MAX - 1) {
+        set_error("connected components: %lld cells exceed the int32 index domain", (long long)n);
+        return MHIP_ELIMIT;
+    }
+    const unsigned g256 = (unsigned)cdiv(n, 256);
+    const int64_t nb = cdiv(n, SCAN_TILE);
+    DevBuf counts, total;
+    MH_TRY(counts.alloc(sizeof(uint32_t) * (size_t)nb));
+    MH_TRY(total.alloc(sizeof(unsigned long long)));
+    int32_t *parent = d_tmp;
+    hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n);
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(g256), dim3(256), 0, s, parent, H, W);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g256), dim3(256), 0, s, parent, n);
+    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, counts.as<uint32_t>(), nb,
+                       total.as<unsigned long long>());
+    hipLaunchKernelGGL(ccl_rank_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
+    hipLaunchKernelGGL(ccl_emit_kernel, dim3(g256), dim3(256), 0, s, parent, d_labels, n);
+    MH_HIP(hipGetLastError());
+    unsigned long long h_total = 0;
+    MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    *nlabels = (int64_t)h_total;
+    return MHIP_OK;
+}
+
+}  // namespace
+
+int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
+                 hipStream_t s)
+{
+    return ccl8_dev<float>(d_data, d_labels, d_tmp, H, W, nlabels, s);
+}
+int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
+                hipStream_t s)
+{
+    return ccl8_dev<uint8_t>(d_data, d_labels, d_tmp, H, W, nlabels, s);
+}
+
+}  // namespace mh

@@ -1,0 +1,140 @@
+// common.hpp -- shared host/device helpers of libmalstroem_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/malstroem_hip.h"
+
+namespace mh {
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+#define MH_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            mh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MHIP_EHIP;                                                                    \
+        }                                                                                        \
+    } while (0)
+
+#define MH_TRY(expr)                \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != MHIP_OK) return _rc; \
+    } while (0)
+
+#define MH_ARG(cond, msg)                   \
+    do {                                    \
+        if (!(cond)) {                      \
+            mh::set_error("invalid argument: %s", msg); \
+            return MHIP_EINVAL;             \
+        }                                   \
+    } while (0)
+
+// ---- device scratch buffer (RAII, stream-ordered free is not needed: all work is on one stream and
+//      we synchronise before releasing) ------------------------------------------------------------
+// Blocks come from a small caching pool (api.hip) so that the iterative stages and repeated pipeline runs do
+// not pay hipMalloc/hipFree (the latter synchronises the device) inside the hot path.
+int pool_alloc(void **p, size_t bytes);
+void pool_free(void *p, size_t bytes);
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t n)
+    {
+        if (n == 0) n = 16;
+        if (p && bytes >= n && bytes <= 2 * n + 4096) return MHIP_OK;  // reuse what we already hold
+        release();
+        MH_TRY(pool_alloc(&p, n));
+        bytes = n;
+        return MHIP_OK;
+    }
+    void release()
+    {
+        if (p) pool_free(p, bytes);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- AGNPS direction codes (reference flow.py:30-38, deltas _flow.pyx:36-46) -------------------
+// code k: U 0, UR 1, R 2, DR 3, D 4, DL 5, L 6, UL 7, NODIR 8
+__host__ __device__ inline int dir_dr(int k) { return (k == 0 || k == 1 || k == 7) ? -1 : (k >= 3 && k <= 5) ? 1 : 0; }
+__host__ __device__ inline int dir_dc(int k) { return (k >= 1 && k <= 3) ? 1 : (k >= 5 && k <= 7) ? -1 : 0; }
+
+// monotone float/double <-> unsigned keys (for atomicMin/Max); NaN must be filtered by the caller
+__host__ __device__ inline uint32_t f32_key(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float key_f32(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+__host__ __device__ inline uint64_t f64_key(double f)
+{
+    uint64_t u;
+    memcpy(&u, &f, 8);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__host__ __device__ inline double key_f64(uint64_t k)
+{
+    uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    double f;
+    memcpy(&f, &u, 8);
+    return f;
+}
+
+// ---- device-pointer stage implementations (one translation unit per stage) --------------------
+struct FillStats {
+    int32_t rounds = 0;
+};
+
+// fill.hip
+int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st);
+int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
+                    FillStats *st);
+int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);
+int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s);
+// d8.hip
+int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s);
+// accum.hip
+int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s);
+// ccl.hip   (d_tmp: H*W int32 scratch)
+int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
+                 hipStream_t s);
+int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
+                hipStream_t s);
+// label_ops.hip
+int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64_t n, hipStream_t s);
+int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask,
+                  hipStream_t s);
+int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
+                    hipStream_t s);
+int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
+                  mhip_index_record *d_rec, hipStream_t s);
+int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s);
+int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
+// watershed.hip
+int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s);
+
+__host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace mh

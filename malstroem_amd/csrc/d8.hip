@@ -1,0 +1,156 @@
+// d8.hip -- D8 flow direction stencil, float64 surface -> uint8 AGNPS codes (gfx950).
+//
+// Reference: flow.terrain_flowdirection (flow.py:142-167) -> _flow.terrain_flow (_flow.pyx:98-176)
+// + set_edges_flow_outward (flow.py:118-139).
+//   interior: i = 8 (NODIR), dzmax = 0.0; for k in U,UR,R,DR,D,DL,L,UL: dz = z - nbr_k, diagonals MULTIPLIED by
+//   INV_SQRT2 = 1/2**0.5 (_flow.pyx:93-94,140); `if dz > dzmax` (strict: the first maximum wins).
+//   border cells: NODIR, or the fixed outward codes when edges_flow_outward.
+//
+// HBM-bound: 8 B read + 1 B written per cell.  One wavefront streams a 256-column strip downwards keeping a
+// rolling 3-row window in registers (each lane owns 4 adjacent columns: two 16-byte loads per row, the
+// left/right neighbour columns come from the adjacent lanes via DPP wave shifts), so every surface row is
+// fetched once per strip and the 4 codes of a lane leave as one 32-bit store.
+#include "common.hpp"
+
+namespace mh {
+namespace {
+
+constexpr int CPL = 4;             // columns per lane
+constexpr int STRIP = 64 * CPL;    // columns per wavefront
+constexpr int ROWS_PER_WAVE = 64;  // rows a wavefront walks down (2 extra halo rows are re-read)
+constexpr int DPP_WF_SL1 = 0x130, DPP_WF_SR1 = 0x138;
+
+__device__ __forceinline__ double lane_from_left(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, DPP_WF_SR1, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, DPP_WF_SR1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_right(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, DPP_WF_SL1, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, DPP_WF_SL1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+struct Row6 {
+    double v[CPL + 2];  // [0] = left neighbour column, [1..4] = own columns, [5] = right neighbour column
+};
+
+// Loads raster row `rr` (clamped into the raster; clamped values are never used for an interior cell).
+__device__ __forceinline__ void load_row(const double *__restrict__ z, int64_t rr, int64_t H, int64_t W, int64_t c,
+                                         int lane, bool fast, Row6 &o)
+{
+    rr = rr < 0 ? 0 : (rr >= H ? H - 1 : rr);
+    const double *row = z + rr * W;
+    if (fast) {
+        const double2 a = *reinterpret_cast<const double2 *>(row + c);
+        const double2 b = *reinterpret_cast<const double2 *>(row + c + 2);
+        o.v[1] = a.x; o.v[2] = a.y; o.v[3] = b.x; o.v[4] = b.y;
+        double l = lane_from_left(o.v[4]), r = lane_from_right(o.v[1]);
+        if (lane == 0) l = row[c > 0 ? c - 1 : 0];
+        if (lane == 63) r = row[c + CPL < W ? c + CPL : W - 1];
+        o.v[0] = l;
+        o.v[5] = r;
+    } else {
+#pragma unroll
+        for (int k = 0; k < CPL + 2; ++k) {
+            int64_t cc = c - 1 + k;
+            cc = cc < 0 ? 0 : (cc >= W ? W - 1 : cc);
+            o.v[k] = row[cc];
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned d8_code(double z, double u, double ur, double r, double dr, double d, double dl,
+                                            double l, double ul)
+{
+    const double INV_SQRT2 = 0.7071067811865475;  // 1 / 2**0.5, _flow.pyx:93-94
+    unsigned i = 8;
+    double dzmax = 0.0, dz;
+    dz = __dsub_rn(z, u);                       if (dz > dzmax) { dzmax = dz; i = 0; }
+    dz = __dmul_rn(__dsub_rn(z, ur), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 1; }
+    dz = __dsub_rn(z, r);                       if (dz > dzmax) { dzmax = dz; i = 2; }
+    dz = __dmul_rn(__dsub_rn(z, dr), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 3; }
+    dz = __dsub_rn(z, d);                       if (dz > dzmax) { dzmax = dz; i = 4; }
+    dz = __dmul_rn(__dsub_rn(z, dl), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 5; }
+    dz = __dsub_rn(z, l);                       if (dz > dzmax) { dzmax = dz; i = 6; }
+    dz = __dmul_rn(__dsub_rn(z, ul), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 7; }
+    return i;
+}
+
+// flow.py:130-139: rows first, then columns overwrite, corners last (same order => same result on 1-wide rasters)
+__device__ __forceinline__ unsigned edge_code(int64_t r, int64_t c, int64_t maxr, int64_t maxc)
+{
+    unsigned code = 8;
+    if (r == 0) code = 0;
+    if (r == maxr) code = 4;
+    if (c == 0) code = 6;
+    if (c == maxc) code = 2;
+    if (r == 0 && c == 0) code = 7;
+    if (r == 0 && c == maxc) code = 1;
+    if (r == maxr && c == 0) code = 5;
+    if (r == maxr && c == maxc) code = 3;
+    return code;
+}
+
+__global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, uint8_t *__restrict__ out, int64_t H,
+                                                int64_t W, int edges_outward)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t strip = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t c0 = strip * STRIP;
+    if (c0 >= W) return;
+    const int64_t c = c0 + (int64_t)lane * CPL;
+    const int64_t r_begin = (int64_t)blockIdx.y * ROWS_PER_WAVE;
+    const int64_t r_end = r_begin + ROWS_PER_WAVE < H ? r_begin + ROWS_PER_WAVE : H;
+    const int64_t maxr = H - 1, maxc = W - 1;
+    // wave-uniform: whole strip inside the raster and rows 16-byte aligned (clamped neighbour columns at the
+    // raster edge are only ever consumed by border cells, whose code does not depend on the surface)
+    const bool fast = (c0 + STRIP <= W) && ((W & 1) == 0);
+    const bool store32 = (c0 + STRIP <= W) && ((W & 3) == 0);
+
+    Row6 up, mid, dn;
+    load_row(z, r_begin - 1, H, W, c, lane, fast, up);
+    load_row(z, r_begin, H, W, c, lane, fast, mid);
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        load_row(z, r + 1, H, W, c, lane, fast, dn);
+        unsigned packed = 0;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int64_t cc = c + j;
+            unsigned code;
+            const bool border = (r == 0) || (r == maxr) || (cc == 0) || (cc >= maxc);
+            if (border)
+                code = edges_outward ? edge_code(r, cc, maxr, maxc) : 8u;
+            else
+                code = d8_code(mid.v[j + 1], up.v[j + 1], up.v[j + 2], mid.v[j + 2], dn.v[j + 2], dn.v[j + 1], dn.v[j],
+                               mid.v[j], up.v[j]);
+            packed |= code << (8 * j);
+        }
+        if (store32) {
+            *reinterpret_cast<uint32_t *>(out + r * W + c) = packed;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                if (c + j < W) out[r * W + c + j] = (uint8_t)(packed >> (8 * j));
+        }
+        up = mid;
+        mid = dn;
+    }
+}
+
+}  // namespace
+
+int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s)
+{
+    const dim3 grid((unsigned)cdiv(cdiv(W, STRIP), 4), (unsigned)cdiv(H, ROWS_PER_WAVE));
+    hipLaunchKernelGGL(d8_kernel, grid, dim3(256), 0, s, d_z, d_out, H, W, edges_outward);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+}  // namespace mh

@@ -1,0 +1,428 @@
+// label_ops.hip -- per-label reductions and label re-mapping (gfx950).
+//
+// Reference:
+//   label.label_stats      _label.pyx:68-97 (python label.py:43-75): min/max (f64), sequential f64 sum, count (i64)
+//   label.label_min_index  _label.pyx:99-128: strict '<', first raster-order occurrence, init (inf,-1,-1)
+//   label.label_max_index  label.py:135-166 : strict '>', first raster-order occurrence, init (-inf,-1,-1)
+//   label.label_count      label.py:169-180 : np.bincount
+//   label.keep_labels      label.py:78-98   : keep[background] = False; mask = keep[labelled]
+//
+// All of them are scatter reductions keyed by label.  Label 0 (background) typically owns ~90 % of the
+// cells, so every kernel first combines equal-label runs inside a wavefront (segmented shuffle reduction)
+// and only the run heads touch global atomics.  min/max go through monotone integer keys; counts are
+// integers; the f64 sum uses global float atomics (order independent whenever every partial sum is exactly
+// representable, which holds for bluespot depths -- SURVEY.md 8a row S; otherwise within 1 ulp-scale
+// rounding of the sequential sum, see tests).
+#include "common.hpp"
+
+namespace mh {
+namespace {
+
+// ---- wave-level segmented combine over runs of equal labels --------------------------------------
+// Lanes are consecutive raster cells; a run is a maximal stretch of lanes with equal label.
+// distance (in lanes) from this lane to the end of its equal-label run (exclusive), computed once per wave
+__device__ __forceinline__ int run_length_from(int32_t lab, int lane, bool valid)
+{
+    // bit i of `brk` set <=> lane i starts a new run
+    const int32_t prev = __shfl_up(lab, 1);
+    const bool prev_valid = __shfl_up((int)valid, 1) != 0;
+    const bool start = (lane == 0) || (lab != prev) || (valid != prev_valid);
+    const uint64_t brk = __ballot(start);
+    // next run start strictly after this lane
+    const uint64_t above = lane == 63 ? 0ull : (brk >> (lane + 1)) << (lane + 1);
+    const int next = above ? __builtin_ctzll(above) : 64;
+    return next - lane;  // >= 1
+}
+
+__device__ __forceinline__ bool is_run_head(int32_t lab, int lane, bool valid)
+{
+    const int32_t prev = __shfl_up(lab, 1);
+    const bool prev_valid = __shfl_up((int)valid, 1) != 0;
+    return (lane == 0) || (lab != prev) || (valid != prev_valid);
+}
+
+// generic segmented suffix-combine: after log2(64) steps lane i holds op over lanes [i, i+len_i)
+template <typename T, typename Op> __device__ __forceinline__ T seg_reduce(T v, int len, Op op)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T ov = __shfl_down(v, o);
+        if (o < len) {
+            // combine only the part that lies inside my run: lanes [i+o, i+min(2o,len))
+            v = op(v, ov);
+        }
+        // after this step lane i covers min(2o, len) lanes provided lane i+o covered min(o, len-o) lanes,
+        // which holds because lane i+o has len' = len - o for lanes of the same run.
+    }
+    return v;
+}
+
+// ---- label_stats ------------------------------------------------------------------------------
+struct StatAcc {
+    uint32_t *minkey;           // f32 ordered keys
+    uint32_t *maxkey;
+    double *sum;
+    unsigned long long *count;
+};
+
+__global__ __launch_bounds__(256) void stats_init_kernel(StatAcc a, int64_t nrec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    a.minkey[i] = f32_key(__builtin_inff());
+    a.maxkey[i] = f32_key(-__builtin_inff());
+    a.sum[i] = 0.0;
+    a.count[i] = 0ull;
+}
+
+// Background (label 0) is accumulated in registers over the whole grid-stride range and leaves as one
+// atomic set per wavefront; other labels leave as one atomic set per equal-label run, and the min/max
+// atomics are skipped when a (possibly stale, hence conservative) read shows they cannot improve the record.
+__global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
+                                                   int64_t n, int64_t nlab, StatAcc a, unsigned int *bad)
+{
+    const int lane = threadIdx.x & 63;
+    float bmin = __builtin_inff(), bmax = -__builtin_inff();
+    double bsum = 0.0;
+    unsigned long long bcnt = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nloop = cdiv(n, stride) * stride;  // keep whole waves in the loop (shuffles need all lanes)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
+        const bool valid = i < n;
+        int32_t l = valid ? lab[i] : -1;
+        const float v = valid ? data[i] : 0.0f;
+        if (valid && (l < 0 || l > nlab)) {
+            atomicOr(bad, 1u);
+            l = -1;
+        }
+        const bool isnan = v != v;
+        // NaN never wins `val < min` / `val > max` in the reference; it does poison the sum.
+        float vmin = isnan ? __builtin_inff() : v, vmax = isnan ? -__builtin_inff() : v;
+        if (__all(l <= 0)) {  // wave-uniform fast path: only background (or padding) in this wave
+            if (l == 0) {
+                bmin = fminf(bmin, vmin);
+                bmax = fmaxf(bmax, vmax);
+                bsum += (double)v;
+                ++bcnt;
+            }
+            continue;
+        }
+        const bool ok = l >= 0;
+        const int len = run_length_from(l, lane, ok);
+        const bool head = is_run_head(l, lane, ok);
+        vmin = seg_reduce(vmin, len, [](float x, float y) { return fminf(x, y); });
+        vmax = seg_reduce(vmax, len, [](float x, float y) { return fmaxf(x, y); });
+        const double s = seg_reduce((double)v, len, [](double x, double y) { return x + y; });
+        if (head && ok) {
+            if (l == 0) {
+                bmin = fminf(bmin, vmin);
+                bmax = fmaxf(bmax, vmax);
+                bsum += s;
+                bcnt += (unsigned long long)len;
+            } else {
+                const uint32_t kmin = f32_key(vmin), kmax = f32_key(vmax);
+                if (kmin < a.minkey[l]) atomicMin(&a.minkey[l], kmin);
+                if (kmax > a.maxkey[l]) atomicMax(&a.maxkey[l], kmax);
+                atomicAdd(&a.sum[l], s);
+                atomicAdd(&a.count[l], (unsigned long long)len);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bmin = fminf(bmin, __shfl_xor(bmin, o));
+        bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+        bsum += __shfl_xor(bsum, o);
+        bcnt += __shfl_xor(bcnt, o);
+    }
+    if (lane == 0 && bcnt) {
+        atomicMin(&a.minkey[0], f32_key(bmin));
+        atomicMax(&a.maxkey[0], f32_key(bmax));
+        atomicAdd(&a.sum[0], bsum);
+        atomicAdd(&a.count[0], bcnt);
+    }
+}
+
+__global__ __launch_bounds__(256) void stats_finish_kernel(StatAcc a, int64_t nrec, mhip_stat_record *rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    mhip_stat_record r;
+    r.min = (double)key_f32(a.minkey[i]);
+    r.max = (double)key_f32(a.maxkey[i]);
+    r.sum = a.sum[i];
+    r.count = (int64_t)a.count[i];
+    rec[i] = r;
+}
+
+// ---- label_min_index / label_max_index ----------------------------------------------------------
+// pass 1: per label extreme of the monotone f64 key (-0.0 folded onto +0.0 so that float equality == key equality)
+// pass 2: smallest linear index whose value equals the extreme
+__device__ __forceinline__ uint64_t arg_key(double v) { return f64_key(v == 0.0 ? 0.0 : v); }
+
+__global__ __launch_bounds__(256) void arg_init_kernel(uint64_t *key, unsigned long long *idx, int64_t nrec, bool is_max)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    key[i] = f64_key(is_max ? -__builtin_inf() : __builtin_inf());
+    idx[i] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void arg_pass1_kernel(const double *__restrict__ data, const int32_t *__restrict__ lab,
+                                                       int64_t n, int64_t nlab, uint64_t *key, bool is_max,
+                                                       unsigned int *bad)
+{
+    const int lane = threadIdx.x & 63;
+    const double ident = is_max ? -__builtin_inf() : __builtin_inf();
+    uint64_t bkey = f64_key(ident);  // background (label 0) extreme, kept in registers
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nloop = cdiv(n, stride) * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
+        const bool valid = i < n;
+        int32_t l = valid ? lab[i] : -1;
+        if (valid && (l < 0 || l > nlab)) {
+            atomicOr(bad, 1u);
+            l = -1;
+        }
+        const double v = valid ? data[i] : 0.0;
+        // NaN never wins a strict compare: map it to the identity
+        uint64_t k = arg_key(v != v ? ident : v);
+        if (__all(l <= 0)) {
+            if (l == 0) bkey = is_max ? (k > bkey ? k : bkey) : (k < bkey ? k : bkey);
+            continue;
+        }
+        const bool ok = l >= 0;
+        const int len = run_length_from(l, lane, ok);
+        const bool head = is_run_head(l, lane, ok);
+        k = is_max ? seg_reduce(k, len, [](uint64_t x, uint64_t y) { return x > y ? x : y; })
+                   : seg_reduce(k, len, [](uint64_t x, uint64_t y) { return x < y ? x : y; });
+        if (head && ok) {
+            if (l == 0) bkey = is_max ? (k > bkey ? k : bkey) : (k < bkey ? k : bkey);
+            else if (is_max) { if (k > key[l]) atomicMax(reinterpret_cast<unsigned long long *>(&key[l]), (unsigned long long)k); }
+            else { if (k < key[l]) atomicMin(reinterpret_cast<unsigned long long *>(&key[l]), (unsigned long long)k); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t ob = __shfl_xor(bkey, o);
+        bkey = is_max ? (ob > bkey ? ob : bkey) : (ob < bkey ? ob : bkey);
+    }
+    if (lane == 0) {
+        if (is_max) atomicMax(reinterpret_cast<unsigned long long *>(&key[0]), (unsigned long long)bkey);
+        else atomicMin(reinterpret_cast<unsigned long long *>(&key[0]), (unsigned long long)bkey);
+    }
+}
+
+__global__ __launch_bounds__(256) void arg_pass2_kernel(const double *__restrict__ data, const int32_t *__restrict__ lab,
+                                                       int64_t n, int64_t nlab, const uint64_t *__restrict__ key,
+                                                       unsigned long long *idx, bool is_max)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = lab[i];
+    if (l < 0 || l > nlab) return;
+    const double v = data[i];
+    if (v != v) return;
+    const uint64_t k = arg_key(v);
+    // the init value (+-inf) is never a strict improvement over the record's own +-inf: skip it like the reference
+    if (k == f64_key(is_max ? -__builtin_inf() : __builtin_inf())) return;
+    // stale reads of idx[] are conservative (the true value is never larger), so skipping on them is safe
+    if (k == key[l] && (unsigned long long)i < idx[l]) atomicMin(&idx[l], (unsigned long long)i);
+}
+
+__global__ __launch_bounds__(256) void arg_finish_kernel(const double *__restrict__ data, const unsigned long long *idx,
+                                                        int64_t nrec, int64_t W, bool is_max, mhip_index_record *rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    mhip_index_record r;
+    const unsigned long long p = idx[i];
+    if (p == ~0ull) {
+        r.value = is_max ? -__builtin_inf() : __builtin_inf();
+        r.row = -1;
+        r.col = -1;
+    } else {
+        r.value = data[p];
+        r.row = (int64_t)(p / (unsigned long long)W);
+        r.col = (int64_t)(p % (unsigned long long)W);
+    }
+    rec[i] = r;
+}
+
+// ---- bincount / max / lut / mask -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_kernel(const int32_t *__restrict__ lab, int64_t n, int64_t nlab,
+                                                   unsigned long long *counts, unsigned int *bad)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long bcnt = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nloop = cdiv(n, stride) * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
+        const bool valid = i < n;
+        int32_t l = valid ? lab[i] : -1;
+        if (valid && (l < 0 || l > nlab)) {
+            atomicOr(bad, 1u);
+            l = -1;
+        }
+        if (__all(l <= 0)) {
+            bcnt += l == 0;
+            continue;
+        }
+        const bool ok = l >= 0;
+        const int len = run_length_from(l, lane, ok);
+        if (is_run_head(l, lane, ok) && ok) {
+            if (l == 0) bcnt += (unsigned long long)len;
+            else atomicAdd(&counts[l], (unsigned long long)len);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bcnt += __shfl_xor(bcnt, o);
+    if (lane == 0 && bcnt) atomicAdd(&counts[0], bcnt);
+}
+
+__global__ __launch_bounds__(256) void max_kernel(const int32_t *__restrict__ lab, int64_t n, int *out)
+{
+    int m = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = lab[i] > m ? lab[i] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int v = __shfl_xor(m, o);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__global__ __launch_bounds__(256) void lut_kernel(int32_t *lab, const int32_t *__restrict__ lut, int64_t nlab, int64_t n,
+                                                 unsigned int *bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = lab[i];
+    if (l < 0 || l > nlab) {
+        atomicOr(bad, 1u);
+        return;
+    }
+    if (l != 0) lab[i] = lut[l];
+}
+
+__global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ lab, const uint8_t *__restrict__ keep,
+                                                  int64_t nlab, int64_t n, uint8_t *mask, unsigned int *bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = lab[i];
+    if (l < 0 || l > nlab) {
+        atomicOr(bad, 1u);
+        return;
+    }
+    mask[i] = keep[l] ? 1 : 0;  // the caller has already cleared keep[background]
+}
+
+// grid for the grid-stride reductions: 256 CUs x 8 blocks
+unsigned stride_grid(int64_t n) { return (unsigned)(cdiv(n, 256) < 2048 ? cdiv(n, 256) : 2048); }
+
+int check_bad(DevBuf &bad, hipStream_t s, const char *what)
+{
+    unsigned int h = 0;
+    MH_HIP(hipMemcpyAsync(&h, bad.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    if (h) {
+        set_error("%s: label outside [0, nlabels]", what);
+        return MHIP_EINVAL;
+    }
+    return MHIP_OK;
+}
+
+}  // namespace
+
+int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
+                    hipStream_t s)
+{
+    const int64_t nrec = nlab + 1;
+    DevBuf mn, mx, sm, ct, bad;
+    MH_TRY(mn.alloc(4 * (size_t)nrec));
+    MH_TRY(mx.alloc(4 * (size_t)nrec));
+    MH_TRY(sm.alloc(8 * (size_t)nrec));
+    MH_TRY(ct.alloc(8 * (size_t)nrec));
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    StatAcc a{mn.as<uint32_t>(), mx.as<uint32_t>(), sm.as<double>(), ct.as<unsigned long long>()};
+    hipLaunchKernelGGL(stats_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
+    hipLaunchKernelGGL(stats_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_data, d_labels, n, nlab, a,
+                       bad.as<unsigned int>());
+    hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "label_stats");
+}
+
+int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
+                  mhip_index_record *d_rec, hipStream_t s)
+{
+    const int64_t nrec = nlab + 1, n = H * W;
+    DevBuf key, idx, bad;
+    MH_TRY(key.alloc(8 * (size_t)nrec));
+    MH_TRY(idx.alloc(8 * (size_t)nrec));
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    const unsigned gr = (unsigned)cdiv(nrec, 256), gn = (unsigned)cdiv(n, 256);
+    hipLaunchKernelGGL(arg_init_kernel, dim3(gr), dim3(256), 0, s, key.as<uint64_t>(), idx.as<unsigned long long>(), nrec, is_max);
+    hipLaunchKernelGGL(arg_pass1_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_data, d_labels, n, nlab, key.as<uint64_t>(), is_max,
+                       bad.as<unsigned int>());
+    hipLaunchKernelGGL(arg_pass2_kernel, dim3(gn), dim3(256), 0, s, d_data, d_labels, n, nlab, key.as<uint64_t>(),
+                       idx.as<unsigned long long>(), is_max);
+    hipLaunchKernelGGL(arg_finish_kernel, dim3(gr), dim3(256), 0, s, d_data, idx.as<unsigned long long>(), nrec, W, is_max,
+                       d_rec);
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "label_min/max_index");
+}
+
+int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s)
+{
+    DevBuf bad;
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    MH_HIP(hipMemsetAsync(d_counts, 0, 8 * (size_t)(nlab + 1), s));
+    hipLaunchKernelGGL(count_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_labels, n, nlab,
+                       reinterpret_cast<unsigned long long *>(d_counts), bad.as<unsigned int>());
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "label_count");
+}
+
+int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s)
+{
+    DevBuf m;
+    MH_TRY(m.alloc(4));
+    const int init = INT32_MIN;
+    MH_HIP(hipMemcpyAsync(m.p, &init, 4, hipMemcpyHostToDevice, s));
+    const unsigned grid = (unsigned)(cdiv(n, 256) < 8192 ? cdiv(n, 256) : 8192);
+    hipLaunchKernelGGL(max_kernel, dim3(grid), dim3(256), 0, s, d_labels, n, m.as<int>());
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(out_max, m.p, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
+}
+
+int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64_t n, hipStream_t s)
+{
+    DevBuf bad;
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    hipLaunchKernelGGL(lut_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_labels, d_lut, nlab, n,
+                       bad.as<unsigned int>());
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "relabel_keep");
+}
+
+int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask, hipStream_t s)
+{
+    DevBuf bad;
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_labels, d_keep, nlab, n, d_mask,
+                       bad.as<unsigned int>());
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "keep_labels");
+}
+
+}  // namespace mh

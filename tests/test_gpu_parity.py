@@ -1,0 +1,191 @@
+"""GPU parity tests: every HIP stage (through the C-ABI / malstroem_amd.algorithms) against
+  * the reference's golden rasters and the pure-Python reference goldens (bit-exact), and
+  * the CPU oracle on seeded synthetic inputs at sizes the oracle finishes in seconds.
+Tolerances: bit-exact everywhere (uint8 flow directions, int32 labels / watersheds, integer-valued float64
+accumulation, float32 filled surface, float64 no-flats surface); label_stats `sum` is compared exactly too
+and, where the reference's own sequential sum is inexact, within 1e-12 relative.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from _cases import PYREF_CASES, fbm, fixtures, pyref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def alg():
+    import malstroem_amd.algorithms as a
+    assert a.hip.available, "HIP library / device missing: the product has no CPU fallback"
+    return a
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return fixtures()
+
+
+def test_native_library_is_loaded(alg):
+    from malstroem_amd import _lib
+    assert _lib.load().mhip_device_count() >= 1
+    assert b"gfx950" in _lib.load().mhip_version()
+
+
+# ---- reference fixtures (reference tests/test_raster_{fill,flowdir,label}.py) -------------------------
+
+def test_fill_reference_golden(alg, fx):
+    filled = alg.fill.fill_terrain(fx["dtm"])
+    assert filled.dtype == np.float32 and np.array_equal(filled, fx["filled"])
+    assert filled.max() == fx["dtm"].max()
+
+
+def test_noflats_reference_golden(alg, fx):
+    short, diag = alg.fill.minimum_safe_short_and_diag(fx["dtm"])
+    assert (short, diag) == (7.275957614183426e-12, 1.0289757937229989e-11)
+    fnf = alg.fill.fill_terrain_no_flats(fx["dtm"], short, diag)
+    assert fnf.dtype == np.float64 and np.array_equal(fnf, fx["filled_no_flats"])
+    assert fnf.max() <= fx["dtm"].max() + sum(fx["dtm"].shape) * diag
+
+
+def test_depths_reference_golden(alg, fx):
+    assert np.array_equal(alg.fill.bluespot_depths(fx["filled"], fx["dtm"]), fx["depths"])
+
+
+def test_flowdir_reference_golden(alg, fx):
+    fd = alg.flow.terrain_flowdirection(fx["filled_no_flats"])
+    assert fd.dtype == np.uint8 and np.array_equal(fd, fx["flowdir_noflats"])
+    with pytest.raises(ValueError):
+        alg.flow.terrain_flowdirection(fx["filled"])   # float32 is rejected like _flow.pyx:99
+
+
+def test_trace_and_upstream_known_answers(alg, fx):
+    # reference tests/test_raster_flowdir.py:28-46
+    fd = alg.flow.terrain_flowdirection(fx["filled_no_flats"])
+    trace = list(alg.flow.trace_downstream(fd, (100, 100)))
+    assert len(trace) == 100 and trace[-1] == (187, 83)
+    seen, stack = set(), [(186, 82)]
+    while stack:
+        c = stack.pop()
+        seen.add(c)
+        stack.extend(alg.flow.upstream_cells(fd, c))
+    assert len(seen) == 5267
+
+
+def test_accum_reference_known_answers(alg, fx):
+    acc = alg.flow.accumulated_flow(fx["flowdir_noflats"])
+    assert acc.dtype == np.float64
+    assert acc.min() >= 1 and acc.max() == 11158 and acc.sum() == 3578615
+    assert np.array_equal(acc, oracle.accumulated_flow(fx["flowdir_noflats"]))
+
+
+def test_watersheds_reference_golden(alg, fx):
+    for dtype in (np.int32, np.int64, np.uint32):   # reference tests/test_raster_flowdir.py:73-140
+        ws = fx["labelled"].astype(dtype)
+        alg.flow.watersheds_from_labels(fx["flowdir_noflats"], ws, unassigned=0)
+        assert ws.dtype == dtype and np.array_equal(ws, fx["wsheds"])
+    assert ws.sum() == 2337891
+
+
+def test_ccl_reference_known_answers(alg, fx):
+    lab, n = alg.label.connected_components(fx["filled_no_flats"] - fx["filled"])
+    assert lab.dtype == np.int32 and n == 525
+    assert (lab == 0).sum() == 40029 and lab.sum() == 1561377
+
+
+def test_label_stats_reference(alg, fx):
+    st = alg.label.label_stats(fx["depths"], fx["labelled"])
+    ref = oracle.label_stats(fx["depths"], fx["labelled"])
+    assert len(st) == fx["labelled"].max() + 1 and st["count"].sum() == fx["labelled"].size
+    for f in ("min", "max", "sum", "count"):
+        assert np.array_equal(st[f], ref[f]), f
+
+
+def test_label_index_reference(alg, fx):
+    acc = oracle.accumulated_flow(fx["flowdir_noflats"])
+    mi = alg.label.label_min_index(fx["filled_no_flats"], fx["labelled"])
+    ma = alg.label.label_max_index(acc, fx["labelled"], int(fx["labelled"].max()))
+    rmi = oracle.label_min_index(fx["filled_no_flats"], fx["labelled"])
+    rma = oracle.label_max_index(acc, fx["labelled"])
+    for f in ("value", "row", "col"):
+        assert np.array_equal(mi[f], rmi[f]) and np.array_equal(ma[f], rma[f]), f
+
+
+# ---- pure-Python reference goldens ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", PYREF_CASES)
+def test_chain_equals_python_reference(alg, name):
+    g = pyref(name)
+    dem = g["dem"]
+    filled = alg.fill.fill_terrain(dem)
+    assert np.array_equal(filled, g["filled"])
+    assert np.array_equal(alg.fill.bluespot_depths(filled, dem), g["depths"])
+    short, diag = alg.fill.minimum_safe_short_and_diag(dem)
+    assert [short, diag] == g["short_diag"].tolist()
+    fnf = alg.fill.fill_terrain_no_flats(dem, short, diag)
+    assert np.array_equal(fnf, g["filled_no_flats"])
+    fd = alg.flow.terrain_flowdirection(fnf)
+    assert np.array_equal(fd, g["flowdir"])   # multiply (cython) == divide (python) on these inputs, see oracle test
+    assert np.array_equal(alg.flow.terrain_flowdirection(fnf, edges_flow_outward=False), g["flowdir_edges_nodir"])
+    assert np.array_equal(alg.flow.terrain_flowdirection(filled.astype(np.float64)), g["flowdir_of_filled"])
+    assert np.array_equal(alg.flow.accumulated_flow(fd), g["accum"])
+    raw, n = alg.label.connected_components(g["depths"])
+    assert n == int(g["raw_nlabels"]) and np.array_equal(raw, g["raw_labels"])
+    st = alg.label.label_stats(g["depths"], raw)
+    for f in ("min", "max", "sum", "count"):
+        assert np.array_equal(st[f], g["raw_stats"][f]), f
+    mask = alg.label.keep_labels(raw, list(g["keepers"]))
+    assert mask.dtype == bool and np.array_equal(mask, g["keep_mask"])
+    lab, nl = alg.label.connected_components(mask)
+    assert nl == int(g["nlabels"]) and np.array_equal(lab, g["labeled"])
+    ws = lab.copy()
+    alg.flow.watersheds_from_labels(fd, ws, 0)
+    assert np.array_equal(ws, g["watersheds"])
+    assert np.array_equal(alg.label.label_count(ws), g["watershed_counts"])
+    mi = alg.label.label_min_index(fnf, lab, nl)
+    ma = alg.label.label_max_index(g["accum"], lab, nl)
+    for f in ("value", "row", "col"):
+        assert np.array_equal(mi[f], g["min_index"][f]), f
+        assert np.array_equal(ma[f], g["max_index"][f]), f
+
+
+# ---- seeded synthetic inputs vs the oracle -----------------------------------------------------------------
+
+SYNTH = [("fbm512_b2", 512, 512, 2.0, 42), ("fbm700x450_b3", 700, 450, 3.0, 7), ("fbm1024_b2", 1024, 1024, 2.0, 1)]
+
+
+@pytest.mark.parametrize("name,h,w,beta,seed", SYNTH)
+def test_chain_equals_oracle(alg, name, h, w, beta, seed):
+    dem = fbm(h, w, beta=beta, seed=seed)
+    filled = alg.fill.fill_terrain(dem)
+    assert np.array_equal(filled, oracle.fill_terrain(dem))
+    short, diag = alg.fill.minimum_safe_short_and_diag(dem)
+    assert (short, diag) == oracle.minimum_safe_short_and_diag(dem)
+    fnf = alg.fill.fill_terrain_no_flats(dem, short, diag)
+    assert np.array_equal(fnf, oracle.fill_terrain_no_flats(dem, short, diag))
+    fd = alg.flow.terrain_flowdirection(fnf)
+    assert np.array_equal(fd, oracle.terrain_flowdirection(fnf))
+    acc = alg.flow.accumulated_flow(fd)
+    assert np.array_equal(acc, oracle.accumulated_flow(fd))
+    depths = alg.fill.bluespot_depths(filled, dem)
+    assert np.array_equal(depths, oracle.depths(filled, dem))
+    raw, n = alg.label.connected_components(depths)
+    oraw, on = oracle.connected_components(depths)
+    assert n == on and np.array_equal(raw, oraw)
+    st, ost = alg.label.label_stats(depths, raw), oracle.label_stats(depths, raw)
+    for f in ("min", "max", "count"):
+        assert np.array_equal(st[f], ost[f]), f
+    assert np.allclose(st["sum"], ost["sum"], rtol=1e-12, atol=0)
+    keep = (ost["count"] >= 5) & (ost["max"] > 0.05)
+    lab, nl = alg.label.connected_components(alg.label.keep_labels(raw, list(keep)))
+    olab, onl = oracle.connected_components(oracle.keep_labels(oraw, list(keep)))
+    assert nl == onl and np.array_equal(lab, olab)
+    ws, ows = lab.copy(), olab.copy()
+    alg.flow.watersheds_from_labels(fd, ws, 0)
+    oracle.watersheds_from_labels(fd, ows, 0)
+    assert np.array_equal(ws, ows)
+    assert np.array_equal(alg.label.label_count(ws), oracle.label_count(ows))
+    for a, b in ((alg.label.label_min_index(fnf, lab, nl), oracle.label_min_index(fnf, lab, nl)),
+                 (alg.label.label_max_index(acc, lab, nl), oracle.label_max_index(acc, lab, nl))):
+        for f in ("value", "row", "col"):
+            assert np.array_equal(a[f], b[f]), f

@@ -374,6 +374,7 @@ struct mhip_ctx {
     bool labels_filtered = false;
     double sh = 0, dg = 0;
     int32_t fill_rounds = 0, noflat_rounds = 0;
+    FillStats fill_st, noflat_st;
     std::map<int, std::pair<hipEvent_t, hipEvent_t>> ev;
     std::map<int, bool> ev_valid;
 };
@@ -511,7 +512,6 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     hipStream_t s = c->stream;
     const int64_t H = c->H, W = c->W, n = H * W;
     hipEvent_t *e0, *e1;
-    for (auto &kv : c->ev_valid) kv.second = false;
 
     if (mask & MHIP_STAGE_FILL) {
         MH_ARG(c->have[MHIP_R_DEM], "FILL needs the DEM");
@@ -525,6 +525,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_HIP(hipEventRecord(*e1, s));
         c->ev_valid[MHIP_STAGE_FILL] = true;
         c->fill_rounds = st.rounds;
+        c->fill_st = st;
         c->have[MHIP_R_FILLED] = c->have[MHIP_R_DEPTHS] = true;
     }
     if (mask & MHIP_STAGE_NOFLAT) {
@@ -538,6 +539,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_HIP(hipEventRecord(*e1, s));
         c->ev_valid[MHIP_STAGE_NOFLAT] = true;
         c->noflat_rounds = st.rounds;
+        c->noflat_st = st;
         c->have[MHIP_R_NOFLAT] = true;
     }
     if (mask & MHIP_STAGE_FLOWDIR) {
@@ -617,7 +619,7 @@ int mhip_ctx_stage_ms(mhip_ctx *c, int stage, float *ms)
 {
     MH_ARG(c && ms, "ctx_stage_ms(ctx, stage, ms)");
     auto it = c->ev.find(stage);
-    MH_ARG(it != c->ev.end() && c->ev_valid[stage], "stage was not part of the last run");
+    MH_ARG(it != c->ev.end() && c->ev_valid[stage], "stage has not been run");
     MH_HIP(hipEventSynchronize(it->second.second));
     MH_HIP(hipEventElapsedTime(ms, it->second.first, it->second.second));
     return MHIP_OK;
@@ -651,6 +653,11 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "nlabels") *value = c->nlabels;
     else if (k == "fill_rounds") *value = c->fill_rounds;
     else if (k == "noflat_rounds") *value = c->noflat_rounds;
+    else if (k == "fill_visits") *value = c->fill_st.visits;
+    else if (k == "fill_cycles") *value = c->fill_st.cycles;
+    else if (k == "fill_tiles") *value = c->fill_st.tiles;
+    else if (k == "noflat_visits") *value = c->noflat_st.visits;
+    else if (k == "noflat_cycles") *value = c->noflat_st.cycles;
     else if (k == "H") *value = c->H;
     else if (k == "W") *value = c->W;
     else {

@@ -104,7 +104,10 @@ __host__ __device__ inline double key_f64(uint64_t k)
 
 // ---- device-pointer stage implementations (one translation unit per stage) --------------------
 struct FillStats {
-    int32_t rounds = 0;
+    int32_t rounds = 0;   // kernel launches (tile rounds)
+    int64_t visits = 0;   // tile visits over all rounds
+    int64_t cycles = 0;   // local (down, up, right, left) cycles over all visits
+    int64_t tiles = 0;    // tiles in the raster
 };
 
 // fill.hip

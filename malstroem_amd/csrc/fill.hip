@@ -150,7 +150,8 @@ template <> struct Inf<double> { static __device__ __forceinline__ double v() { 
 template <typename WT, bool NOFLAT>
 __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(const float *__restrict__ dem, WT *__restrict__ W, int64_t H,
                                                         int64_t Wd, int ntr, int ntc, uint8_t *cur, uint8_t *nxt,
-                                                        unsigned int *counter, int first_round, double sh, double dg)
+                                                        unsigned int *counter, int first_round, double sh, double dg,
+                                                        unsigned long long *stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63;
@@ -206,7 +207,9 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(const f
 
     uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;
     bool capped = true;
+    int ncyc = 0;
     for (int cyc = 0; cyc < MAXCYC; ++cyc) {
+        ++ncyc;
         uint64_t a1 = 0, a2 = 0;
         if constexpr (NOFLAT) {
             pass_noflat<true>(w, d, upd, sh, dg, a1, topN, botN);
@@ -235,6 +238,10 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(const f
     }
 
     const bool changed = (anyN | anyT) != 0;
+    if (lane == 0) {  // schedule statistics: tile visits, local cycles
+        atomicAdd(&stats[0], 1ull);
+        atomicAdd(&stats[1], (unsigned long long)ncyc);
+    }
     if (changed || first_round) {
         // interior write-back.  Raster border cells never move: they are written once (first round, straight
         // from dem, including row 0 / column 0 which only ever sit in a halo ring) and skipped afterwards.
@@ -300,7 +307,10 @@ int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, dou
     const int ntr = (int)cdiv(H - 2, TI), ntc = (int)cdiv(W - 2, TI);
     const int64_t nt = (int64_t)ntr * ntc;
     constexpr int BATCH = 8;
-    DevBuf flags, counters;
+    DevBuf flags, counters, statbuf;
+    MH_TRY(statbuf.alloc(16));
+    MH_HIP(hipMemsetAsync(statbuf.p, 0, 16, s));
+    unsigned long long *d_stats = statbuf.as<unsigned long long>();
     MH_TRY(flags.alloc((size_t)nt * 2));
     MH_TRY(counters.alloc(sizeof(unsigned int) * BATCH));
     MH_HIP(hipMemsetAsync(flags.p, 0, (size_t)nt * 2, s));
@@ -315,7 +325,7 @@ int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, dou
     unsigned int h_cnt[BATCH];
     // round 0 initialises every tile; then batches of BATCH rounds between host checks
     MH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * BATCH, s));
-    hipLaunchKernelGGL(kern, grid, block, lds, s, d_dem, d_out, H, W, ntr, ntc, fl[0], fl[1], cnt, 1, sh, dg);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, d_dem, d_out, H, W, ntr, ntc, fl[0], fl[1], cnt, 1, sh, dg, d_stats);
     MH_HIP(hipGetLastError());
     round = 1;
     MH_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
@@ -326,7 +336,7 @@ int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, dou
         MH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * BATCH, s));
         for (int b = 0; b < BATCH; ++b) {
             uint8_t *cur = fl[(round + b) & 1], *nxt = fl[(round + b + 1) & 1];
-            hipLaunchKernelGGL(kern, grid, block, lds, s, d_dem, d_out, H, W, ntr, ntc, cur, nxt, cnt + b, 0, sh, dg);
+            hipLaunchKernelGGL(kern, grid, block, lds, s, d_dem, d_out, H, W, ntr, ntc, cur, nxt, cnt + b, 0, sh, dg, d_stats);
         }
         MH_HIP(hipGetLastError());
         MH_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(unsigned int) * BATCH, hipMemcpyDeviceToHost, s));
@@ -344,7 +354,15 @@ int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, dou
             return MHIP_ENOTCONV;
         }
     }
-    if (st) st->rounds = round;
+    if (st) {
+        unsigned long long h_stats[2] = {0, 0};
+        MH_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));
+        st->rounds = round;
+        st->visits = (int64_t)h_stats[0];
+        st->cycles = (int64_t)h_stats[1];
+        st->tiles = nt;
+    }
     return MHIP_OK;
 }
 

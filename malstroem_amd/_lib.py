@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libmalstroem_hip.so"
+LIB_PATH = Path(os.environ.get("MALSTROEM_HIP_LIB", _PKG / "lib" / "libmalstroem_hip.so"))  # override: dev builds
 CSRC = _PKG / "csrc"
 
 STAT_DTYPE = np.dtype([("min", "<f8"), ("max", "<f8"), ("sum", "<f8"), ("count", "<i8")])   # _label.pyx:22-24

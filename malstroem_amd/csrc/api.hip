@@ -172,9 +172,13 @@ int mhip_fill_noflat_f64(const float *dem, double *out, int64_t H, int64_t W, do
     DevBuf d_dem, d_out;
     MH_TRY(upload(d_dem, dem, n * 4, s));
     MH_TRY(d_out.alloc(n * 8));
-    FillStats st;
-    MH_TRY(fill_noflat_dev(d_dem.as<float>(), d_out.as<double>(), H, W, short_, diag, s, &st));
-    if (out_rounds) *out_rounds = st.rounds;
+    // plain fill first: it seeds the no-flats iteration with a rigorous upper bound (see fill_noflat_dev)
+    DevBuf d_filled;
+    MH_TRY(d_filled.alloc(n * 4));
+    FillStats st0, st;
+    MH_TRY(fill_plain_dev(d_dem.as<float>(), d_filled.as<float>(), H, W, s, &st0));
+    MH_TRY(fill_noflat_dev(d_dem.as<float>(), d_out.as<double>(), H, W, short_, diag, s, &st, d_filled.as<float>()));
+    if (out_rounds) *out_rounds = st.rounds + st0.rounds;
     return download(out, d_out, n * 8, s);
 }
 
@@ -466,6 +470,9 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
     MH_HIP(hipMemcpyAsync(c->r[which].p, host, raster_elem(which) * (size_t)(c->H * c->W), hipMemcpyHostToDevice, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     c->have[which] = true;
+    if (which == MHIP_R_DEM)  // a new DEM invalidates everything derived from the previous one
+        for (int k = 0; k < MHIP_R_COUNT_; ++k)
+            if (k != MHIP_R_DEM) c->have[k] = false;
     if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; }
     return MHIP_OK;
 }
@@ -535,7 +542,14 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_HIP(hipEventRecord(*e0, s));
         MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), n, &c->sh, &c->dg, s));
         FillStats st;
-        MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st));
+        if (!c->have[MHIP_R_FILLED]) {  // the plain fill seeds the no-flats iteration (fill_noflat_dev)
+            MH_TRY(ctx_raster(c, MHIP_R_FILLED));
+            FillStats st0;
+            MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st0));
+            c->have[MHIP_R_FILLED] = true;
+        }
+        MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st,
+                               c->r[MHIP_R_FILLED].as<float>()));
         MH_HIP(hipEventRecord(*e1, s));
         c->ev_valid[MHIP_STAGE_NOFLAT] = true;
         c->noflat_rounds = st.rounds;

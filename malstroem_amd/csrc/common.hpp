@@ -113,7 +113,7 @@ struct FillStats {
 // fill.hip
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                    FillStats *st);
+                    FillStats *st, const float *d_filled = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);
 int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s);
 // d8.hip

@@ -28,7 +28,13 @@ namespace {
 
 constexpr int WN = 64;  // window edge (tile + halo)
 constexpr int TI = 62;  // tile interior edge
-constexpr int MAXCYC = 6;
+#ifndef MH_MAXCYC
+#define MH_MAXCYC 2
+#endif
+#ifndef MH_ROW_BARRIER
+#define MH_ROW_BARRIER 1
+#endif
+constexpr int MAXCYC = MH_MAXCYC;
 constexpr int DPP_WF_SL1 = 0x130;  // lane i <- lane i+1
 constexpr int DPP_WF_SR1 = 0x138;  // lane i <- lane i-1
 
@@ -74,7 +80,9 @@ __device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN],
         any |= ch;
         if (r == 1) first |= ch;
         if (r == TI) last |= ch;
+#if MH_ROW_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
+#endif
     }
 }
 
@@ -99,7 +107,9 @@ __device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN
         any |= ch;
         if (r == 1) first |= ch;
         if (r == TI) last |= ch;
+#if MH_ROW_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
+#endif
     }
 }
 
@@ -144,147 +154,221 @@ template <typename WT> struct Inf;
 template <> struct Inf<float> { static __device__ __forceinline__ float v() { return __builtin_inff(); } };
 template <> struct Inf<double> { static __device__ __forceinline__ double v() { return __builtin_inf(); } };
 
-// ---- one round: every active tile is visited by one wavefront -------------------------------------
-// flags: cur[t] != 0 => tile t must be visited this round; visited tiles clear cur[t] and raise nxt[] of the
-// neighbours whose halo they changed.  counter += number of raised flags (0 => converged).
-template <typename WT, bool NOFLAT>
-__global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(const float *__restrict__ dem, WT *__restrict__ W, int64_t H,
-                                                        int64_t Wd, int ntr, int ntc, uint8_t *cur, uint8_t *nxt,
-                                                        unsigned int *counter, int first_round, double sh, double dg,
-                                                        unsigned long long *stats)
+// ---- one round: a resident grid of wavefronts pulls the active tiles from sharded worklists ----------------
+// Round k consumes list[k&1][shard][..] (count[k][shard] entries) and appends the tiles whose halo it changed to
+// list[(k+1)&1][shard'] where shard' = tile % NSHARD; mark[][] de-duplicates appends (a tile clears its own mark
+// when it is visited).  Wave g starts pulling at shard g % NSHARD and walks the other shards when its own runs dry,
+// so the work is balanced while every queue head / append counter only sees 1/NSHARD of the traffic (one shared
+// word saturates at ~90 atomics per microsecond on this chip).  sum(count[k+1][*]) == 0  <=>  converged.
+constexpr int NSHARD = 8;
+struct RoundArgs {
+    int64_t H, Wd;
+    int ntr, ntc;
+    int shard_cap;              // list capacity per shard
+    int *list_cur, *list_nxt;   // [NSHARD][shard_cap]
+    unsigned int *mark_cur, *mark_nxt;
+    unsigned int *count_cur, *count_nxt, *head;   // [NSHARD] each, per round
+    double sh, dg, seed_add;
+    unsigned long long *stats;  // [64][2] sharded {visits, local cycles}
+};
+enum { INIT_NONE = 0, INIT_INF = 1, INIT_SEED = 2 };
+
+template <typename WT, bool NOFLAT, int INIT>
+__device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__restrict__ dem, const float *__restrict__ seed,
+                                           WT *__restrict__ W, int64_t tile, uint32_t *scr, int lane, unsigned &visits,
+                                           unsigned &cycles)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform => scalar addressing below
-    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-    if (tile >= (int64_t)ntr * ntc) return;
-    if (!first_round) {
-        if (cur[tile] == 0) return;  // wave-uniform
-        if (lane == 0) cur[tile] = 0;
-    }
-    uint32_t *scr = lds + wave * (WN * (WN + 1));
+    const int64_t H = a.H, Wd = a.Wd;
+    const int ntr = a.ntr, ntc = a.ntc;
+    constexpr bool first_round = INIT != INIT_NONE;  // compile time: keeps the 128 row loads straight-line
     const int ti = (int)(tile / ntc), tj = (int)(tile % ntc);
     const int64_t r0 = (int64_t)ti * TI, c0 = (int64_t)tj * TI;  // raster coords of window (0,0)
     const int64_t cc = c0 + lane;
     const bool col_in = cc < Wd;
-    const bool col_border = (cc == 0) || (cc == Wd - 1);
+    const bool upd = lane >= 1 && lane <= TI;
 
+    // ---- stage-in: all 128 row loads are issued back to back (scalar row base + one shared per-lane offset keeps
+    // them off the VGPR address budget); a visit's latency is dominated by this one round trip to HBM/L2.
     WT w[WN];
     float d[WN];
-    const WT INF = Inf<WT>::v();
-    // scalar row base + one shared per-lane offset: keeps the 128 row loads off the VGPR address budget
-    const float *dem0 = dem + (r0 * Wd + c0);
-    const WT *W0 = W + (r0 * Wd + c0);
+    {
+        const WT INF = Inf<WT>::v();
+        // Unconditional loads from clamped (always in-raster) addresses + selects: no exec-masked branches, so all
+        // 128 loads are in flight together.  Row pointers advance incrementally in SGPRs (opaque asm keeps the
+        // compiler from hoisting 64 row offsets out of the persistent tile loop and spilling them).
+        const int lane_c = (int)(cc < Wd ? lane : Wd - 1 - c0);
+        typedef const float __attribute__((address_space(1))) *gfp;   // keep "global" through the opaque asm
+        typedef const WT __attribute__((address_space(1))) *gwp;
+        gfp dp = (gfp)(dem + (r0 * Wd + c0));
+        gfp sp = (gfp)(seed + (r0 * Wd + c0));
+        gwp wp = (gwp)(W + (r0 * Wd + c0));
+        const bool col_border = (cc == 0) || (cc == Wd - 1);
 #pragma unroll
-    for (int r = 0; r < WN; ++r) {
-        const int64_t rr = r0 + r;
-        const bool in = col_in && rr < H;
-        float dv = in ? dem0[(int64_t)r * Wd + lane] : __builtin_inff();
-        WT wv;
-        if (first_round) {
-            const bool border = (rr == 0) || (rr == H - 1) || col_border;
-            wv = (in && border) ? (WT)dv : INF;  // fill.py:102-109 _initialize_filled
-        } else {
-            wv = in ? W0[(int64_t)r * Wd + lane] : INF;
+        for (int r = 0; r < WN; ++r) {
+            const int64_t rr = r0 + r;
+            const bool in = col_in && rr < H;
+            float dv = dp[lane_c];
+            WT wv;
+            if constexpr (INIT == INIT_NONE) {
+                wv = wp[lane_c];
+                wv = in ? wv : INF;
+            } else {
+                const bool border = (rr == 0) || (rr == H - 1) || col_border;
+                if constexpr (INIT == INIT_SEED) {  // rigorous upper bound of the fixed point: see fill_noflat_dev
+                    const float fv = sp[lane_c];
+                    wv = in ? (border ? (WT)dv : (WT)((double)fv + a.seed_add)) : INF;
+                } else {
+                    wv = (in && border) ? (WT)dv : INF;  // fill.py:102-109 _initialize_filled
+                }
+            }
+            dv = in ? dv : __builtin_inff();
+            if (rr + 1 < H) {  // wave-uniform: stay on the last raster row once we run off the bottom
+                dp += Wd;
+                sp += Wd;
+                wp += Wd;
+            }
+            asm volatile("" : "+s"(dp), "+s"(sp), "+s"(wp));
+            // NaN handling: a NaN neighbour never wins `a <= b` in the reference (_fill.pyx:22) and a NaN dem cell
+            // is never updated (`fv > NaN` is false): both behave like +inf inside the window.
+            if (dv != dv) dv = __builtin_inff();
+            if (wv != wv) wv = INF;
+            w[r] = wv;
+            d[r] = dv;
         }
-        // NaN handling: a NaN neighbour never wins `a <= b` in the reference (_fill.pyx:22) and a NaN dem
-        // cell is never updated (`fv > NaN` is false): both behave like +inf inside the window.
-        if (dv != dv) dv = __builtin_inff();
-        if (wv != wv) wv = INF;
-        w[r] = wv;
-        d[r] = dv;
-    }
-    const bool upd = lane >= 1 && lane <= TI;
-    if constexpr (!NOFLAT) {
-        // freeze the halo ring: d == w makes max(min(..), d) a no-op there (both layouts: rows 0/63, lanes 0/63)
-        d[0] = w[0];
-        d[WN - 1] = w[WN - 1];
-        if (!upd) {
+        if constexpr (!NOFLAT) {
+            // freeze the halo ring: d == w makes max(min(..), d) a no-op there (both layouts: rows 0/63, lanes 0/63)
+            d[0] = w[0];
+            d[WN - 1] = w[WN - 1];
+            if (!upd) {
 #pragma unroll
-            for (int r = 0; r < WN; ++r) d[r] = w[r];
+                for (int r = 0; r < WN; ++r) d[r] = w[r];
+            }
         }
     }
 
+    // ---- local solve: (down, up) passes in the row layout, transpose, (down, up) = (right, left), transpose
     uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;
     bool capped = true;
     int ncyc = 0;
     for (int cyc = 0; cyc < MAXCYC; ++cyc) {
         ++ncyc;
-        uint64_t a1 = 0, a2 = 0;
-        if constexpr (NOFLAT) {
-            pass_noflat<true>(w, d, upd, sh, dg, a1, topN, botN);
-            pass_noflat<false>(w, d, upd, sh, dg, a1, topN, botN);
-        } else {
-            pass_plain<true>(w, d, a1, topN, botN);
-            pass_plain<false>(w, d, a1, topN, botN);
+        uint64_t chg = 0;
+#pragma nounroll
+        for (int half = 0; half < 2; ++half) {
+            uint64_t any = 0, first = 0, last = 0;
+            if constexpr (NOFLAT) {
+                pass_noflat<true>(w, d, upd, a.sh, a.dg, any, first, last);
+                pass_noflat<false>(w, d, upd, a.sh, a.dg, any, first, last);
+            } else {
+                pass_plain<true>(w, d, any, first, last);
+                pass_plain<false>(w, d, any, first, last);
+            }
+            transpose(w, scr, lane);
+            transpose(d, scr, lane);
+            if (half == 0) {
+                anyN |= any; topN |= first; botN |= last;
+            } else {
+                anyT |= any; leftT |= first; rightT |= last;
+            }
+            chg |= any;
         }
-        transpose(w, scr, lane);
-        transpose(d, scr, lane);
-        if constexpr (NOFLAT) {
-            pass_noflat<true>(w, d, upd, sh, dg, a2, leftT, rightT);
-            pass_noflat<false>(w, d, upd, sh, dg, a2, leftT, rightT);
-        } else {
-            pass_plain<true>(w, d, a2, leftT, rightT);
-            pass_plain<false>(w, d, a2, leftT, rightT);
-        }
-        transpose(w, scr, lane);
-        transpose(d, scr, lane);
-        anyN |= a1;
-        anyT |= a2;
-        if ((a1 | a2) == 0) {
+        if (chg == 0) {
             capped = false;
             break;
         }
     }
 
     const bool changed = (anyN | anyT) != 0;
-    if (lane == 0) {  // schedule statistics: tile visits, local cycles
-        atomicAdd(&stats[0], 1ull);
-        atomicAdd(&stats[1], (unsigned long long)ncyc);
-    }
+    visits += 1;
+    cycles += ncyc;
+    // ---- stage-out: interior cells that are not raster border cells (those never move)
     if (changed || first_round) {
-        // interior write-back.  Raster border cells never move: they are written once (first round, straight
-        // from dem, including row 0 / column 0 which only ever sit in a halo ring) and skipped afterwards.
-        WT *Wst = W + (r0 * Wd + c0);
+        const bool lane_ok = upd && col_in && cc != 0 && cc != Wd - 1;
+        typedef WT __attribute__((address_space(1))) *gwsp;
+        gwsp wst = (gwsp)(W + ((r0 + 1) * Wd + c0));
 #pragma unroll
-        for (int r = 0; r < WN; ++r) {
+        for (int r = 1; r <= TI; ++r) {
             const int64_t rr = r0 + r;
-            const bool interior_pos = (r >= 1 && r <= TI) && upd;
-            if (rr < H && col_in) {
-                const bool border = (rr == 0) || (rr == H - 1) || col_border;
-                if (!border) {
-                    if (interior_pos) Wst[(int64_t)r * Wd + lane] = w[r];
-                } else if (first_round) {  // wherever the border cell sits in the window (halo ring included)
-                    Wst[(int64_t)r * Wd + lane] = (WT)dem0[(int64_t)r * Wd + lane];
-                }
-            }
+            if (rr < H - 1 && lane_ok) wst[lane] = w[r];  // rr >= 1 always; H-1 is a border row
+            wst += Wd;
+            asm volatile("" : "+s"(wst));
         }
     }
-    if (changed && lane == 0) {
+    if (first_round) {
+        // raster border cells are written once, straight from dem, wherever they sit in the window (halo included)
+#pragma unroll 2
+        for (int r = 0; r < WN; ++r) {
+            const int64_t rr = r0 + r;
+            if (rr < H && col_in && (rr == 0 || rr == H - 1 || cc == 0 || cc == Wd - 1))
+                W[rr * Wd + cc] = (WT)dem[rr * Wd + cc];
+        }
+    }
+    if (changed) {
         // which neighbours saw their halo change?  N layout masks are indexed by column, T layout by row.
+        // Lane k (k < 9) owns neighbour k, so the returning atomics of all directions are in flight together.
         const uint64_t B1 = 1ull << 1, BT = 1ull << TI;
         const bool top = topN != 0 || (anyT & B1), bot = botN != 0 || (anyT & BT);
         const bool left = leftT != 0 || (anyN & B1), right = rightT != 0 || (anyN & BT);
         const bool tl = (topN & B1) || (leftT & B1), tr = (topN & BT) || (rightT & B1);
         const bool bl = (botN & B1) || (leftT & BT), br = (botN & BT) || (rightT & BT);
-        unsigned int raised = 0;
-        auto raise = [&](int di, int dj, bool cond) {
-            const int a = ti + di, b = tj + dj;
-            if (cond && a >= 0 && a < ntr && b >= 0 && b < ntc) {
-                nxt[(int64_t)a * ntc + b] = 1;
-                ++raised;
+        const unsigned bits = (tl ? 1u : 0u) | (top ? 2u : 0u) | (tr ? 4u : 0u) | (left ? 8u : 0u) | (capped ? 16u : 0u) |
+                              (right ? 32u : 0u) | (bl ? 64u : 0u) | (bot ? 128u : 0u) | (br ? 256u : 0u);
+        if (lane < 9 && ((bits >> lane) & 1u)) {
+            const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
+            if (p >= 0 && p < ntr && q >= 0 && q < ntc) {
+                const int t = p * ntc + q, sh = t % NSHARD;
+                if (atomicExch(&a.mark_nxt[t], 1u) == 0u)
+                    a.list_nxt[(size_t)sh * a.shard_cap + atomicAdd(&a.count_nxt[sh], 1u)] = t;
             }
-        };
-        raise(-1, 0, top);
-        raise(1, 0, bot);
-        raise(0, -1, left);
-        raise(0, 1, right);
-        raise(-1, -1, tl);
-        raise(-1, 1, tr);
-        raise(1, -1, bl);
-        raise(1, 1, br);
-        raise(0, 0, capped);
-        if (raised) atomicAdd(counter, raised);
+        }
+    }
+}
+
+template <typename WT, bool NOFLAT, int INIT>
+__global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundArgs a, const float *__restrict__ dem,
+                                                                         const float *__restrict__ seed, WT *__restrict__ W)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform => scalar addressing
+    uint32_t *scr = lds + wave * (WN * (WN + 1));
+    const int64_t nt = (int64_t)a.ntr * a.ntc;
+    const int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    unsigned visits = 0, cycles = 0;
+    if constexpr (INIT != INIT_NONE) {
+        // first round: every tile, statically strided (uniform work)
+        const int64_t nwaves = (int64_t)gridDim.x * 4;
+        for (int64_t t = g; t < nt; t += nwaves) visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, t, scr, lane, visits, cycles);
+    } else {
+        // own shard first; then one vector look at all (head, count) pairs picks the shards that still hold work
+        // (a stale head only costs one wasted pop), so an idle wave leaves after ~2 memory round trips
+        int sh = (int)(g % NSHARD);
+        for (int pass = 0; pass < 4; ++pass) {
+            const unsigned int n = a.count_cur[sh];
+            for (;;) {
+                unsigned int i = 0;
+                if (lane == 0) i = atomicAdd(&a.head[sh], 1u);
+                i = __builtin_amdgcn_readfirstlane(i);
+                if (i >= n) break;
+                const int tile = a.list_cur[(size_t)sh * a.shard_cap + i];
+                if (lane == 0) a.mark_cur[tile] = 0u;
+                visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, tile, scr, lane, visits, cycles);
+            }
+            bool more = false;
+            if (lane < NSHARD) more = __hip_atomic_load(&a.head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.count_cur[lane];
+            const uint64_t left = __ballot(more);
+            if (!left) break;
+            // spread the helpers: pick the (g mod popcount)-th shard that still has work
+            int want = (int)(g % __builtin_popcountll(left));
+            uint64_t m = left;
+            while (want--) m &= m - 1;
+            sh = __builtin_ctzll(m);
+        }
+    }
+    if (lane == 0 && visits) {
+        unsigned long long *sh = a.stats + 2 * (g & 63);
+        atomicAdd(&sh[0], (unsigned long long)visits);
+        atomicAdd(&sh[1], (unsigned long long)cycles);
     }
 }
 
@@ -294,10 +378,13 @@ template <typename WT> __global__ void copy_dem_kernel(const float *dem, WT *out
     if (i < n) out[i] = (WT)dem[i];
 }
 
+constexpr int MAX_ROUNDS = 1 << 15;
+
 template <typename WT, bool NOFLAT>
-int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, FillStats *st)
+int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, double dg, const float *d_seed,
+             double seed_add, hipStream_t s, FillStats *st)
 {
-    if (st) st->rounds = 0;
+    if (st) *st = FillStats();
     if (H < 3 || W < 3) {  // no interior cell: filled == dem (fill.py:102-109 with an empty sweep area)
         int64_t n = H * W;
         hipLaunchKernelGGL((copy_dem_kernel<WT>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_dem, d_out, n);
@@ -307,60 +394,87 @@ int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, dou
     const int ntr = (int)cdiv(H - 2, TI), ntc = (int)cdiv(W - 2, TI);
     const int64_t nt = (int64_t)ntr * ntc;
     constexpr int BATCH = 8;
-    DevBuf flags, counters, statbuf;
-    MH_TRY(statbuf.alloc(16));
-    MH_HIP(hipMemsetAsync(statbuf.p, 0, 16, s));
-    unsigned long long *d_stats = statbuf.as<unsigned long long>();
-    MH_TRY(flags.alloc((size_t)nt * 2));
-    MH_TRY(counters.alloc(sizeof(unsigned int) * BATCH));
-    MH_HIP(hipMemsetAsync(flags.p, 0, (size_t)nt * 2, s));
-    uint8_t *fl[2] = {flags.as<uint8_t>(), flags.as<uint8_t>() + nt};
-    unsigned int *cnt = counters.as<unsigned int>();
-    const size_t lds = 4 * WN * (WN + 1) * sizeof(uint32_t);
-    const dim3 grid((unsigned)cdiv(nt, 4)), block(256);
-    auto kern = fill_round_kernel<WT, NOFLAT>;
-    MH_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // workspace: lists[2][NSHARD][cap] | marks[2][nt] | count[MAX_ROUNDS+1][NSHARD] | head[MAX_ROUNDS+1][NSHARD] | stats[64][2]
+    DevBuf ws;
+    auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    const int shard_cap = (int)cdiv(nt, NSHARD) + 1;
+    const size_t list_elems = (size_t)NSHARD * shard_cap;
+    const size_t off_marks = align16(list_elems * 2 * 4), off_count = align16(off_marks + (size_t)nt * 2 * 4);
+    const size_t off_head = align16(off_count + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
+    const size_t off_stats = align16(off_head + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
+    MH_TRY(ws.alloc(off_stats + 64 * 16));
+    MH_HIP(hipMemsetAsync(ws.as<char>() + off_marks, 0, off_stats + 64 * 16 - off_marks, s));
+    int *lists = ws.as<int>();
+    unsigned int *marks = reinterpret_cast<unsigned int *>(ws.as<char>() + off_marks);
+    unsigned int *count = reinterpret_cast<unsigned int *>(ws.as<char>() + off_count);
+    unsigned int *head = reinterpret_cast<unsigned int *>(ws.as<char>() + off_head);
+    unsigned long long *d_stats = reinterpret_cast<unsigned long long *>(ws.as<char>() + off_stats);
 
-    int round = 0;
-    unsigned int h_cnt[BATCH];
-    // round 0 initialises every tile; then batches of BATCH rounds between host checks
-    MH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * BATCH, s));
-    hipLaunchKernelGGL(kern, grid, block, lds, s, d_dem, d_out, H, W, ntr, ntc, fl[0], fl[1], cnt, 1, sh, dg, d_stats);
+    const size_t lds = 4 * WN * (WN + 1) * sizeof(uint32_t);
+    // resident grid: as many blocks as the chip holds at this kernel's occupancy
+    const int resident_blocks = 256 * (NOFLAT ? 1 : 2);
+    auto k_none = fill_round_kernel<WT, NOFLAT, INIT_NONE>;
+    auto k_inf = fill_round_kernel<WT, NOFLAT, INIT_INF>;
+    auto k_seed = fill_round_kernel<WT, NOFLAT, NOFLAT ? INIT_SEED : INIT_INF>;
+    MH_HIP(hipFuncSetAttribute((const void *)k_none, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MH_HIP(hipFuncSetAttribute((const void *)k_inf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MH_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+    auto launch = [&](int round, int init) {
+        RoundArgs a;
+        a.H = H; a.Wd = W; a.ntr = ntr; a.ntc = ntc;
+        a.shard_cap = shard_cap;
+        a.list_cur = lists + (size_t)(round & 1) * list_elems; a.list_nxt = lists + (size_t)((round + 1) & 1) * list_elems;
+        a.mark_cur = marks + (size_t)(round & 1) * nt; a.mark_nxt = marks + (size_t)((round + 1) & 1) * nt;
+        a.count_cur = count + (size_t)round * NSHARD; a.count_nxt = count + (size_t)(round + 1) * NSHARD;
+        a.head = head + (size_t)round * NSHARD;
+        a.sh = sh; a.dg = dg; a.seed_add = seed_add; a.stats = d_stats;
+        const int64_t want = cdiv(nt, 4);
+        const unsigned grid = (unsigned)(want < resident_blocks ? want : resident_blocks);
+        auto kern = init == INIT_NONE ? k_none : (init == INIT_SEED ? k_seed : k_inf);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, d_dem, d_seed ? d_seed : d_dem, d_out);
+    };
+
+    unsigned int h_cnt[BATCH * NSHARD];
+    auto round_total = [&](int b) {
+        unsigned int t = 0;
+        for (int k = 0; k < NSHARD; ++k) t += h_cnt[b * NSHARD + k];
+        return t;
+    };
+    launch(0, d_seed ? INIT_SEED : INIT_INF);
     MH_HIP(hipGetLastError());
-    round = 1;
-    MH_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    int round = 1;
+    MH_HIP(hipMemcpyAsync(h_cnt, count + NSHARD, sizeof(unsigned int) * NSHARD, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
-    bool active = h_cnt[0] != 0;
-    const int64_t max_rounds = 64 + 8 * (cdiv(H, TI) + cdiv(W, TI)) * 64;  // generous safety cap
+    bool active = round_total(0) != 0;
     while (active) {
-        MH_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned int) * BATCH, s));
-        for (int b = 0; b < BATCH; ++b) {
-            uint8_t *cur = fl[(round + b) & 1], *nxt = fl[(round + b + 1) & 1];
-            hipLaunchKernelGGL(kern, grid, block, lds, s, d_dem, d_out, H, W, ntr, ntc, cur, nxt, cnt + b, 0, sh, dg, d_stats);
+        if (round + BATCH >= MAX_ROUNDS) {
+            set_error("fill did not converge within %d rounds", MAX_ROUNDS);
+            return MHIP_ENOTCONV;
         }
+        for (int b = 0; b < BATCH; ++b) launch(round + b, INIT_NONE);
         MH_HIP(hipGetLastError());
-        MH_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(unsigned int) * BATCH, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(h_cnt, count + (size_t)(round + 1) * NSHARD, sizeof(unsigned int) * BATCH * NSHARD,
+                              hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         int used = BATCH;
         for (int b = 0; b < BATCH; ++b)
-            if (h_cnt[b] == 0) {
+            if (round_total(b) == 0) {  // round (round + b) appended nothing: converged, later launches were no-ops
                 used = b + 1;
                 active = false;
                 break;
             }
         round += used;
-        if (round > max_rounds) {
-            set_error("fill did not converge within %lld rounds", (long long)max_rounds);
-            return MHIP_ENOTCONV;
-        }
     }
     if (st) {
-        unsigned long long h_stats[2] = {0, 0};
-        MH_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, s));
+        unsigned long long h_stats[128];
+        MH_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         st->rounds = round;
-        st->visits = (int64_t)h_stats[0];
-        st->cycles = (int64_t)h_stats[1];
+        for (int k = 0; k < 64; ++k) {
+            st->visits += (int64_t)h_stats[2 * k];
+            st->cycles += (int64_t)h_stats[2 * k + 1];
+        }
         st->tiles = nt;
     }
     return MHIP_OK;
@@ -410,13 +524,22 @@ __global__ void depths_kernel(const float *__restrict__ f, const float *__restri
 
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st)
 {
-    return fill_dev<float, false>(d_dem, d_out, H, W, 0.0, 0.0, s, st);
+    return fill_dev<float, false>(d_dem, d_out, H, W, 0.0, 0.0, nullptr, 0.0, s, st);
 }
 
+// No-flats fill.  With `d_filled` (the plain fill F of the same DEM) the iteration starts from the pointwise
+// upper bound U = F + K instead of +inf, K = 1.01 * (H*W) * diag:  along a simple path that realises F[c] the
+// no-flats recurrence v <- max(dtm, fl(v + eps)) grows by at most eps*(1 + 2**-10) per step over the running
+// maximum (<= F[c]), a simple path has at most H*W steps and eps <= diag, hence G <= U.  The greatest fixed
+// point G is the only fixed point X with G <= X (Knaster-Tarski), and the monotone chaotic iteration started
+// at any U >= G stays >= G and is dominated by the iteration started at +inf, so it stops exactly at G: the
+// seeded schedule returns the same bits as the reference's start from +inf, in far fewer rounds.
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                    FillStats *st)
+                    FillStats *st, const float *d_filled)
 {
-    return fill_dev<double, true>(d_dem, d_out, H, W, sh, dg, s, st);
+    const bool seedable = d_filled && sh >= 0.0 && dg >= sh && dg == dg && dg < 1e300;
+    const double K = 1.01 * (double)(H * W) * dg;
+    return fill_dev<double, true>(d_dem, d_out, H, W, sh, dg, seedable ? d_filled : nullptr, K, s, st);
 }
 
 // fill.py:235-250: maxval = f64(max(|amax|,|amin|)); short = (nextafter(maxval, inf) - maxval) * 1024; diag = short * 2**0.5

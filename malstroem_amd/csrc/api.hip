@@ -366,8 +366,10 @@ int mhip_watersheds_i32(const uint8_t *flowdir, int32_t *labels, int64_t H, int6
  * ================================================================================================ */
 
 struct mhip_ctx {
-    int64_t H = 0, W = 0;   // local band
-    int64_t H_global = 0, row0 = 0;
+    int64_t H = 0, W = 0;   // local raster: owned rows + halo rows
+    int64_t H_global = 0, row0 = 0, H_owned = 0;
+    int ht = 0, hb = 0;     // 1 if a halo row (copy of the neighbouring band's edge row) sits above / below the owned rows
+    FillRun *run[2] = {nullptr, nullptr};   // resumable fill (plain, no-flats) in band mode
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     DevBuf r[MHIP_R_COUNT_];
@@ -416,7 +418,8 @@ static int ctx_events(mhip_ctx *c, int stage, hipEvent_t **a, hipEvent_t **b)
 int mhip_comm_unique_id(void *id128)
 {
     (void)id128;
-    set_error("multi-GPU bands are not built into this library yet");
+    set_error("the RCCL transport is not built into this library yet: bands exchange their halo rows through the host "
+              "launcher (mhip_ctx_get_edge_row / mhip_ctx_set_halo_row)");
     return MHIP_ECOMM;
 }
 
@@ -425,14 +428,14 @@ int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t ro
 {
     MH_ARG(out && H_global >= 1 && W >= 1 && H_local >= 1 && row0 >= 0 && row0 + H_local <= H_global, "ctx_create_band geometry");
     (void)nccl_unique_id;
-    if (nranks != 1) {
-        set_error("multi-GPU bands are not built into this library yet");
-        return MHIP_ECOMM;
-    }
     MH_TRY(require_device());
     MH_HIP(hipSetDevice(device));
     mhip_ctx *c = new mhip_ctx();
-    c->H = H_local; c->W = W; c->H_global = H_global; c->row0 = row0;
+    c->ht = row0 > 0 ? 1 : 0;
+    c->hb = row0 + H_local < H_global ? 1 : 0;
+    c->H_owned = H_local;
+    c->H = H_local + c->ht + c->hb;
+    c->W = W; c->H_global = H_global; c->row0 = row0;
     c->device = device; c->rank = rank; c->nranks = nranks;
     if (hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
@@ -458,6 +461,8 @@ int mhip_ctx_destroy(mhip_ctx *c)
         (void)hipEventDestroy(kv.second.second);
     }
     (void)hipStreamDestroy(c->stream);
+    delete c->run[0];
+    delete c->run[1];
     delete c;
     return MHIP_OK;
 }
@@ -467,7 +472,8 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
     MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_, "ctx_upload(ctx, which, host)");
     MH_HIP(hipSetDevice(c->device));
     MH_TRY(ctx_raster(c, which));
-    MH_HIP(hipMemcpyAsync(c->r[which].p, host, raster_elem(which) * (size_t)(c->H * c->W), hipMemcpyHostToDevice, c->stream));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * c->ht, host, rowb * (size_t)c->H_owned, hipMemcpyHostToDevice, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     c->have[which] = true;
     if (which == MHIP_R_DEM)  // a new DEM invalidates everything derived from the previous one
@@ -484,8 +490,123 @@ int mhip_ctx_download(mhip_ctx *c, int which, void *host)
     MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_, "ctx_download(ctx, which, host)");
     MH_ARG(c->have[which], "raster has not been computed or uploaded");
     MH_HIP(hipSetDevice(c->device));
-    MH_HIP(hipMemcpyAsync(host, c->r[which].p, raster_elem(which) * (size_t)(c->H * c->W), hipMemcpyDeviceToHost, c->stream));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * c->ht, rowb * (size_t)c->H_owned, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+/* ---- row-band helpers: the host launcher moves edge rows between neighbouring bands -------------------------- */
+
+int mhip_ctx_band_info(mhip_ctx *c, int64_t *row_off, int64_t *rows_local, int32_t *halo_top, int32_t *halo_bottom)
+{
+    MH_ARG(c, "ctx");
+    if (row_off) *row_off = c->row0 - c->ht;
+    if (rows_local) *rows_local = c->H;
+    if (halo_top) *halo_top = c->ht;
+    if (halo_bottom) *halo_bottom = c->hb;
+    return MHIP_OK;
+}
+
+int mhip_ctx_get_edge_row(mhip_ctx *c, int which, int side, void *host)
+{
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_ && (side == 0 || side == 1), "ctx_get_edge_row(ctx, which, side, host)");
+    MH_ARG(c->r[which].p, "raster has not been computed or uploaded");
+    MH_HIP(hipSetDevice(c->device));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    const int64_t row = side == 0 ? c->ht : c->ht + c->H_owned - 1;
+    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+int mhip_ctx_set_halo_row(mhip_ctx *c, int which, int side, const void *host, int32_t *changed)
+{
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_ && (side == 0 || side == 1), "ctx_set_halo_row(ctx, which, side, host)");
+    MH_ARG(side == 0 ? c->ht : c->hb, "this band has no halo row on that side");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, which));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    const int64_t row = side == 0 ? 0 : c->H - 1;
+    DevBuf tmp;
+    MH_TRY(tmp.alloc(rowb));
+    MH_HIP(hipMemcpyAsync(tmp.p, host, rowb, hipMemcpyHostToDevice, c->stream));
+    int ch = 0;
+    MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, tmp.p, (int64_t)rowb, &ch, c->stream));
+    if (changed) *changed = ch;
+    return MHIP_OK;
+}
+
+int mhip_ctx_dem_minmax(mhip_ctx *c, float *mn, float *mx, int32_t *has_nan)
+{
+    MH_ARG(c && mn && mx && has_nan && c->have[MHIP_R_DEM], "ctx_dem_minmax needs the DEM");
+    MH_HIP(hipSetDevice(c->device));
+    int hn = 0;
+    MH_TRY(minmax_dev(c->r[MHIP_R_DEM].as<float>() + c->W * c->ht, c->H_owned * c->W, mn, mx, &hn, c->stream));
+    *has_nan = hn;
+    return MHIP_OK;
+}
+
+/* resumable fill: kind 0 = fill_terrain (needs DEM incl. halo rows), kind 1 = fill_terrain_no_flats (needs DEM and the
+ * converged plain fill incl. halo rows; short/diag from the GLOBAL |dem| maximum). */
+int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32_t *active)
+{
+    MH_ARG(c && active && (kind == 0 || kind == 1) && c->have[MHIP_R_DEM], "ctx_fill_begin(ctx, kind, short, diag, active)");
+    MH_HIP(hipSetDevice(c->device));
+    const int which = kind ? MHIP_R_NOFLAT : MHIP_R_FILLED;
+    MH_TRY(ctx_raster(c, which));
+    delete c->run[kind];
+    FillRun *f = c->run[kind] = new FillRun();
+    f->noflat = kind != 0;
+    f->dem = c->r[MHIP_R_DEM].as<float>();
+    f->out = c->r[which].p;
+    f->H = c->H; f->W = c->W;
+    f->fixed_top = c->ht; f->fixed_bot = c->hb;
+    if (kind) {
+        MH_ARG(c->have[MHIP_R_FILLED], "the no-flats fill of a band starts from the converged plain fill");
+        f->sh = short_; f->dg = diag;
+        c->sh = short_; c->dg = diag;
+        noflat_seed(*f, c->r[MHIP_R_FILLED].as<float>(), short_, diag, c->H_global * c->W);
+    }
+    bool a = false;
+    MH_TRY(f->begin(c->stream, &a));
+    *active = a;
+    return MHIP_OK;
+}
+
+int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
+{
+    MH_ARG(c && active && (kind == 0 || kind == 1) && c->run[kind], "ctx_fill_batch needs ctx_fill_begin");
+    MH_HIP(hipSetDevice(c->device));
+    bool a = false;
+    MH_TRY(c->run[kind]->batch(c->stream, &a));
+    *active = a;
+    return MHIP_OK;
+}
+
+int mhip_ctx_fill_halo_changed(mhip_ctx *c, int kind, int side)
+{
+    MH_ARG(c && (kind == 0 || kind == 1) && c->run[kind] && (side == 0 || side == 1), "ctx_fill_halo_changed needs ctx_fill_begin");
+    MH_HIP(hipSetDevice(c->device));
+    return c->run[kind]->activate_row(side, c->stream);
+}
+
+int mhip_ctx_fill_end(mhip_ctx *c, int kind)
+{
+    MH_ARG(c && (kind == 0 || kind == 1) && c->run[kind], "ctx_fill_end needs ctx_fill_begin");
+    MH_HIP(hipSetDevice(c->device));
+    FillStats st;
+    MH_TRY(c->run[kind]->finish(c->stream, &st));
+    delete c->run[kind];
+    c->run[kind] = nullptr;
+    if (kind) { c->noflat_rounds = st.rounds; c->noflat_st = st; c->have[MHIP_R_NOFLAT] = true; }
+    else {
+        c->fill_rounds = st.rounds; c->fill_st = st; c->have[MHIP_R_FILLED] = true;
+        MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
+        MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(),
+                          c->H * c->W, c->stream));
+        c->have[MHIP_R_DEPTHS] = true;
+    }
     return MHIP_OK;
 }
 
@@ -519,6 +640,11 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     hipStream_t s = c->stream;
     const int64_t H = c->H, W = c->W, n = H * W;
     hipEvent_t *e0, *e1;
+    if (c->nranks > 1 || c->ht || c->hb) {
+        // row-band mode: the fills run through mhip_ctx_fill_begin/batch (halo refreshes in between); stages whose
+        // cross-band protocol is not built yet are refused instead of silently computing band-local results
+        MH_ARG((mask & ~(MHIP_STAGE_FLOWDIR)) == 0, "this stage is not available on a row band yet (use mhip_ctx_fill_* and FLOWDIR)");
+    }
 
     if (mask & MHIP_STAGE_FILL) {
         MH_ARG(c->have[MHIP_R_DEM], "FILL needs the DEM");
@@ -561,7 +687,8 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
         MH_TRY(ctx_events(c, MHIP_STAGE_FLOWDIR, &e0, &e1));
         MH_HIP(hipEventRecord(*e0, s));
-        MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), H, W, 1, s));
+        MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), H, W, 1, s, c->row0 - c->ht,
+                      c->H_global));
         MH_HIP(hipEventRecord(*e1, s));
         c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
         c->have[MHIP_R_FLOWDIR] = true;

@@ -111,13 +111,38 @@ struct FillStats {
 };
 
 // fill.hip
+// Resumable fill run (row-band mode interleaves halo refreshes between batches of rounds).
+struct FillRun {
+    bool noflat = false;
+    const float *dem = nullptr;
+    void *out = nullptr;            // float* (plain) or double* (no-flats)
+    int64_t H = 0, W = 0;           // local raster (band + halo rows)
+    double sh = 0, dg = 0;
+    const float *seed = nullptr;    // plain-filled surface: no-flats upper-bound start (see fill_noflat_dev)
+    double seed_add = 0;
+    int fixed_top = 0, fixed_bot = 0;  // local row 0 / H-1 is a halo row owned by the neighbouring band
+    struct Impl;
+    Impl *impl;
+    FillRun();
+    ~FillRun();
+    FillRun(const FillRun &) = delete;
+    FillRun &operator=(const FillRun &) = delete;
+    int begin(hipStream_t s, bool *active);      // initialising round over every tile
+    int batch(hipStream_t s, bool *active);      // a batch of rounds; *active == false: locally converged
+    int activate_row(int side, hipStream_t s);   // halo row `side` (0 top, 1 bottom) changed: revisit its tile row
+    int finish(hipStream_t s, FillStats *st);
+};
+void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_t ncells_global);
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);
 int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s);
 // d8.hip
-int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s);
+int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s, int64_t row_off = 0,
+           int64_t Hg = 0);
+int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
+int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
 // accum.hip
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s);
 // ccl.hip   (d_tmp: H*W int32 scratch)

@@ -96,8 +96,10 @@ __device__ __forceinline__ unsigned edge_code(int64_t r, int64_t c, int64_t maxr
     return code;
 }
 
+// row_off / Hg: row band of a larger raster (local row r is global row r + row_off of Hg rows); only global border
+// rows get the border codes, the band's halo rows are computed from clamped data and overwritten by the host.
 __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, uint8_t *__restrict__ out, int64_t H,
-                                                int64_t W, int edges_outward)
+                                                int64_t W, int edges_outward, int64_t row_off, int64_t Hg)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
     const int64_t c = c0 + (int64_t)lane * CPL;
     const int64_t r_begin = (int64_t)blockIdx.y * ROWS_PER_WAVE;
     const int64_t r_end = r_begin + ROWS_PER_WAVE < H ? r_begin + ROWS_PER_WAVE : H;
-    const int64_t maxr = H - 1, maxc = W - 1;
+    const int64_t maxr = Hg - 1, maxc = W - 1;
     // wave-uniform: whole strip inside the raster and rows 16-byte aligned (clamped neighbour columns at the
     // raster edge are only ever consumed by border cells, whose code does not depend on the surface)
     const bool fast = (c0 + STRIP <= W) && ((W & 1) == 0);
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
         for (int j = 0; j < CPL; ++j) {
             const int64_t cc = c + j;
             unsigned code;
-            const bool border = (r == 0) || (r == maxr) || (cc == 0) || (cc >= maxc);
+            const int64_t gr = r + row_off;
+            const bool border = (gr == 0) || (gr == maxr) || (cc == 0) || (cc >= maxc);
             if (border)
-                code = edges_outward ? edge_code(r, cc, maxr, maxc) : 8u;
+                code = edges_outward ? edge_code(gr, cc, maxr, maxc) : 8u;
             else
                 code = d8_code(mid.v[j + 1], up.v[j + 1], up.v[j + 2], mid.v[j + 2], dn.v[j + 2], dn.v[j + 1], dn.v[j],
                                mid.v[j], up.v[j]);
@@ -145,10 +148,12 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
 
 }  // namespace
 
-int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s)
+int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s, int64_t row_off,
+           int64_t Hg)
 {
+    if (Hg <= 0) Hg = H;
     const dim3 grid((unsigned)cdiv(cdiv(W, STRIP), 4), (unsigned)cdiv(H, ROWS_PER_WAVE));
-    hipLaunchKernelGGL(d8_kernel, grid, dim3(256), 0, s, d_z, d_out, H, W, edges_outward);
+    hipLaunchKernelGGL(d8_kernel, grid, dim3(256), 0, s, d_z, d_out, H, W, edges_outward, row_off, Hg);
     MH_HIP(hipGetLastError());
     return MHIP_OK;
 }

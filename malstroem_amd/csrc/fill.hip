@@ -88,8 +88,8 @@ __device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN],
 
 // no-flats f64: min4(diagonals)+diag, min4(edges)+short, self; single IEEE adds (_fill.pyx:107-117).
 template <bool DOWN>
-__device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN], bool upd, double sh, double dg,
-                                            uint64_t &any, uint64_t &first, uint64_t &last)
+__device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, double sh,
+                                            double dg, uint64_t &any, uint64_t &first, uint64_t &last)
 {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN
         me = __dadd_rn(me, sh);
         double m = fmin(fmin(md, me), cu);
         double nv = fmax(m, (double)d[r]);
-        nv = upd ? nv : cu;
+        nv = (upd && ((rowok >> r) & 1ull)) ? nv : cu;
         const uint64_t ch = __ballot(nv != cu);
         w[r] = nv;
         any |= ch;
@@ -170,6 +170,9 @@ struct RoundArgs {
     unsigned int *count_cur, *count_nxt, *head;   // [NSHARD] each, per round
     double sh, dg, seed_add;
     unsigned long long *stats;  // [64][2] sharded {visits, local cycles}
+    // row-band mode: local row 0 / H-1 is a HALO row owned by the neighbouring band: never updated here, not a raster
+    // border (its start value is +inf or the seed, not dem); the host refreshes it between rounds
+    int fixed_top, fixed_bot;
 };
 enum { INIT_NONE = 0, INIT_INF = 1, INIT_SEED = 2 };
 
@@ -213,7 +216,7 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
                 wv = wp[lane_c];
                 wv = in ? wv : INF;
             } else {
-                const bool border = (rr == 0) || (rr == H - 1) || col_border;
+                const bool border = (rr == 0 && !a.fixed_top) || (rr == H - 1 && !a.fixed_bot) || col_border;
                 if constexpr (INIT == INIT_SEED) {  // rigorous upper bound of the fixed point: see fill_noflat_dev
                     const float fv = sp[lane_c];
                     wv = in ? (border ? (WT)dv : (WT)((double)fv + a.seed_add)) : INF;
@@ -232,6 +235,9 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             // is never updated (`fv > NaN` is false): both behave like +inf inside the window.
             if (dv != dv) dv = __builtin_inff();
             if (wv != wv) wv = INF;
+            if constexpr (!NOFLAT) {
+                if ((a.fixed_top && rr == 0) || (a.fixed_bot && rr == H - 1)) dv = wv;  // halo row of a band: frozen
+            }
             w[r] = wv;
             d[r] = dv;
         }
@@ -247,6 +253,11 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
     }
 
     // ---- local solve: (down, up) passes in the row layout, transpose, (down, up) = (right, left), transpose
+    // window rows that may be updated (all but a band's halo rows); after the transpose rows <-> lanes swap roles
+    uint64_t rowok = ~0ull;
+    if (a.fixed_top && r0 == 0) rowok &= ~1ull;
+    if (a.fixed_bot && H - 1 - r0 < WN) rowok &= ~(1ull << (H - 1 - r0));
+    const bool upd_t = upd && ((rowok >> lane) & 1ull);
     uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;
     bool capped = true;
     int ncyc = 0;
@@ -257,8 +268,8 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
         for (int half = 0; half < 2; ++half) {
             uint64_t any = 0, first = 0, last = 0;
             if constexpr (NOFLAT) {
-                pass_noflat<true>(w, d, upd, a.sh, a.dg, any, first, last);
-                pass_noflat<false>(w, d, upd, a.sh, a.dg, any, first, last);
+                pass_noflat<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any, first, last);
+                pass_noflat<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any, first, last);
             } else {
                 pass_plain<true>(w, d, any, first, last);
                 pass_plain<false>(w, d, any, first, last);
@@ -295,12 +306,22 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
         }
     }
     if (first_round) {
-        // raster border cells are written once, straight from dem, wherever they sit in the window (halo included)
+        // raster border cells are written once, straight from dem, wherever they sit in the window (halo included);
+        // a band's halo rows get their start value (+inf / seed) until the neighbour's first exchange arrives
 #pragma unroll 2
         for (int r = 0; r < WN; ++r) {
             const int64_t rr = r0 + r;
-            if (rr < H && col_in && (rr == 0 || rr == H - 1 || cc == 0 || cc == Wd - 1))
-                W[rr * Wd + cc] = (WT)dem[rr * Wd + cc];
+            if (rr < H && col_in) {
+                const bool colb = (cc == 0 || cc == Wd - 1);
+                const bool fixed = (a.fixed_top && rr == 0) || (a.fixed_bot && rr == H - 1);
+                if (colb || ((rr == 0 || rr == H - 1) && !fixed)) {
+                    W[rr * Wd + cc] = (WT)dem[rr * Wd + cc];
+                } else if (fixed) {
+                    WT v = Inf<WT>::v();
+                    if constexpr (INIT == INIT_SEED) v = (WT)((double)seed[rr * Wd + cc] + a.seed_add);
+                    W[rr * Wd + cc] = v;
+                }
+            }
         }
     }
     if (changed) {
@@ -379,106 +400,189 @@ template <typename WT> __global__ void copy_dem_kernel(const float *dem, WT *out
 }
 
 constexpr int MAX_ROUNDS = 1 << 15;
+constexpr int BATCH = 8;
+
+// marks every tile of tile-row `ti` active for the round that is launched next (band mode: a halo row changed)
+__global__ void activate_tile_row_kernel(int ti, int ntc, int shard_cap, int *list, unsigned int *mark, unsigned int *count)
+{
+    const int tj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tj >= ntc) return;
+    const int t = ti * ntc + tj, sh = t % NSHARD;
+    if (atomicExch(&mark[t], 1u) == 0u) list[(size_t)sh * shard_cap + atomicAdd(&count[sh], 1u)] = t;
+}
+
+}  // namespace
+
+// ---- resumable fill: begin() runs the initialising round, batch() runs BATCH rounds between host checks ---------
+struct FillRun::Impl {
+    DevBuf ws;
+    int *lists = nullptr;
+    unsigned int *marks = nullptr, *count = nullptr, *head = nullptr;
+    unsigned long long *d_stats = nullptr;
+    int ntr = 0, ntc = 0, shard_cap = 0, round = 0, rounds_used = 0;
+    int64_t nt = 0;
+    size_t list_elems = 0;
+    bool trivial = false;  // no interior cell
+};
+
+FillRun::FillRun() : impl(new Impl) {}
+FillRun::~FillRun() { delete impl; }
 
 template <typename WT, bool NOFLAT>
-int fill_dev(const float *d_dem, WT *d_out, int64_t H, int64_t W, double sh, double dg, const float *d_seed,
-             double seed_add, hipStream_t s, FillStats *st)
+static int fill_launch(FillRun &f, int round, int init, hipStream_t s)
 {
-    if (st) *st = FillStats();
-    if (H < 3 || W < 3) {  // no interior cell: filled == dem (fill.py:102-109 with an empty sweep area)
-        int64_t n = H * W;
-        hipLaunchKernelGGL((copy_dem_kernel<WT>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_dem, d_out, n);
-        MH_HIP(hipGetLastError());
-        return MHIP_OK;
-    }
-    const int ntr = (int)cdiv(H - 2, TI), ntc = (int)cdiv(W - 2, TI);
-    const int64_t nt = (int64_t)ntr * ntc;
-    constexpr int BATCH = 8;
-    // workspace: lists[2][NSHARD][cap] | marks[2][nt] | count[MAX_ROUNDS+1][NSHARD] | head[MAX_ROUNDS+1][NSHARD] | stats[64][2]
-    DevBuf ws;
-    auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    const int shard_cap = (int)cdiv(nt, NSHARD) + 1;
-    const size_t list_elems = (size_t)NSHARD * shard_cap;
-    const size_t off_marks = align16(list_elems * 2 * 4), off_count = align16(off_marks + (size_t)nt * 2 * 4);
-    const size_t off_head = align16(off_count + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
-    const size_t off_stats = align16(off_head + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
-    MH_TRY(ws.alloc(off_stats + 64 * 16));
-    MH_HIP(hipMemsetAsync(ws.as<char>() + off_marks, 0, off_stats + 64 * 16 - off_marks, s));
-    int *lists = ws.as<int>();
-    unsigned int *marks = reinterpret_cast<unsigned int *>(ws.as<char>() + off_marks);
-    unsigned int *count = reinterpret_cast<unsigned int *>(ws.as<char>() + off_count);
-    unsigned int *head = reinterpret_cast<unsigned int *>(ws.as<char>() + off_head);
-    unsigned long long *d_stats = reinterpret_cast<unsigned long long *>(ws.as<char>() + off_stats);
-
+    FillRun::Impl &m = *f.impl;
     const size_t lds = 4 * WN * (WN + 1) * sizeof(uint32_t);
-    // resident grid: as many blocks as the chip holds at this kernel's occupancy
-    const int resident_blocks = 256 * (NOFLAT ? 1 : 2);
+    const int resident_blocks = 256 * (NOFLAT ? 1 : 2);  // as many blocks as the chip holds at this kernel's occupancy
     auto k_none = fill_round_kernel<WT, NOFLAT, INIT_NONE>;
     auto k_inf = fill_round_kernel<WT, NOFLAT, INIT_INF>;
     auto k_seed = fill_round_kernel<WT, NOFLAT, NOFLAT ? INIT_SEED : INIT_INF>;
-    MH_HIP(hipFuncSetAttribute((const void *)k_none, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MH_HIP(hipFuncSetAttribute((const void *)k_inf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    MH_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-
-    auto launch = [&](int round, int init) {
-        RoundArgs a;
-        a.H = H; a.Wd = W; a.ntr = ntr; a.ntc = ntc;
-        a.shard_cap = shard_cap;
-        a.list_cur = lists + (size_t)(round & 1) * list_elems; a.list_nxt = lists + (size_t)((round + 1) & 1) * list_elems;
-        a.mark_cur = marks + (size_t)(round & 1) * nt; a.mark_nxt = marks + (size_t)((round + 1) & 1) * nt;
-        a.count_cur = count + (size_t)round * NSHARD; a.count_nxt = count + (size_t)(round + 1) * NSHARD;
-        a.head = head + (size_t)round * NSHARD;
-        a.sh = sh; a.dg = dg; a.seed_add = seed_add; a.stats = d_stats;
-        const int64_t want = cdiv(nt, 4);
-        const unsigned grid = (unsigned)(want < resident_blocks ? want : resident_blocks);
-        auto kern = init == INIT_NONE ? k_none : (init == INIT_SEED ? k_seed : k_inf);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, d_dem, d_seed ? d_seed : d_dem, d_out);
-    };
-
-    unsigned int h_cnt[BATCH * NSHARD];
-    auto round_total = [&](int b) {
-        unsigned int t = 0;
-        for (int k = 0; k < NSHARD; ++k) t += h_cnt[b * NSHARD + k];
-        return t;
-    };
-    launch(0, d_seed ? INIT_SEED : INIT_INF);
+    static bool attr_done = false;
+    if (!attr_done) {
+        MH_HIP(hipFuncSetAttribute((const void *)k_none, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MH_HIP(hipFuncSetAttribute((const void *)k_inf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MH_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    RoundArgs a;
+    a.H = f.H; a.Wd = f.W; a.ntr = m.ntr; a.ntc = m.ntc; a.shard_cap = m.shard_cap;
+    a.list_cur = m.lists + (size_t)(round & 1) * m.list_elems; a.list_nxt = m.lists + (size_t)((round + 1) & 1) * m.list_elems;
+    a.mark_cur = m.marks + (size_t)(round & 1) * m.nt; a.mark_nxt = m.marks + (size_t)((round + 1) & 1) * m.nt;
+    a.count_cur = m.count + (size_t)round * NSHARD; a.count_nxt = m.count + (size_t)(round + 1) * NSHARD;
+    a.head = m.head + (size_t)round * NSHARD;
+    a.sh = f.sh; a.dg = f.dg; a.seed_add = f.seed_add; a.stats = m.d_stats;
+    a.fixed_top = f.fixed_top; a.fixed_bot = f.fixed_bot;
+    const int64_t want = cdiv(m.nt, 4);
+    const unsigned grid = (unsigned)(want < resident_blocks ? want : resident_blocks);
+    auto kern = init == INIT_NONE ? k_none : (init == INIT_SEED ? k_seed : k_inf);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, f.dem, f.seed ? f.seed : f.dem, reinterpret_cast<WT *>(f.out));
     MH_HIP(hipGetLastError());
-    int round = 1;
-    MH_HIP(hipMemcpyAsync(h_cnt, count + NSHARD, sizeof(unsigned int) * NSHARD, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
-    bool active = round_total(0) != 0;
-    while (active) {
-        if (round + BATCH >= MAX_ROUNDS) {
-            set_error("fill did not converge within %d rounds", MAX_ROUNDS);
-            return MHIP_ENOTCONV;
-        }
-        for (int b = 0; b < BATCH; ++b) launch(round + b, INIT_NONE);
-        MH_HIP(hipGetLastError());
-        MH_HIP(hipMemcpyAsync(h_cnt, count + (size_t)(round + 1) * NSHARD, sizeof(unsigned int) * BATCH * NSHARD,
-                              hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
-        int used = BATCH;
-        for (int b = 0; b < BATCH; ++b)
-            if (round_total(b) == 0) {  // round (round + b) appended nothing: converged, later launches were no-ops
-                used = b + 1;
-                active = false;
-                break;
-            }
-        round += used;
-    }
-    if (st) {
-        unsigned long long h_stats[128];
-        MH_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
-        st->rounds = round;
-        for (int k = 0; k < 64; ++k) {
-            st->visits += (int64_t)h_stats[2 * k];
-            st->cycles += (int64_t)h_stats[2 * k + 1];
-        }
-        st->tiles = nt;
-    }
     return MHIP_OK;
 }
+
+static int fill_launch_any(FillRun &f, int round, int init, hipStream_t s)
+{
+    return f.noflat ? fill_launch<double, true>(f, round, init, s) : fill_launch<float, false>(f, round, init, s);
+}
+
+int FillRun::begin(hipStream_t s, bool *active)
+{
+    Impl &m = *impl;
+    m.round = 0;
+    m.rounds_used = 0;
+    *active = false;
+    m.trivial = H < 3 || W < 3;
+    if (m.trivial) {  // no interior cell: filled == dem (fill.py:102-109 with an empty sweep area)
+        const int64_t n = H * W;
+        if (noflat) hipLaunchKernelGGL((copy_dem_kernel<double>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dem, reinterpret_cast<double *>(out), n);
+        else hipLaunchKernelGGL((copy_dem_kernel<float>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dem, reinterpret_cast<float *>(out), n);
+        MH_HIP(hipGetLastError());
+        return MHIP_OK;
+    }
+    m.ntr = (int)cdiv(H - 2, TI);
+    m.ntc = (int)cdiv(W - 2, TI);
+    m.nt = (int64_t)m.ntr * m.ntc;
+    // workspace: lists[2][NSHARD][cap] | marks[2][nt] | count[MAX_ROUNDS+1][NSHARD] | head[MAX_ROUNDS+1][NSHARD] | stats[64][2]
+    auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    m.shard_cap = (int)cdiv(m.nt, NSHARD) + 1;
+    m.list_elems = (size_t)NSHARD * m.shard_cap;
+    const size_t off_marks = align16(m.list_elems * 2 * 4), off_count = align16(off_marks + (size_t)m.nt * 2 * 4);
+    const size_t off_head = align16(off_count + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
+    const size_t off_stats = align16(off_head + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
+    MH_TRY(m.ws.alloc(off_stats + 64 * 16));
+    MH_HIP(hipMemsetAsync(m.ws.as<char>() + off_marks, 0, off_stats + 64 * 16 - off_marks, s));
+    m.lists = m.ws.as<int>();
+    m.marks = reinterpret_cast<unsigned int *>(m.ws.as<char>() + off_marks);
+    m.count = reinterpret_cast<unsigned int *>(m.ws.as<char>() + off_count);
+    m.head = reinterpret_cast<unsigned int *>(m.ws.as<char>() + off_head);
+    m.d_stats = reinterpret_cast<unsigned long long *>(m.ws.as<char>() + off_stats);
+
+    MH_TRY(fill_launch_any(*this, 0, seed ? INIT_SEED : INIT_INF, s));
+    m.round = 1;
+    m.rounds_used = 1;
+    unsigned int h_cnt[NSHARD];
+    MH_HIP(hipMemcpyAsync(h_cnt, m.count + NSHARD, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    unsigned int t = 0;
+    for (int k = 0; k < NSHARD; ++k) t += h_cnt[k];
+    *active = t != 0;
+    return MHIP_OK;
+}
+
+int FillRun::batch(hipStream_t s, bool *active)
+{
+    Impl &m = *impl;
+    *active = false;
+    if (m.trivial) return MHIP_OK;
+    if (m.round + BATCH >= MAX_ROUNDS) {
+        set_error("fill did not converge within %d rounds", MAX_ROUNDS);
+        return MHIP_ENOTCONV;
+    }
+    unsigned int h_cnt[BATCH * NSHARD];
+    for (int b = 0; b < BATCH; ++b) MH_TRY(fill_launch_any(*this, m.round + b, INIT_NONE, s));
+    MH_HIP(hipMemcpyAsync(h_cnt, m.count + (size_t)(m.round + 1) * NSHARD, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    int used = BATCH;
+    bool still = true;
+    for (int b = 0; b < BATCH; ++b) {
+        unsigned int t = 0;
+        for (int k = 0; k < NSHARD; ++k) t += h_cnt[b * NSHARD + k];
+        if (t == 0) {  // round (round + b) appended nothing: converged, the later launches were no-ops
+            used = b + 1;
+            still = false;
+            break;
+        }
+    }
+    // every launched round index is spent (its queue heads have been advanced, even by no-op launches), so the next
+    // batch -- possibly re-armed by activate_row() -- starts on fresh counters; BATCH is even: list parity is kept
+    m.round += BATCH;
+    m.rounds_used += used;
+    *active = still;
+    return MHIP_OK;
+}
+
+int FillRun::activate_row(int side, hipStream_t s)
+{
+    Impl &m = *impl;
+    if (m.trivial) return MHIP_OK;
+    const int ti = side == 0 ? 0 : m.ntr - 1;
+    hipLaunchKernelGGL(activate_tile_row_kernel, dim3((unsigned)cdiv(m.ntc, 256)), dim3(256), 0, s, ti, m.ntc, m.shard_cap,
+                       m.lists + (size_t)(m.round & 1) * m.list_elems, m.marks + (size_t)(m.round & 1) * m.nt,
+                       m.count + (size_t)m.round * NSHARD);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+int FillRun::finish(hipStream_t s, FillStats *st)
+{
+    Impl &m = *impl;
+    if (st) {
+        *st = FillStats();
+        if (!m.trivial) {
+            unsigned long long h_stats[128];
+            MH_HIP(hipMemcpyAsync(h_stats, m.d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
+            MH_HIP(hipStreamSynchronize(s));
+            st->rounds = m.rounds_used;
+            for (int k = 0; k < 64; ++k) {
+                st->visits += (int64_t)h_stats[2 * k];
+                st->cycles += (int64_t)h_stats[2 * k + 1];
+            }
+            st->tiles = m.nt;
+        }
+    }
+    m.ws.release();
+    return MHIP_OK;
+}
+
+static int fill_run_to_convergence(FillRun &f, hipStream_t s, FillStats *st)
+{
+    bool active = false;
+    MH_TRY(f.begin(s, &active));
+    while (active) MH_TRY(f.batch(s, &active));
+    return f.finish(s, st);
+}
+
+namespace {
 
 // ---- min/max reduction for minimum_safe_short_and_diag -------------------------------------------
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned int *out)
@@ -524,22 +628,77 @@ __global__ void depths_kernel(const float *__restrict__ f, const float *__restri
 
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st)
 {
-    return fill_dev<float, false>(d_dem, d_out, H, W, 0.0, 0.0, nullptr, 0.0, s, st);
+    FillRun f;
+    f.noflat = false; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W;
+    return fill_run_to_convergence(f, s, st);
 }
 
 // No-flats fill.  With `d_filled` (the plain fill F of the same DEM) the iteration starts from the pointwise
-// upper bound U = F + K instead of +inf, K = 1.01 * (H*W) * diag:  along a simple path that realises F[c] the
+// upper bound U = F + K instead of +inf, K = 1.01 * ncells * diag:  along a simple path that realises F[c] the
 // no-flats recurrence v <- max(dtm, fl(v + eps)) grows by at most eps*(1 + 2**-10) per step over the running
-// maximum (<= F[c]), a simple path has at most H*W steps and eps <= diag, hence G <= U.  The greatest fixed
+// maximum (<= F[c]), a simple path has at most ncells steps and eps <= diag, hence G <= U.  The greatest fixed
 // point G is the only fixed point X with G <= X (Knaster-Tarski), and the monotone chaotic iteration started
 // at any U >= G stays >= G and is dominated by the iteration started at +inf, so it stops exactly at G: the
 // seeded schedule returns the same bits as the reference's start from +inf, in far fewer rounds.
+void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_t ncells_global)
+{
+    const bool seedable = d_filled && sh >= 0.0 && dg >= sh && dg == dg && dg < 1e300;
+    f.seed = seedable ? d_filled : nullptr;
+    f.seed_add = 1.01 * (double)ncells_global * dg;
+}
+
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled)
 {
-    const bool seedable = d_filled && sh >= 0.0 && dg >= sh && dg == dg && dg < 1e300;
-    const double K = 1.01 * (double)(H * W) * dg;
-    return fill_dev<double, true>(d_dem, d_out, H, W, sh, dg, seedable ? d_filled : nullptr, K, s, st);
+    FillRun f;
+    f.noflat = true; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W; f.sh = sh; f.dg = dg;
+    noflat_seed(f, d_filled, sh, dg, H * W);
+    return fill_run_to_convergence(f, s, st);
+}
+
+int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s)
+{
+    DevBuf acc;
+    MH_TRY(acc.alloc(sizeof(unsigned int) * 4));
+    unsigned int init[4] = {0u, 0xffffffffu, 0u, 0u};
+    MH_HIP(hipMemcpyAsync(acc.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+    const unsigned grid = (unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, d_x, n, acc.as<unsigned int>());
+    MH_HIP(hipGetLastError());
+    unsigned int h[4];
+    MH_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    *mx = key_f32(h[0]);
+    *mn = key_f32(h[1]);
+    *has_nan = h[2] != 0;
+    return MHIP_OK;
+}
+
+namespace {
+__global__ void row_update_kernel(uint8_t *dst, const uint8_t *src, int64_t n, int *changed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t v = src[i];
+    if (dst[i] != v) {
+        dst[i] = v;
+        *changed = 1;
+    }
+}
+}  // namespace
+
+// dst[0..nbytes) = src[0..nbytes); *changed = 1 if any byte differed (band halo refresh)
+int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s)
+{
+    DevBuf flag;
+    MH_TRY(flag.alloc(4));
+    MH_HIP(hipMemsetAsync(flag.p, 0, 4, s));
+    hipLaunchKernelGGL(row_update_kernel, dim3((unsigned)cdiv(nbytes, 256)), dim3(256), 0, s, (uint8_t *)d_dst, (const uint8_t *)d_src,
+                       nbytes, flag.as<int>());
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(changed, flag.p, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
 }
 
 // fill.py:235-250: maxval = f64(max(|amax|,|amin|)); short = (nextafter(maxval, inf) - maxval) * 1024; diag = short * 2**0.5

@@ -1,0 +1,302 @@
+"""Row-band decomposition of one large DEM over several GPUs.
+
+Each rank owns a contiguous band of rows plus one halo row per neighbour.  The fills (plain and no-flats) are
+global fixed points: every band iterates locally (``mhip_ctx_fill_batch``), neighbours swap their edge rows, a
+band whose halo changed re-activates the tiles next to it, and an all-reduce of "somebody is still active"
+ends the loop -- the result is bit-identical to the single-raster fill because the iteration is monotone and
+schedule independent (csrc/fill.hip).  D8 needs one halo row of the no-flats surface and hands its own edge
+rows to the neighbours afterwards (accumulation / watersheds walk across bands on them).
+
+Transport: ``Comm`` moves a few rows (W * 4..8 bytes each) per exchange.  ``TorchComm`` uses
+``torch.distributed`` (plumbing only; gloo on host buffers today -- the product path stays torch-free);
+``ThreadComm`` connects several bands inside one process (tests on a single GPU).  The compute backend is
+``HipBand`` (the C-ABI band context); tests may substitute a CPU stand-in to exercise the protocol over gloo.
+"""
+import ctypes
+import queue
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_FLOWDIR
+from .pipeline import RASTERS
+
+__all__ = ["band_rows", "Comm", "ThreadComm", "TorchComm", "HipBand", "BandPipeline"]
+
+
+def band_rows(H, size, rank):
+    """(row0, nrows) of band ``rank``: contiguous, sizes differ by at most one row."""
+    base, extra = divmod(int(H), int(size))
+    if base < 1:
+        raise ValueError("more bands (%d) than raster rows (%d)" % (size, H))
+    row0 = rank * base + min(rank, extra)
+    return row0, base + (1 if rank < extra else 0)
+
+
+# ---- transports -----------------------------------------------------------------------------------------------
+
+class Comm(object):
+    """Minimal neighbour/collective interface the band protocol needs."""
+    rank = 0
+    size = 1
+
+    def exchange_rows(self, to_up, to_down):
+        """Send ``to_up`` to rank-1 and ``to_down`` to rank+1 (None at the raster ends); returns (from_up, from_down)."""
+        raise NotImplementedError
+
+    def allreduce_max(self, value):
+        raise NotImplementedError
+
+    def allgather(self, obj):
+        raise NotImplementedError
+
+
+class SingleComm(Comm):
+    def exchange_rows(self, to_up, to_down):
+        return None, None
+
+    def allreduce_max(self, value):
+        return value
+
+    def allgather(self, obj):
+        return [obj]
+
+
+class ThreadComm(Comm):
+    """In-process transport: ``ThreadComm.world(n)`` returns n endpoints to be driven by n threads."""
+
+    class _World(object):
+        def __init__(self, n):
+            self.n = n
+            self.down = [queue.Queue() for _ in range(n)]   # down[i]: messages travelling from rank i to rank i+1
+            self.up = [queue.Queue() for _ in range(n)]     # up[i]: messages travelling from rank i to rank i-1
+            self.barrier = threading.Barrier(n)
+            self.slots = [None] * n
+
+    @classmethod
+    def world(cls, n):
+        w = cls._World(n)
+        return [cls(w, r) for r in range(n)]
+
+    def __init__(self, world, rank):
+        self._w = world
+        self.rank = rank
+        self.size = world.n
+
+    def exchange_rows(self, to_up, to_down):
+        w = self._w
+        if self.rank > 0:
+            w.up[self.rank].put(None if to_up is None else np.array(to_up, copy=True))
+        if self.rank < self.size - 1:
+            w.down[self.rank].put(None if to_down is None else np.array(to_down, copy=True))
+        from_up = w.down[self.rank - 1].get(timeout=600) if self.rank > 0 else None
+        from_down = w.up[self.rank + 1].get(timeout=600) if self.rank < self.size - 1 else None
+        return from_up, from_down
+
+    def allgather(self, obj):
+        w = self._w
+        w.slots[self.rank] = obj
+        w.barrier.wait(timeout=600)
+        out = list(w.slots)
+        w.barrier.wait(timeout=600)
+        return out
+
+    def allreduce_max(self, value):
+        return max(self.allgather(value))
+
+
+class TorchComm(Comm):
+    """torch.distributed transport on host buffers (gloo).  Plumbing only: no tensor ever reaches a kernel."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self._group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def exchange_rows(self, to_up, to_down):
+        torch, dist = self._torch, self._dist
+        ops, recv_up, recv_down, keep = [], None, None, []
+        if self.rank > 0:
+            t = torch.from_numpy(np.ascontiguousarray(to_up).view(np.uint8).reshape(-1).copy())
+            recv_up = torch.empty_like(t)
+            keep.append(t)
+            ops += [dist.P2POp(dist.isend, t, self.rank - 1, self._group), dist.P2POp(dist.irecv, recv_up, self.rank - 1, self._group)]
+        if self.rank < self.size - 1:
+            t = torch.from_numpy(np.ascontiguousarray(to_down).view(np.uint8).reshape(-1).copy())
+            recv_down = torch.empty_like(t)
+            keep.append(t)
+            ops += [dist.P2POp(dist.isend, t, self.rank + 1, self._group), dist.P2POp(dist.irecv, recv_down, self.rank + 1, self._group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        like_up = to_up if to_up is not None else to_down
+        like_down = to_down if to_down is not None else to_up
+        from_up = None if recv_up is None else recv_up.numpy().view(like_up.dtype).reshape(like_up.shape)
+        from_down = None if recv_down is None else recv_down.numpy().view(like_down.dtype).reshape(like_down.shape)
+        return from_up, from_down
+
+    def allreduce_max(self, value):
+        t = self._torch.tensor([float(value)], dtype=self._torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
+        return float(t[0])
+
+    def allgather(self, obj):
+        out = [None] * self.size
+        self._dist.all_gather_object(out, obj, group=self._group)
+        return out
+
+
+# ---- compute backend: one band context on one GPU -----------------------------------------------------------------
+
+class HipBand(object):
+    """ctypes face of a band ``mhip_ctx`` (include/malstroem_hip.h, row-band protocol)."""
+
+    def __init__(self, H_global, W, row0, nrows, device=0, rank=0, size=1):
+        self.W, self.nrows = int(W), int(nrows)
+        self._ctx = ctypes.c_void_p()
+        _lib.call("mhip_ctx_create_band", ctypes.byref(self._ctx), _lib.i64(H_global), _lib.i64(W), _lib.i64(row0),
+                  _lib.i64(nrows), int(device), int(rank), int(size), None)
+
+    def close(self):
+        if self._ctx:
+            _lib.call("mhip_ctx_destroy", self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def upload(self, name, arr):
+        which = RASTERS[name]
+        a = np.ascontiguousarray(arr, dtype=RASTER_DTYPE[which])
+        if a.shape != (self.nrows, self.W):
+            raise ValueError("band raster must be %s, got %s" % ((self.nrows, self.W), a.shape))
+        _lib.call("mhip_ctx_upload", self._ctx, which, _lib.ptr(a))
+
+    def download(self, name):
+        which = RASTERS[name]
+        out = np.empty((self.nrows, self.W), dtype=RASTER_DTYPE[which])
+        _lib.call("mhip_ctx_download", self._ctx, which, _lib.ptr(out))
+        return out
+
+    def get_edge_row(self, name, side):
+        which = RASTERS[name]
+        out = np.empty(self.W, dtype=RASTER_DTYPE[which])
+        _lib.call("mhip_ctx_get_edge_row", self._ctx, which, int(side), _lib.ptr(out))
+        return out
+
+    def set_halo_row(self, name, side, row):
+        which = RASTERS[name]
+        a = np.ascontiguousarray(row, dtype=RASTER_DTYPE[which])
+        changed = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_set_halo_row", self._ctx, which, int(side), _lib.ptr(a), ctypes.byref(changed))
+        return bool(changed.value)
+
+    def dem_minmax(self):
+        mn, mx, nan = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_int32(0)
+        _lib.call("mhip_ctx_dem_minmax", self._ctx, ctypes.byref(mn), ctypes.byref(mx), ctypes.byref(nan))
+        return np.float32(mn.value), np.float32(mx.value), bool(nan.value)
+
+    def fill_begin(self, kind, short=0.0, diag=0.0):
+        active = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_fill_begin", self._ctx, int(kind), ctypes.c_double(short), ctypes.c_double(diag), ctypes.byref(active))
+        return bool(active.value)
+
+    def fill_batch(self, kind):
+        active = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_fill_batch", self._ctx, int(kind), ctypes.byref(active))
+        return bool(active.value)
+
+    def fill_halo_changed(self, kind, side):
+        _lib.call("mhip_ctx_fill_halo_changed", self._ctx, int(kind), int(side))
+
+    def fill_end(self, kind):
+        _lib.call("mhip_ctx_fill_end", self._ctx, int(kind))
+
+    def run_flowdir(self):
+        _lib.call("mhip_ctx_run", self._ctx, STAGE_FLOWDIR)
+        _lib.call("mhip_ctx_sync", self._ctx)
+
+    def get_int(self, key):
+        v = ctypes.c_int64(0)
+        _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))
+        return v.value
+
+
+# ---- the protocol ---------------------------------------------------------------------------------------------------
+
+class BandPipeline(object):
+    """One rank's share of a row-banded DEM.  Every rank calls the same methods in the same order (SPMD)."""
+
+    def __init__(self, comm, shape, device=0, backend_factory=None):
+        self.comm = comm
+        self.H, self.W = int(shape[0]), int(shape[1])
+        self.row0, self.nrows = band_rows(self.H, comm.size, comm.rank)
+        factory = backend_factory or HipBand
+        self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size)
+        self.has_up = comm.rank > 0
+        self.has_down = comm.rank < comm.size - 1
+        self.exchanges = {"fill": 0, "noflat": 0}
+        self.short = self.diag = None
+
+    def close(self):
+        self.band.close()
+
+    # ---- helpers
+    def _swap_edges(self, name):
+        """Neighbours trade edge rows of raster ``name``; returns which of my halo rows changed (top, bottom)."""
+        b = self.band
+        to_up = b.get_edge_row(name, 0) if self.has_up else None
+        to_down = b.get_edge_row(name, 1) if self.has_down else None
+        from_up, from_down = self.comm.exchange_rows(to_up, to_down)
+        ch_top = b.set_halo_row(name, 0, from_up) if self.has_up else False
+        ch_bot = b.set_halo_row(name, 1, from_down) if self.has_down else False
+        return ch_top, ch_bot
+
+    def upload_dem(self, dem_band):
+        """``dem_band``: this rank's owned rows (nrows x W float32).  DEM halo rows are fetched from the neighbours."""
+        self.band.upload("dem", dem_band)
+        self._swap_edges("dem")
+
+    def _fill(self, kind, name, short=0.0, diag=0.0):
+        b = self.band
+        active = b.fill_begin(kind, short, diag)
+        while True:
+            ch_top, ch_bot = self._swap_edges(name)
+            if ch_top:
+                b.fill_halo_changed(kind, 0)
+            if ch_bot:
+                b.fill_halo_changed(kind, 1)
+            self.exchanges["noflat" if kind else "fill"] += 1
+            busy = active or ch_top or ch_bot
+            if not self.comm.allreduce_max(1.0 if busy else 0.0):
+                break
+            active = b.fill_batch(kind) if busy else False
+        b.fill_end(kind)
+
+    def fill(self):
+        """fill.fill_terrain over all bands (+ bluespot depths of the owned rows)."""
+        self._fill(0, "filled")
+
+    def short_and_diag(self):
+        """fill.minimum_safe_short_and_diag on the GLOBAL raster (reference fill.py:235-250)."""
+        mn, mx, _ = self.band.dem_minmax()
+        amax = np.float32(max(self.comm.allgather(float(mx))))
+        amin = np.float32(min(self.comm.allgather(float(mn))))
+        maxval = np.float64(max(abs(amax), abs(amin)))
+        nextval = np.nextafter(maxval, np.float64(float('inf')))
+        short = (nextval - maxval) * 1024
+        self.short, self.diag = float(short), float(short * (2 ** 0.5))
+        return self.short, self.diag
+
+    def noflat(self):
+        """fill.fill_terrain_no_flats over all bands (needs fill())."""
+        short, diag = self.short_and_diag()
+        self._fill(1, "noflat", short, diag)
+
+    def flowdir(self):
+        """D8 on the no-flats surface, edges outward; afterwards the flow-direction halo rows are valid too."""
+        self.band.run_flowdir()
+        self._swap_edges("flowdir")
+
+    def download(self, name):
+        return self.band.download(name)

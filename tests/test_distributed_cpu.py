@@ -1,0 +1,94 @@
+"""CPU-only: the row-band protocol (malstroem_amd.distributed) with world_size 2 and 3 over real
+torch.distributed/gloo processes and over the in-process ThreadComm, on a CPU stand-in backend, checked against
+the oracle run on the undivided raster."""
+import os
+import subprocess
+import sys
+import threading
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from _cases import fbm
+from _cpu_band import CpuBand
+from malstroem_amd.distributed import BandPipeline, ThreadComm, band_rows
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def reference(dem):
+    filled = oracle.fill_terrain(dem)
+    short, diag = oracle.minimum_safe_short_and_diag(dem)
+    fnf = oracle.fill_terrain_no_flats(dem, short, diag)
+    return dict(filled=filled, depths=oracle.depths(filled, dem), noflat=fnf, flowdir=oracle.terrain_flowdirection(fnf),
+                short_diag=(short, diag))
+
+
+def test_band_rows_partition():
+    for H, n in ((188, 2), (188, 3), (7, 7), (1000, 8)):
+        rows = [band_rows(H, n, r) for r in range(n)]
+        assert rows[0][0] == 0 and sum(k for _, k in rows) == H
+        assert all(rows[i][0] + rows[i][1] == rows[i + 1][0] for i in range(n - 1))
+    with pytest.raises(ValueError):
+        band_rows(3, 4, 0)
+
+
+@pytest.mark.parametrize("nbands", [2, 3, 5])
+def test_protocol_threadcomm_cpu_backend(nbands):
+    dem = fbm(90, 70, beta=2.0, seed=4)
+    ref = reference(dem)
+    out = [None] * nbands
+
+    def work(comm):
+        p = BandPipeline(comm, dem.shape, backend_factory=CpuBand)
+        p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+        p.fill()
+        p.noflat()
+        p.flowdir()
+        out[comm.rank] = {k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir")}
+        out[comm.rank]["short_diag"] = (p.short, p.diag)
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(300) for t in threads]
+    assert all(o is not None for o in out)
+    for k in ("filled", "depths", "noflat", "flowdir"):
+        assert np.array_equal(np.concatenate([o[k] for o in out]), ref[k]), k
+    assert out[0]["short_diag"] == ref["short_diag"]
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+import numpy as np, torch.distributed as dist
+from _cases import fbm
+from _cpu_band import CpuBand
+from malstroem_amd.distributed import BandPipeline, TorchComm
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+dem = fbm(90, 70, beta=2.0, seed=4)
+p = BandPipeline(TorchComm(), dem.shape, backend_factory=CpuBand)
+p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+p.fill(); p.noflat(); p.flowdir()
+np.savez(os.path.join(os.environ["OUT"], "rank%d.npz" % dist.get_rank()), row0=p.row0,
+         **{k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir")})
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2])
+def test_protocol_gloo_processes(world, tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   REPO=str(ROOT), OUT=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    dem = fbm(90, 70, beta=2.0, seed=4)
+    ref = reference(dem)
+    parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    for k in ("filled", "depths", "noflat", "flowdir"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k

@@ -15,7 +15,7 @@ __all__ = ["available", "enable", "disable", "enabled"]
 
 available = _lib.LIB_PATH.exists() and _lib.device_count() > 0
 enabled = False
-_orig = {}
+_orig = []   # (module object, attribute name, original function)
 
 # (module name, attribute) -> HIP implementation
 _PATCH = {
@@ -45,7 +45,7 @@ def enable(target=None):
     if target is not None and not _orig:
         for (mod, attr), fn in _PATCH.items():
             m = getattr(target, mod)
-            _orig[(m, attr)] = getattr(m, attr)
+            _orig.append((m, attr, getattr(m, attr)))
             setattr(m, attr, fn)
     enabled = True
 
@@ -53,9 +53,9 @@ def enable(target=None):
 def disable():
     """Undo ``enable(target)`` (restores the reference functions) and mark the backend disabled."""
     global enabled
-    for (m, attr), fn in _orig.items():
+    for m, attr, fn in _orig:
         setattr(m, attr, fn)
-    _orig.clear()
+    del _orig[:]
     enabled = False
 
 

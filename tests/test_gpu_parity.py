@@ -189,3 +189,73 @@ def test_chain_equals_oracle(alg, name, h, w, beta, seed):
                  (alg.label.label_max_index(acc, lab, nl), oracle.label_max_index(acc, lab, nl))):
         for f in ("value", "row", "col"):
             assert np.array_equal(a[f], b[f]), f
+
+
+# ---- drop-in boundary: the hip switch rebinds a target package like speedups.enable() does ---------------------
+
+def test_enable_patches_and_disable_restores_a_target_package(alg):
+    import types
+    sentinel = object()
+    target = types.SimpleNamespace(
+        fill=types.SimpleNamespace(fill_terrain=sentinel, fill_terrain_no_flats=sentinel, minimum_safe_short_and_diag=sentinel),
+        flow=types.SimpleNamespace(terrain_flowdirection=sentinel, _terrain_flow=sentinel, accumulated_flow=sentinel,
+                                   watersheds_from_labels=sentinel),
+        label=types.SimpleNamespace(connected_components=sentinel, label_stats=sentinel, label_min_index=sentinel,
+                                    label_max_index=sentinel, keep_labels=sentinel, label_count=sentinel))
+    alg.hip.disable()
+    alg.hip.enable(target=target)
+    try:
+        assert alg.hip.enabled and alg.speedups.enabled
+        assert target.fill.fill_terrain is alg.fill.fill_terrain
+        assert target.flow.accumulated_flow is alg.flow.accumulated_flow
+        assert target.label.connected_components is alg.label.connected_components
+        alg.hip.enable(target=target)  # idempotent like speedups.enable (speedups/__init__.py:44-45)
+    finally:
+        alg.hip.disable()
+    assert target.fill.fill_terrain is sentinel and target.label.label_count is sentinel
+    assert not alg.hip.enabled
+    alg.hip.enable()
+
+
+def test_tools_run_on_the_device_pipeline(alg, fx):
+    """DemTool + BluespotTool (reference tests/test_raster_dem.py:7-22, test_raster_bluespot.py:18-69) with in-memory
+    reader/writer stubs like the reference's NumpyRasterReader (test_raster_bluespot.py:9-15)."""
+    from malstroem_amd.bluespots import BluespotTool
+    from malstroem_amd.dem import DemTool
+
+    class Reader(object):
+        def __init__(self, a):
+            self.a, self.transform = a, [float(v) for v in fx["geotransform"]]
+
+        def read(self):
+            return self.a
+
+    class Writer(object):
+        def write(self, a):
+            self.a = a
+
+        def write_geojson_features(self, fc):
+            self.fc = fc
+
+    filled, flowdir, depths, accum = Writer(), Writer(), Writer(), Writer()
+    pipe = DemTool(Reader(fx["dtm"]), filled, flowdir, depths, accum).process(keep_pipeline=True)
+    assert np.array_equal(filled.a, fx["filled"]) and np.array_equal(flowdir.a, fx["flowdir_noflats"])
+    assert np.array_equal(depths.a, fx["depths"]) and accum.a.max() == 11158
+
+    def run(filter_fn, pipeline):
+        labeled, pour, wsheds = Writer(), Writer(), Writer()
+        BluespotTool(input_depths=Reader(fx["depths"]), input_flowdir=Reader(fx["flowdir_noflats"]),
+                     input_bluespot_filter_function=filter_fn, input_accum=Reader(accum.a), output_labeled_raster=labeled,
+                     output_pourpoints=pour, output_watersheds_raster=wsheds, pipeline=pipeline).process()
+        return labeled.a, pour.fc, wsheds.a
+
+    lab, fc, ws = run(lambda s: True, pipe)
+    pipe.close()
+    assert lab.max() == 523 and len(fc["features"]) == 524          # tests/test_commandline.py:43 (no filter)
+    # the CLI test's filter 'area > 20.5 and maxdepth > 0.5 or volume > 2.5' (tests/test_commandline.py:15) keeps 486
+    lab2, fc2, ws2 = run(lambda s: s["area"] > 20.5 and s["max"] > 0.5 or s["volume"] > 2.5, None)
+    assert lab2.max() == 486                                          # tests/test_commandline.py:24
+    p = fc2["features"][5]["properties"]
+    assert set(p) >= {"bspot_id", "cell_row", "cell_col", "bspot_dmax", "bspot_area", "bspot_vol", "wshed_area", "bspot_fumm"}
+    m = lab2 > 0
+    assert np.array_equal(ws2[m], lab2[m])

@@ -135,7 +135,8 @@ int mhip_ctx_destroy(mhip_ctx *ctx);
  * buffers + torch.distributed/gloo or any other transport; the RCCL device transport is not built in yet) and drives
  * the fills to a GLOBAL fixed point: begin -> { batch; exchange edge rows; halo_changed } until no band is active. */
 int mhip_ctx_band_info(mhip_ctx *ctx, int64_t *row_off, int64_t *rows_local, int32_t *halo_top, int32_t *halo_bottom);
-int mhip_ctx_get_edge_row(mhip_ctx *ctx, int which, int side, void *host);   /* side 0: first owned row, 1: last owned row */
+int mhip_ctx_get_edge_row(mhip_ctx *ctx, int which, int side, void *host);   /* side 0: first owned row, 1: last owned row,
+                                                                                2: top halo row, 3: bottom halo row */
 int mhip_ctx_set_halo_row(mhip_ctx *ctx, int which, int side, const void *host, int32_t *changed); /* 0: top halo, 1: bottom */
 int mhip_ctx_dem_minmax(mhip_ctx *ctx, float *mn, float *mx, int32_t *has_nan);   /* owned rows only */
 /* kind 0: fill.fill_terrain, kind 1: fill.fill_terrain_no_flats (short/diag from the GLOBAL dem extremes) */
@@ -143,6 +144,15 @@ int mhip_ctx_fill_begin(mhip_ctx *ctx, int kind, double short_, double diag, int
 int mhip_ctx_fill_batch(mhip_ctx *ctx, int kind, int32_t *active);
 int mhip_ctx_fill_halo_changed(mhip_ctx *ctx, int kind, int side);
 int mhip_ctx_fill_end(mhip_ctx *ctx, int kind);   /* kind 0 also computes the bluespot depths */
+/* accumulation on a band: mhip_ctx_zero_raster(ACCUM) once, then { mhip_ctx_run(ACCUM); swap ACCUM edge rows } until no
+ * halo row changes (a halo value <= 0 means "not known yet" and blocks the cells below it). */
+int mhip_ctx_zero_raster(mhip_ctx *ctx, int which);
+/* labelling on a band: local components -> host merges the boundary equivalences of all bands -> global LUT */
+int mhip_ctx_band_ccl_local(mhip_ctx *ctx, int64_t *nlocal);
+int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int64_t nlabels_global);
+/* watersheds on a band: local pointer jumping with pseudo labels on the halo rows, then a boundary LUT */
+int mhip_ctx_band_watershed_local(mhip_ctx *ctx);
+int mhip_ctx_band_apply_neg_lut(mhip_ctx *ctx, int which, const int32_t *lut, int64_t n);
 int mhip_ctx_upload_dem(mhip_ctx *ctx, const float *dem_band);       /* H_local x W host raster */
 int mhip_ctx_upload(mhip_ctx *ctx, int which, const void *host);     /* any raster (for sub-commands) */
 int mhip_ctx_download(mhip_ctx *ctx, int which, void *host);         /* H_local x W */

@@ -68,9 +68,13 @@ struct Nodes {           // global perimeter-node arrays, index = tile * NODE_ST
 
 // ---- the tile kernel (phase 1 when FINAL == false, phase 3 when FINAL == true) ------------------------------
 template <bool FINAL>
+// Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
+// final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
+// they never receive and are never written here.
 __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
-                                                        int64_t W, int ntc, Nodes nd)
+                                                        int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot)
 {
+    auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
     __shared__ uint64_t st[AT * AT];
     __shared__ uint8_t win[(AT + 2) * FS];
     const int tile = blockIdx.x;
@@ -101,6 +105,13 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         }
         uint64_t sum = 1, pending = deg_in;
         if (!inside) pending = 15;  // not a raster cell: never fires
+        const bool halo = inside && halo_row(r0 + r);
+        if (halo) {
+            const double ext = out[(r0 + r) * W + c0 + c];
+            pending = ext > 0.0 ? 0 : 15;
+            sum = ext > 0.0 ? (uint64_t)ext : 0;
+            deg_ext = 0;
+        }
         if (FINAL && deg_ext && inside) {
             const int64_t node = (int64_t)tile * NODE_STRIDE + perim_slot(r, c);
             if (nd.arrived[node] == deg_ext) sum += nd.inflow[node];
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             r += dir_dr((int)code);
             c += dir_dc((int)code);
             if (r < 0 || r >= AT || c < 0 || c >= AT) break;  // leaves the tile (or the raster)
+            if (halo_row(r0 + r)) break;                       // flows into the neighbouring band
             const uint64_t delta = total - ONE_PENDING;
             const uint64_t now = atomicAdd(reinterpret_cast<unsigned long long *>(&st[r * AT + c]), (unsigned long long)delta) + delta;
             if ((now >> DEG_SHIFT) & 0xf) break;
@@ -132,7 +144,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     if (FINAL) {
         for (int i = tid; i < AT * AT; i += 256) {
             const int r = i / AT, c = i - r * AT;
-            if ((r0 + r) < H && (c0 + c) < W) {
+            if ((r0 + r) < H && (c0 + c) < W && !halo_row(r0 + r)) {
                 const uint64_t s = st[i];
                 out[(r0 + r) * W + c0 + c] = ((s >> DEG_SHIFT) & 0xf) ? 0.0 : (double)(s & SUM_MASK);
             }
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         }
         // entry cell?  follow its tile-local path to the cell where it leaves the tile
         bool entry = false;
-        if (inside) {
+        if (inside && !halo_row(r0 + r)) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int nr = r + dir_dr(k), nc = c + dir_dc(k);
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
                     if (gr >= 0 && gr < H && gc >= 0 && gc < W) ex = (uint16_t)perim_slot(pr, pc);  // else: leaves the raster
                     break;
                 }
+                if (halo_row(r0 + nr)) break;  // continues in the neighbouring band
                 pr = nr;
                 pc = nc;
             }
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void accum_graph_walk_kernel(Nodes nd, int64_t
 
 }  // namespace
 
-int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s)
+int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot)
 {
     const int ntr = (int)cdiv(H, AT), ntc = (int)cdiv(W, AT);
     const int64_t ntiles = (int64_t)ntr * ntc, nnodes = ntiles * NODE_STRIDE;
@@ -264,11 +277,11 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     nd.exit_of = reinterpret_cast<uint16_t *>(b + o_exit);
     nd.flags = reinterpret_cast<uint8_t *>(b + o_flags);
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
-    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd);
+    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot);
     hipLaunchKernelGGL(accum_link_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
-    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd);
+    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
     return MHIP_OK;

@@ -510,11 +510,12 @@ int mhip_ctx_band_info(mhip_ctx *c, int64_t *row_off, int64_t *rows_local, int32
 
 int mhip_ctx_get_edge_row(mhip_ctx *c, int which, int side, void *host)
 {
-    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_ && (side == 0 || side == 1), "ctx_get_edge_row(ctx, which, side, host)");
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_ && side >= 0 && side <= 3, "ctx_get_edge_row(ctx, which, side, host)");
     MH_ARG(c->r[which].p, "raster has not been computed or uploaded");
+    MH_ARG(side < 2 || (side == 2 ? c->ht : c->hb), "this band has no halo row on that side");
     MH_HIP(hipSetDevice(c->device));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
-    const int64_t row = side == 0 ? c->ht : c->ht + c->H_owned - 1;
+    const int64_t row = side == 0 ? c->ht : side == 1 ? c->ht + c->H_owned - 1 : side == 2 ? 0 : c->H - 1;
     MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     return MHIP_OK;
@@ -534,6 +535,71 @@ int mhip_ctx_set_halo_row(mhip_ctx *c, int which, int side, const void *host, in
     int ch = 0;
     MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, tmp.p, (int64_t)rowb, &ch, c->stream));
     if (changed) *changed = ch;
+    return MHIP_OK;
+}
+
+int mhip_ctx_zero_raster(mhip_ctx *c, int which)
+{
+    MH_ARG(c && which >= 0 && which < MHIP_R_COUNT_, "ctx_zero_raster(ctx, which)");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, which));
+    MH_HIP(hipMemsetAsync(c->r[which].p, 0, raster_elem(which) * (size_t)(c->H * c->W), c->stream));
+    return MHIP_OK;
+}
+
+/* connected components of the band's LOCAL raster (owned + halo rows) in a band-local label space 1..nlocal */
+int mhip_ctx_band_ccl_local(mhip_ctx *c, int64_t *nlocal)
+{
+    MH_ARG(c && nlocal && c->have[MHIP_R_DEPTHS], "ctx_band_ccl_local needs bluespot depths");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, MHIP_R_LABELS));
+    if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)(c->H * c->W)));
+    MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), c->H, c->W,
+                        nlocal, c->stream));
+    c->nlabels_raw = *nlocal;
+    c->have[MHIP_R_LABELS] = true;
+    c->labels_filtered = false;
+    return MHIP_OK;
+}
+
+/* band-local labels -> global labels through a host-built LUT (nlocal + 1 entries, lut[0] == 0) */
+int mhip_ctx_band_relabel(mhip_ctx *c, const int32_t *lut, int64_t nlocal, int64_t nlabels_global)
+{
+    MH_ARG(c && lut && nlocal >= 0 && c->have[MHIP_R_LABELS], "ctx_band_relabel(ctx, lut, nlocal, nglobal)");
+    MH_HIP(hipSetDevice(c->device));
+    DevBuf d_lut;
+    MH_TRY(d_lut.alloc(4 * (size_t)(nlocal + 1)));
+    MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)(nlocal + 1), hipMemcpyHostToDevice, c->stream));
+    MH_TRY(relabel_lut_dev(c->r[MHIP_R_LABELS].as<int32_t>(), d_lut.as<int32_t>(), nlocal, c->H * c->W, c->stream));
+    c->nlabels = c->nlabels_raw = nlabels_global;
+    c->labels_filtered = true;
+    return MHIP_OK;
+}
+
+/* watersheds inside the band: halo rows are terminals carrying pseudo labels -(1+col) (top) / -(1+W+col) (bottom) */
+int mhip_ctx_band_watershed_local(mhip_ctx *c)
+{
+    MH_ARG(c && c->have[MHIP_R_LABELS] && c->have[MHIP_R_FLOWDIR], "ctx_band_watershed_local needs labels and flow directions");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
+    const size_t n = (size_t)(c->H * c->W);
+    MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * n, hipMemcpyDeviceToDevice, c->stream));
+    MH_TRY(band_pseudo_labels_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, c->ht, c->hb, c->stream));
+    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, 0, c->stream, true));
+    c->have[MHIP_R_WATERSHEDS] = true;
+    return MHIP_OK;
+}
+
+/* raster[i] = lut[-raster[i]-1] wherever raster[i] < 0 (resolves the pseudo labels once the boundary system is solved) */
+int mhip_ctx_band_apply_neg_lut(mhip_ctx *c, int which, const int32_t *lut, int64_t n)
+{
+    MH_ARG(c && lut && n >= 1 && (which == MHIP_R_WATERSHEDS || which == MHIP_R_LABELS) && c->r[which].p, "ctx_band_apply_neg_lut");
+    MH_HIP(hipSetDevice(c->device));
+    DevBuf d_lut;
+    MH_TRY(d_lut.alloc(4 * (size_t)n));
+    MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    MH_TRY(negative_lut_dev(c->r[which].as<int32_t>(), c->H * c->W, d_lut.as<int32_t>(), n, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
     return MHIP_OK;
 }
 
@@ -643,7 +709,8 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     if (c->nranks > 1 || c->ht || c->hb) {
         // row-band mode: the fills run through mhip_ctx_fill_begin/batch (halo refreshes in between); stages whose
         // cross-band protocol is not built yet are refused instead of silently computing band-local results
-        MH_ARG((mask & ~(MHIP_STAGE_FLOWDIR)) == 0, "this stage is not available on a row band yet (use mhip_ctx_fill_* and FLOWDIR)");
+        MH_ARG((mask & ~(MHIP_STAGE_FLOWDIR | MHIP_STAGE_ACCUM)) == 0,
+               "this stage runs through the band entry points on a row band (mhip_ctx_fill_*, mhip_ctx_band_*)");
     }
 
     if (mask & MHIP_STAGE_FILL) {
@@ -698,7 +765,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
         MH_TRY(ctx_events(c, MHIP_STAGE_ACCUM, &e0, &e1));
         MH_HIP(hipEventRecord(*e0, s));
-        MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), H, W, s));
+        MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), H, W, s, c->ht, c->hb));
         MH_HIP(hipEventRecord(*e1, s));
         c->ev_valid[MHIP_STAGE_ACCUM] = true;
         c->have[MHIP_R_ACCUM] = true;

@@ -144,7 +144,7 @@ int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_ou
 int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
 // accum.hip
-int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s);
+int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0);
 // ccl.hip   (d_tmp: H*W int32 scratch)
 int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
                  hipStream_t s);
@@ -161,7 +161,10 @@ int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int6
 int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s);
 int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
 // watershed.hip
-int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s);
+int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s,
+                   bool band_mode = false);
+int band_pseudo_labels_dev(int32_t *d_ws, int64_t H, int64_t W, int top, int bottom, hipStream_t s);
+int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nlut, hipStream_t s);
 
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -102,9 +102,39 @@ __global__ __launch_bounds__(256) void ws_assign_kernel(const int32_t *__restric
     lab[i] = lab[t];                           // lab[t] is an input label: labelled cells are never written
 }
 
+// band mode: halo rows become terminals carrying pseudo labels -(1+col) (top) / -(1+W+col) (bottom)
+__global__ void ws_pseudo_kernel(int32_t *ws, int64_t H, int64_t W, int top, int bottom)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    if (top) ws[c] = -(int32_t)(1 + c);
+    if (bottom) ws[(H - 1) * W + c] = -(int32_t)(1 + W + c);
+}
+__global__ void ws_neg_lut_kernel(int32_t *lab, int64_t n, const int32_t *__restrict__ lut, int64_t nlut)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = lab[i];
+    if (v < 0 && (int64_t)(-(int64_t)v - 1) < nlut) lab[i] = lut[-(int64_t)v - 1];
+}
+
 }  // namespace
 
-int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s)
+int band_pseudo_labels_dev(int32_t *d_ws, int64_t H, int64_t W, int top, int bottom, hipStream_t s)
+{
+    hipLaunchKernelGGL(ws_pseudo_kernel, dim3((unsigned)cdiv(W, 256)), dim3(256), 0, s, d_ws, H, W, top, bottom);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nlut, hipStream_t s)
+{
+    hipLaunchKernelGGL(ws_neg_lut_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_lab, n, d_lut, nlut);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s, bool band_mode)
 {
     const int64_t n = H * W;
     if (n >= (int64_t)NONE - 1) {
@@ -122,6 +152,10 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     MH_HIP(hipMemcpyAsync(&interior_nodir, d_cnt, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     uint32_t *q = nullptr;
+    if (interior_nodir && band_mode) {
+        set_error("watersheds on a row band need every flow path to leave the raster (interior NODIR cell found)");
+        return MHIP_EINVAL;
+    }
     if (interior_nodir) {
         MH_TRY(Q.alloc(4 * (size_t)n));
         q = Q.as<uint32_t>();

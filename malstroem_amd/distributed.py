@@ -19,7 +19,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_FLOWDIR
+from ._lib import R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_ACCUM, STAGE_FLOWDIR
 from .pipeline import RASTERS
 
 __all__ = ["band_rows", "Comm", "ThreadComm", "TorchComm", "HipBand", "BandPipeline"]
@@ -216,6 +216,29 @@ class HipBand(object):
         _lib.call("mhip_ctx_run", self._ctx, STAGE_FLOWDIR)
         _lib.call("mhip_ctx_sync", self._ctx)
 
+    def zero_raster(self, name):
+        _lib.call("mhip_ctx_zero_raster", self._ctx, RASTERS[name])
+
+    def run_accum(self):
+        _lib.call("mhip_ctx_run", self._ctx, STAGE_ACCUM)
+        _lib.call("mhip_ctx_sync", self._ctx)
+
+    def ccl_local(self):
+        n = ctypes.c_int64(0)
+        _lib.call("mhip_ctx_band_ccl_local", self._ctx, ctypes.byref(n))
+        return int(n.value)
+
+    def relabel(self, lut, nlabels_global):
+        lut = np.ascontiguousarray(lut, dtype=np.int32)
+        _lib.call("mhip_ctx_band_relabel", self._ctx, _lib.ptr(lut), _lib.i64(lut.size - 1), _lib.i64(nlabels_global))
+
+    def watershed_local(self):
+        _lib.call("mhip_ctx_band_watershed_local", self._ctx)
+
+    def apply_neg_lut(self, name, lut):
+        lut = np.ascontiguousarray(lut, dtype=np.int32)
+        _lib.call("mhip_ctx_band_apply_neg_lut", self._ctx, RASTERS[name], _lib.ptr(lut), _lib.i64(lut.size))
+
     def get_int(self, key):
         v = ctypes.c_int64(0)
         _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))
@@ -297,6 +320,123 @@ class BandPipeline(object):
         """D8 on the no-flats surface, edges outward; afterwards the flow-direction halo rows are valid too."""
         self.band.run_flowdir()
         self._swap_edges("flowdir")
+
+    def accum(self):
+        """flow.accumulated_flow over all bands: local accumulation with the neighbours' edge values as sources, repeated
+        until no halo row changes (one iteration per band crossing of the longest flow path)."""
+        b = self.band
+        b.zero_raster("accum")
+        self.exchanges["accum"] = 0
+        while True:
+            b.run_accum()
+            ch_top, ch_bot = self._swap_edges("accum")
+            self.exchanges["accum"] += 1
+            if not self.comm.allreduce_max(1.0 if (ch_top or ch_bot) else 0.0):
+                break
+
+    def label(self):
+        """label.connected_components over all bands with scipy's numbering (order of first raster pixel).
+
+        Every band labels its local raster (owned + halo rows); the four boundary rows of every band are gathered,
+        the cross-band equivalences are solved identically on every rank, and each band rewrites its labels through
+        a LUT.  Returns the global number of labels."""
+        import scipy.sparse
+        import scipy.sparse.csgraph
+        b, comm, W = self.band, self.comm, self.W
+        nloc = b.ccl_local()
+        rows = dict(nloc=nloc, first=b.get_edge_row("labels", 0), last=b.get_edge_row("labels", 1),
+                    top=b.get_edge_row("labels", 2) if self.has_up else None,
+                    bot=b.get_edge_row("labels", 3) if self.has_down else None)
+        allrows = comm.allgather(rows)
+        R = comm.size
+        key = lambda r, lab: (np.int64(r) << 32) | lab.astype(np.int64)
+        # equivalences between band r and r+1: r.last == (r+1).top and r.bot == (r+1).first, cell by cell
+        ea, eb = [], []
+        for r in range(R - 1):
+            up, dn = allrows[r], allrows[r + 1]
+            for a, c in ((up["last"], dn["top"]), (up["bot"], dn["first"])):
+                m = (a > 0) & (c > 0)
+                ea.append(key(r, a[m]))
+                eb.append(key(r + 1, c[m]))
+        ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
+        eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
+        nodes, inv = np.unique(np.concatenate([ea, eb]), return_inverse=True)
+        nn = nodes.size
+        if nn:
+            g = scipy.sparse.coo_matrix((np.ones(ea.size, np.int8), (inv[:ea.size], inv[ea.size:])), shape=(nn, nn))
+            ncls, cls = scipy.sparse.csgraph.connected_components(g, directed=False)
+        else:
+            ncls, cls = 0, np.zeros(0, np.int64)
+        node_rank = (nodes >> 32).astype(np.int64)
+        node_lab = (nodes & 0xffffffff).astype(np.int64)
+        # phantom = local component made of halo cells only (no owned cell): in a halo row but not in the adjacent owned row
+        phantom = np.zeros(nn, bool)
+        for r in range(R):
+            rr = allrows[r]
+            mine = node_rank == r
+            for halo, edge in ((rr["top"], rr["first"]), (rr["bot"], rr["last"])):
+                if halo is None:
+                    continue
+                ph = np.setdiff1d(halo[halo > 0], edge[edge > 0])
+                phantom |= mine & np.isin(node_lab, ph)
+        # class owner = smallest rank with a real member; representative = smallest local label of the owner's members
+        big = np.int64(1) << 62
+        score = np.where(phantom, big, (node_rank << 32) | node_lab)
+        rep_score = np.full(ncls, big, np.int64)
+        np.minimum.at(rep_score, cls, score)
+        is_rep = score == rep_score[cls]
+        # ---- my LUT: own-numbered labels are all local labels except phantoms and non-representative class members
+        mine = node_rank == comm.rank
+        drop = np.zeros(nloc + 1, bool)
+        drop[0] = True
+        drop[node_lab[mine & ~is_rep]] = True
+        keep = ~drop
+        n_own = int(keep.sum())
+        offsets = np.concatenate([[0], np.cumsum(comm.allgather(n_own))])
+        lut = np.zeros(nloc + 1, np.int64)
+        lut[keep] = offsets[comm.rank] + np.arange(1, n_own + 1)
+        # owners publish the global label of the classes they own; members look it up
+        my_reps = mine & is_rep
+        published = comm.allgather((cls[my_reps], lut[node_lab[my_reps]]))
+        class_label = np.zeros(ncls, np.int64)
+        for ids, labs in published:
+            class_label[ids] = labs
+        members = mine & ~is_rep
+        lut[node_lab[members]] = class_label[cls[members]]
+        self.nlabels = int(offsets[-1])
+        self.label_range = (int(offsets[comm.rank]) + 1, int(offsets[comm.rank + 1]))
+        b.relabel(lut.astype(np.int32), self.nlabels)
+        return self.nlabels
+
+    def watershed(self):
+        """flow.watersheds_from_labels over all bands: local pointer jumping with pseudo labels on the halo rows, then the
+        boundary system (2 rows per band) is solved identically on every rank and applied as a LUT."""
+        b, comm, W = self.band, self.comm, self.W
+        b.watershed_local()
+        rows = comm.allgather((b.get_edge_row("watersheds", 0), b.get_edge_row("watersheds", 1)))
+        R = comm.size
+        # node(r, s, c) = (2r + s) * W + c for the first (s=0) / last (s=1) owned row of band r
+        vals = np.concatenate([np.concatenate(p) for p in rows]).astype(np.int64)
+        for r in range(R):
+            for s_ in (0, 1):
+                seg = vals[(2 * r + s_) * W:(2 * r + s_ + 1) * W]
+                neg = seg < 0
+                idx = -seg[neg] - 1
+                up = idx < W          # pseudo label of band r's top halo = last owned row of band r-1
+                tgt = np.where(up, (2 * (r - 1) + 1) * W + idx, (2 * (r + 1)) * W + (idx - W))
+                seg[neg] = -(tgt + 1)
+        for _ in range(64):
+            neg = vals < 0
+            if not neg.any():
+                break
+            vals[neg] = vals[-vals[neg] - 1]
+        vals[vals < 0] = 0            # a flow cycle across bands: stays unassigned
+        lut = np.zeros(2 * W, np.int64)
+        if self.has_up:
+            lut[:W] = vals[(2 * (comm.rank - 1) + 1) * W:(2 * (comm.rank - 1) + 2) * W]
+        if self.has_down:
+            lut[W:] = vals[(2 * (comm.rank + 1)) * W:(2 * (comm.rank + 1) + 1) * W]
+        b.apply_neg_lut("watersheds", lut.astype(np.int32))
 
     def download(self, name):
         return self.band.download(name)

@@ -19,7 +19,8 @@ class CpuBand(object):
         pass
 
     def _dtype(self, name):
-        return {"dem": np.float32, "filled": np.float32, "depths": np.float32, "noflat": np.float64, "flowdir": np.uint8}[name]
+        return {"dem": np.float32, "filled": np.float32, "depths": np.float32, "noflat": np.float64, "flowdir": np.uint8,
+                "accum": np.float64, "labels": np.int32, "watersheds": np.int32}[name]
 
     def _raster(self, name):
         if name not in self.r:
@@ -33,7 +34,8 @@ class CpuBand(object):
         return self.r[name][self.ht:self.ht + self.nrows].copy()
 
     def get_edge_row(self, name, side):
-        return self._raster(name)[self.ht if side == 0 else self.ht + self.nrows - 1].copy()
+        row = {0: self.ht, 1: self.ht + self.nrows - 1, 2: 0, 3: self.H - 1}[side]
+        return self._raster(name)[row].copy()
 
     def set_halo_row(self, name, side, row):
         a = self._raster(name)
@@ -114,6 +116,94 @@ class CpuBand(object):
             fd[gr == maxr, 0] = 5
             fd[gr == maxr, maxc] = 3
         self._raster("flowdir")[...] = fd
+
+    def zero_raster(self, name):
+        self._raster(name)[...] = 0
+
+    def run_accum(self):
+        """Kahn accumulation of the owned rows; halo cells are sources when their value is known (> 0), else they block."""
+        fd, acc = self.r["flowdir"], self._raster("accum")
+        H, W = self.H, self.W
+        DR = [-1, -1, 0, 1, 1, 1, 0, -1]
+        DC = [0, 1, 1, 1, 0, -1, -1, -1]
+        halo = np.zeros(H, bool)
+        if self.ht:
+            halo[0] = True
+        if self.hb:
+            halo[H - 1] = True
+        val = np.zeros((H, W))
+        pend = np.zeros((H, W), int)
+        for r in range(H):
+            for c in range(W):
+                if halo[r]:
+                    val[r, c] = acc[r, c] if acc[r, c] > 0 else 0
+                    pend[r, c] = 0 if acc[r, c] > 0 else 99
+                    continue
+                val[r, c] = 1
+                for k in range(8):
+                    nr, nc = r + DR[k], c + DC[k]
+                    if 0 <= nr < H and 0 <= nc < W and fd[nr, nc] <= 7 and fd[nr, nc] == (k + 4) % 8:
+                        pend[r, c] += 1
+        stack = [(r, c) for r in range(H) for c in range(W) if pend[r, c] == 0]
+        done = np.zeros((H, W), bool)
+        while stack:
+            r, c = stack.pop()
+            done[r, c] = True
+            d = fd[r, c]
+            if d > 7:
+                continue
+            nr, nc = r + DR[d], c + DC[d]
+            if not (0 <= nr < H and 0 <= nc < W) or halo[nr]:
+                continue
+            val[nr, nc] += val[r, c]
+            pend[nr, nc] -= 1
+            if pend[nr, nc] == 0:
+                stack.append((nr, nc))
+        own = ~halo
+        acc[own] = np.where(done[own], val[own], 0.0)
+
+    def ccl_local(self):
+        lab, n = oracle.connected_components(self.r["depths"])
+        self._raster("labels")[...] = lab
+        return n
+
+    def relabel(self, lut, nlabels_global):
+        self.r["labels"][...] = np.asarray(lut)[self.r["labels"]]
+
+    def watershed_local(self):
+        ws = self._raster("watersheds")
+        ws[...] = self.r["labels"]
+        if self.ht:
+            ws[0] = -(1 + np.arange(self.W))
+        if self.hb:
+            ws[-1] = -(1 + self.W + np.arange(self.W))
+        # nearest labelled cell downstream (labels incl. the negative pseudo labels are terminals), 0 when the path leaves
+        fd = self.r["flowdir"]
+        DR = [-1, -1, 0, 1, 1, 1, 0, -1]
+        DC = [0, 1, 1, 1, 0, -1, -1, -1]
+        out = ws.copy()
+        for r in range(self.H):
+            for c in range(self.W):
+                if ws[r, c] != 0:
+                    continue
+                pr, pc, res = r, c, 0
+                for _ in range(self.H * self.W):
+                    d = fd[pr, pc]
+                    if d > 7:
+                        break
+                    pr, pc = pr + DR[d], pc + DC[d]
+                    if not (0 <= pr < self.H and 0 <= pc < self.W):
+                        break
+                    if ws[pr, pc] != 0:
+                        res = ws[pr, pc]
+                        break
+                out[r, c] = res
+        ws[...] = out
+
+    def apply_neg_lut(self, name, lut):
+        a = self.r[name]
+        neg = a < 0
+        a[neg] = np.asarray(lut)[-a[neg] - 1]
 
     def get_int(self, key):
         return 0

@@ -16,14 +16,20 @@ from _cpu_band import CpuBand
 from malstroem_amd.distributed import BandPipeline, ThreadComm, band_rows
 
 ROOT = Path(__file__).resolve().parent.parent
+KEYS = ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")
 
 
 def reference(dem):
     filled = oracle.fill_terrain(dem)
     short, diag = oracle.minimum_safe_short_and_diag(dem)
     fnf = oracle.fill_terrain_no_flats(dem, short, diag)
-    return dict(filled=filled, depths=oracle.depths(filled, dem), noflat=fnf, flowdir=oracle.terrain_flowdirection(fnf),
-                short_diag=(short, diag))
+    fd = oracle.terrain_flowdirection(fnf)
+    depths = oracle.depths(filled, dem)
+    lab, n = oracle.connected_components(depths)
+    ws = lab.copy()
+    oracle.watersheds_from_labels(fd, ws, 0)
+    return dict(filled=filled, depths=depths, noflat=fnf, flowdir=fd, accum=oracle.accumulated_flow(fd), labels=lab,
+                nlabels=n, watersheds=ws, short_diag=(short, diag))
 
 
 def test_band_rows_partition():
@@ -47,16 +53,21 @@ def test_protocol_threadcomm_cpu_backend(nbands):
         p.fill()
         p.noflat()
         p.flowdir()
-        out[comm.rank] = {k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir")}
+        p.accum()
+        n = p.label()
+        p.watershed()
+        out[comm.rank] = {k: p.download(k) for k in KEYS}
         out[comm.rank]["short_diag"] = (p.short, p.diag)
+        out[comm.rank]["nlabels"] = n
 
     threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
     [t.start() for t in threads]
     [t.join(300) for t in threads]
     assert all(o is not None for o in out)
-    for k in ("filled", "depths", "noflat", "flowdir"):
+    for k in KEYS:
         assert np.array_equal(np.concatenate([o[k] for o in out]), ref[k]), k
     assert out[0]["short_diag"] == ref["short_diag"]
+    assert all(o["nlabels"] == ref["nlabels"] for o in out)
 
 
 WORKER = r'''
@@ -70,9 +81,9 @@ dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.
 dem = fbm(90, 70, beta=2.0, seed=4)
 p = BandPipeline(TorchComm(), dem.shape, backend_factory=CpuBand)
 p.upload_dem(dem[p.row0:p.row0 + p.nrows])
-p.fill(); p.noflat(); p.flowdir()
-np.savez(os.path.join(os.environ["OUT"], "rank%d.npz" % dist.get_rank()), row0=p.row0,
-         **{k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir")})
+p.fill(); p.noflat(); p.flowdir(); p.accum(); n = p.label(); p.watershed()
+np.savez(os.path.join(os.environ["OUT"], "rank%d.npz" % dist.get_rank()), row0=p.row0, nlabels=n,
+         **{k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")})
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -90,5 +101,6 @@ def test_protocol_gloo_processes(world, tmp_path):
     dem = fbm(90, 70, beta=2.0, seed=4)
     ref = reference(dem)
     parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
-    for k in ("filled", "depths", "noflat", "flowdir"):
+    for k in KEYS:
         assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
+    assert all(int(p["nlabels"]) == ref["nlabels"] for p in parts)

@@ -1,5 +1,6 @@
 """GPU: several row bands of one DEM (one band context each, driven by threads over the in-process ThreadComm on a
-single MI355X) must reproduce the undivided raster bit for bit: fill, depths, no-flats fill, D8."""
+single MI355X) must reproduce the undivided raster bit for bit: fill, depths, no-flats fill, D8, accumulation,
+bluespot labels (scipy numbering) and watersheds."""
 import threading
 
 import numpy as np
@@ -23,7 +24,11 @@ def run_bands(dem, nbands):
             p.fill()
             p.noflat()
             p.flowdir()
-            out[comm.rank] = {k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir")}
+            p.accum()
+            n = p.label()
+            p.watershed()
+            out[comm.rank] = {k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")}
+            out[comm.rank]["nlabels"] = n
             out[comm.rank]["short_diag"] = (p.short, p.diag)
             out[comm.rank]["exchanges"] = dict(p.exchanges)
             p.close()
@@ -47,6 +52,13 @@ def test_bands_match_reference_fixture(nbands):
     assert np.array_equal(np.concatenate([o["noflat"] for o in out]), fx["filled_no_flats"])
     assert np.array_equal(np.concatenate([o["flowdir"] for o in out]), fx["flowdir_noflats"])
     assert out[0]["short_diag"] == (7.275957614183426e-12, 1.0289757937229989e-11)
+    acc = np.concatenate([o["accum"] for o in out])
+    assert acc.min() >= 1 and acc.max() == 11158 and acc.sum() == 3578615
+    lab, n = oracle.connected_components(fx["depths"])
+    assert out[0]["nlabels"] == n == 523 and np.array_equal(np.concatenate([o["labels"] for o in out]), lab)
+    ws = lab.copy()
+    oracle.watersheds_from_labels(fx["flowdir_noflats"], ws, 0)
+    assert np.array_equal(np.concatenate([o["watersheds"] for o in out]), ws)
 
 
 @pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (4, 1024, 1024), (4, 1000, 130)])
@@ -58,5 +70,13 @@ def test_bands_match_oracle(nbands, h, w):
     fnf = oracle.fill_terrain_no_flats(dem, short, diag)
     assert np.array_equal(np.concatenate([o["filled"] for o in out]), filled)
     assert np.array_equal(np.concatenate([o["noflat"] for o in out]), fnf)
-    assert np.array_equal(np.concatenate([o["flowdir"] for o in out]), oracle.terrain_flowdirection(fnf))
+    fd = oracle.terrain_flowdirection(fnf)
+    assert np.array_equal(np.concatenate([o["flowdir"] for o in out]), fd)
     assert out[0]["short_diag"] == (short, diag)
+    assert np.array_equal(np.concatenate([o["accum"] for o in out]), oracle.accumulated_flow(fd))
+    lab, n = oracle.connected_components(oracle.depths(filled, dem))
+    assert all(o["nlabels"] == n for o in out)
+    assert np.array_equal(np.concatenate([o["labels"] for o in out]), lab)
+    ws = lab.copy()
+    oracle.watersheds_from_labels(fd, ws, 0)
+    assert np.array_equal(np.concatenate([o["watersheds"] for o in out]), ws)

@@ -11,9 +11,14 @@ A "step" is one pass of the whole chain over the DEM:
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384] [--beta 2.0]
 
-N > 1 is launched by torch.distributed.run (one process per GPU).  torch is used ONLY for the
-barrier / max-over-ranks of the timing (gloo); the product itself is torch-free.  Until the RCCL halo
-exchange lands, N > 1 runs one independent DEM replica per GPU ("replicas only", weak scaling).
+N > 1 is launched by torch.distributed.run (one process per GPU).  torch is used ONLY for rank plumbing
+(gloo: barrier, max-over-ranks of the timing, moving a few halo rows); the product itself is torch-free.
+N > 1 is WEAK scaling of ONE DEM: the global raster is (N * size) x size, row-banded over the GPUs
+(malstroem_amd.distributed.BandPipeline: halo-row exchange for the two fills, D8, accumulation, labelling with
+cross-band equivalences, watersheds).  Each band is the same fBm tile, mirrored on odd ranks so that the global
+surface is continuous across band boundaries.  The per-label record reductions (label_stats, label_count,
+pour points) are not band-merged yet and are left out of the N > 1 step (they are ~7 % of the N = 1 step).
+Should the band path fail on a box, the run falls back to one independent DEM per GPU and says so.
 
 Only the `cpu_baseline` leg touches oracle/ (the single-thread C restatement of the reference path),
 on a bounded sample, on rank 0 at N = 1.
@@ -57,6 +62,25 @@ def fbm(n, beta=2.0, seed=42):
     z -= z.min()
     z *= 100.0 / z.max()
     return z.astype(np.float32)
+
+
+def pmc_traffic(stage, n):
+    """HBM bytes of the stage's kernels from the committed rocprofv3 PMC passes (profiles/r01c_pmc_hbm_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2; FETCH_SIZE doubled for the 16-byte-per-lane
+    streaming reads of d8 as MI355X_MICROARCH.md prescribes, left as reported for the 4-byte tile loads of the fills)."""
+    path = ROOT / "profiles" / "r01c_pmc_hbm_traffic.json"
+    if n != 16384 or not path.exists():
+        return None
+    kernels = {"flowdir": ("d8_kernel", 2.0), "fill": ("fill_round_kernel<float", 1.0), "noflat": ("fill_round_kernel<double", 1.0),
+               "accum": ("accum_", 1.0), "label": ("ccl_", 1.0), "watershed": ("ws_", 1.0)}
+    if stage not in kernels:
+        return None
+    prefix, fcorr = kernels[stage]
+    tot = 0.0
+    for row in json.loads(path.read_text()):
+        if row["kernel"].startswith(prefix):
+            tot += (row["fetch_size_kb"] * fcorr + row["write_size_kb"]) * 1024.0
+    return {"hbm_bytes_per_stage": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "source": "profiles/r01c_pmc_hbm_traffic.json"}
 
 
 def cpu_baseline(dem, sample):
@@ -109,32 +133,60 @@ def main():
 
     n = args.size
     t_gen = time.perf_counter()
-    dem = fbm(n, beta=args.beta, seed=42 + rank)
+    dem = fbm(n, beta=args.beta, seed=42)   # every rank builds the same tile (bands mirror it on odd ranks)
     t_gen = time.perf_counter() - t_gen
 
-    pipe = HydroPipeline(dem.shape, device=local_rank)
-    pipe.upload("dem", dem)
+    ndev = _lib.device_count()
+    device = local_rank % ndev
+    parallelism = "1 GPU"
+    stage_names = STAGES
+    band = None
+    if world > 1:
+        try:
+            from malstroem_amd.distributed import BandPipeline, TorchComm
+            band = BandPipeline(TorchComm(), (n * world, n), device=device)
+            band.upload_dem(dem if rank % 2 == 0 else dem[::-1])
+            parallelism = "row bands of one %dx%d DEM over %d GPUs, halo rows host-staged over gloo" % (n * world, n, world)
+            stage_names = ["fill", "noflat", "flowdir", "accum", "label", "watershed"]
+        except Exception as e:  # pragma: no cover - only on a multi-GPU node
+            band = None
+            parallelism = "replicas only (band mode failed: %s)" % (str(e)[:80],)
+    pipe = None
+    if band is None:
+        pipe = HydroPipeline(dem.shape, device=device)
+        pipe.upload("dem", dem)
 
-    def step():
-        pipe.run("fill", "noflat", "flowdir", "accum", "label")
-        pipe.apply_keep(None)
-        pipe.run("watershed", "pourpoints")
+    stage_ms = {s: 0.0 for s in stage_names}
+
+    def step(record):
+        if band is not None:
+            for name, fn in (("fill", band.fill), ("noflat", band.noflat), ("flowdir", band.flowdir), ("accum", band.accum),
+                             ("label", band.label), ("watershed", band.watershed)):
+                t = time.perf_counter()
+                fn()
+                if record:
+                    stage_ms[name] += (time.perf_counter() - t) * 1e3
+        else:
+            pipe.run("fill", "noflat", "flowdir", "accum", "label")
+            pipe.apply_keep(None)
+            pipe.run("watershed", "pourpoints")
+            pipe.sync()
+            if record:
+                for s in stage_names:
+                    stage_ms[s] += pipe.stage_ms(s)
 
     def barrier():
-        pipe.sync()
+        if pipe is not None:
+            pipe.sync()
         if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
-        step()
+        step(False)
     barrier()
     t0 = time.perf_counter()
-    stage_ms = {s: 0.0 for s in STAGES}
     for _ in range(args.steps):
-        step()
-        pipe.sync()
-        for s in STAGES:
-            stage_ms[s] += pipe.stage_ms(s)
+        step(True)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -146,16 +198,21 @@ def main():
     cells = float(n) * n
     ms_per_step = elapsed * 1e3 / args.steps
     value = cells * world * args.steps / elapsed / 1e6
-    for s in STAGES:
+    for s in stage_names:
         stage_ms[s] /= args.steps
 
+    if band is not None:
+        info = {"nlabels": band.nlabels, "halo_exchanges": dict(band.exchanges)}
+    else:
+        info = {k: pipe.get_int(k) for k in ("fill_rounds", "noflat_rounds", "nlabels", "fill_tiles", "fill_visits", "fill_cycles",
+                                            "noflat_visits", "noflat_cycles")}
     if rank == 0:
         stages = {}
-        for s in STAGES:
+        for s in stage_names:
             gbs = ALG_BYTES[s] * cells / (stage_ms[s] * 1e-3) / 1e9 if stage_ms[s] > 0 else 0.0
             stages[s] = {"ms": round(stage_ms[s], 3), "alg_bytes_per_cell": ALG_BYTES[s], "achieved_GBs": round(gbs, 1),
                          "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
-        dominant = max(STAGES, key=lambda s: stage_ms[s])
+        dominant = max(stage_names, key=lambda s: stage_ms[s])
         d8 = stages["flowdir"]
         out = {
             "metric": "Mcells/s fill->D8->accum->label(+watershed) on %d^2 f32 fBm DEM" % n,
@@ -164,23 +221,21 @@ def main():
             "dtype": "f32 fill / f64 no-flats+D8+accum / u8 flowdir / i32 labels", "data": "synthetic",
             "config": {"workload": "%dx%d fBm beta=%g float32 DEM per GPU: fill+depths -> no-flats fill -> D8 -> accumulation -> "
                                    "CCL+label_stats -> watersheds+label_count -> pour points" % (n, n, args.beta),
-                       "parallelism": "1 GPU" if world == 1 else "replicas only (one DEM per GPU, no halo exchange yet)",
-                       "fill_rounds": pipe.get_int("fill_rounds"), "noflat_rounds": pipe.get_int("noflat_rounds"),
-                       "nlabels": pipe.get_int("nlabels"),
-                       "fill_tiles": pipe.get_int("fill_tiles"), "fill_visits": pipe.get_int("fill_visits"),
-                       "fill_cycles": pipe.get_int("fill_cycles"), "noflat_visits": pipe.get_int("noflat_visits"),
-                       "noflat_cycles": pipe.get_int("noflat_cycles"), "dem_generation_s": round(t_gen, 1)},
+                       "parallelism": parallelism, "dem_generation_s": round(t_gen, 1), **info},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": None,
+                         "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": pmc_traffic(dominant, n),
                          "note": "dominant stage by device time; algorithmic bytes of the whole stage / stage time (HIP events)"},
             "d8_roofline": {"bound": "hbm", "kernel": "d8_kernel", "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "traffic": None},
+                            "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "traffic": pmc_traffic("flowdir", n)},
             "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dem, min(args.cpu_sample, n))
         print(json.dumps(out), flush=True)
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
+    if band is not None:
+        band.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,163 @@
+"""GPU: edge cases and randomised inputs beyond the D8-of-a-no-flats-surface pipeline, always against the oracle
+(or scipy for the labelling): flow cycles, interior sinks, inward pointing edges, tiny / ragged rasters, masks with
+every kind of adjacency, explicit nlabels, error behaviour."""
+import numpy as np
+import pytest
+import scipy.ndimage
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def alg():
+    import malstroem_amd.algorithms as a
+    assert a.hip.available
+    return a
+
+
+def random_acyclic_flow(rng, h, w, edges, sink_frac=0.03):
+    """Random D8 codes that always descend a random strictly ordered potential => acyclic; `edges`: outward / nodir / free."""
+    pot = rng.permutation(h * w).reshape(h, w).astype(np.int64)
+    fd = np.full((h, w), 8, np.uint8)
+    DR = [-1, -1, 0, 1, 1, 1, 0, -1]
+    DC = [0, 1, 1, 1, 0, -1, -1, -1]
+    for r in range(h):
+        for c in range(w):
+            cand = [k for k in range(8) if 0 <= r + DR[k] < h and 0 <= c + DC[k] < w and pot[r + DR[k], c + DC[k]] < pot[r, c]]
+            if cand and rng.random() > sink_frac:
+                fd[r, c] = cand[rng.integers(len(cand))]
+    if edges == "outward":
+        from malstroem_amd.algorithms.flow import set_edges_flow_outward
+        set_edges_flow_outward(fd)
+    elif edges == "nodir":
+        fd[0, :] = fd[-1, :] = 8
+        fd[:, 0] = fd[:, -1] = 8
+    return fd
+
+
+@pytest.mark.parametrize("edges", ["outward", "nodir", "free"])
+@pytest.mark.parametrize("seed", range(6))
+def test_watersheds_on_random_acyclic_flow_with_sinks(alg, edges, seed):
+    rng = np.random.default_rng(100 + seed)
+    h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    fd = random_acyclic_flow(rng, h, w, edges)
+    lab = np.where(rng.random((h, w)) < 0.15, rng.integers(1, 9, (h, w)), 0).astype(np.int32)
+    want = lab.copy()
+    oracle.watersheds_from_labels(fd, want, 0)
+    got = lab.copy()
+    alg.flow.watersheds_from_labels(fd, got, 0)
+    assert np.array_equal(got, want)
+    # a non-zero `unassigned` marker
+    lab2 = np.where(lab == 0, -7, lab).astype(np.int32)
+    want2, got2 = lab2.copy(), lab2.copy()
+    oracle.watersheds_from_labels(fd, want2, -7)
+    alg.flow.watersheds_from_labels(fd, got2, -7)
+    assert np.array_equal(got2, want2)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_accumulation_on_random_flow_incl_cycles(alg, seed):
+    rng = np.random.default_rng(200 + seed)
+    h, w = int(rng.integers(2, 70)), int(rng.integers(2, 140))
+    fd = rng.integers(0, 9, (h, w)).astype(np.uint8)     # arbitrary codes: cycles, sinks, off-raster flow
+    assert np.array_equal(alg.flow.accumulated_flow(fd), oracle.accumulated_flow(fd))
+    fd2 = random_acyclic_flow(rng, h, w, "free", sink_frac=0.0)
+    acc = alg.flow.accumulated_flow(fd2)
+    assert np.array_equal(acc, oracle.accumulated_flow(fd2)) and acc.min() >= 1
+
+
+def test_watersheds_terminate_on_a_cycle_through_edge_cells(alg):
+    fd = np.full((4, 5), 8, np.uint8)
+    fd[0, 1], fd[0, 2] = 2, 6          # two edge cells pointing at each other: the reference never returns
+    fd[1, 1] = 0                       # drains into the cycle
+    lab = np.zeros((4, 5), np.int32)
+    lab[3, 3] = 5
+    alg.flow.watersheds_from_labels(fd, lab, 0)
+    assert lab[0, 1] == 0 and lab[0, 2] == 0 and lab[1, 1] == 0 and lab[3, 3] == 5
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (7, 1), (2, 2), (3, 3), (3, 130), (130, 3), (65, 63), (64, 64), (63, 127)])
+def test_tiny_and_ragged_rasters(alg, shape):
+    rng = np.random.default_rng(sum(shape))
+    dem = (rng.random(shape) * 10).astype(np.float32)
+    filled = alg.fill.fill_terrain(dem)
+    assert np.array_equal(filled, oracle.fill_terrain(dem))
+    short, diag = alg.fill.minimum_safe_short_and_diag(dem)
+    assert (short, diag) == oracle.minimum_safe_short_and_diag(dem)
+    fnf = alg.fill.fill_terrain_no_flats(dem, short, diag)
+    assert np.array_equal(fnf, oracle.fill_terrain_no_flats(dem, short, diag))
+    for outward in (True, False):
+        assert np.array_equal(alg.flow.terrain_flowdirection(fnf, outward), oracle.terrain_flowdirection(fnf, outward))
+    fd = alg.flow.terrain_flowdirection(fnf)
+    assert np.array_equal(alg.flow.accumulated_flow(fd), oracle.accumulated_flow(fd))
+    lab, n = alg.label.connected_components(alg.fill.bluespot_depths(filled, dem))
+    olab, on = oracle.connected_components(oracle.depths(filled, dem))
+    assert n == on and np.array_equal(lab, olab)
+    assert np.array_equal(alg.label.label_count(lab), np.bincount(lab.ravel()))
+
+
+def test_no_flats_defaults_equal_plain_fill_in_float64(alg):
+    rng = np.random.default_rng(5)
+    dem = (rng.random((50, 60)) * 5).astype(np.float32)
+    assert np.array_equal(alg.fill.fill_terrain_no_flats(dem), oracle.fill_terrain_no_flats(dem, 0.0, 0.0))
+    assert np.array_equal(alg.fill.fill_terrain_no_flats(dem), alg.fill.fill_terrain(dem).astype(np.float64))
+
+
+def test_fill_with_nan_cells_matches_the_reference_comparisons(alg):
+    rng = np.random.default_rng(6)
+    dem = (rng.random((40, 45)) * 5).astype(np.float32)
+    dem[10, 10] = dem[20:23, 30] = np.nan          # interior NaN: never updated, never wins a min (fill.py:37, _fill.pyx:48)
+    got, want = alg.fill.fill_terrain(dem), oracle.fill_terrain(dem)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_connected_components_random_masks_equal_scipy(alg, seed):
+    rng = np.random.default_rng(300 + seed)
+    h, w = int(rng.integers(1, 200)), int(rng.integers(1, 300))
+    for density in (0.05, 0.4, 0.6, 0.95):
+        mask = rng.random((h, w)) < density
+        want, n = scipy.ndimage.label(mask, structure=np.ones((3, 3)))
+        for data in (mask, mask.astype(np.uint8) * 3, np.where(mask, rng.standard_normal((h, w)), 0).astype(np.float32)):
+            got, gn = alg.label.connected_components(data)
+            assert got.dtype == np.int32 and gn == n and np.array_equal(got, want)
+    full = np.ones((h, w), np.float32)
+    full[0, 0] = np.nan                                   # NaN != 0: foreground like in scipy
+    got, gn = alg.label.connected_components(full)
+    assert gn == 1 and got.min() == 1
+    got, gn = alg.label.connected_components(np.zeros((h, w), np.float32))
+    assert gn == 0 and not got.any()
+
+
+def test_label_reductions_with_explicit_nlabels_ties_and_nan(alg):
+    rng = np.random.default_rng(7)
+    lab = rng.integers(0, 6, (70, 90)).astype(np.int32)
+    data32 = np.round(rng.standard_normal((70, 90)), 1).astype(np.float32)     # many exact ties
+    data64 = data32.astype(np.float64)
+    data64[lab == 4] = 1.5                                                     # constant label: first raster cell wins
+    st, ost = alg.label.label_stats(data32, lab, 9), oracle.label_stats(data32, lab, 9)   # nlabels > max(label)
+    assert len(st) == 10
+    for f in ("min", "max", "count"):
+        assert np.array_equal(st[f], ost[f])
+    assert np.allclose(st["sum"], ost["sum"], rtol=1e-12, atol=0)
+    for fn, ofn in ((alg.label.label_min_index, oracle.label_min_index), (alg.label.label_max_index, oracle.label_max_index)):
+        a, b = fn(data64, lab, 9), ofn(data64, lab, 9)
+        for f in ("value", "row", "col"):
+            assert np.array_equal(a[f], b[f]), f
+        assert a["row"][7] == -1 and a["col"][9] == -1                         # empty labels keep (inf, -1, -1)
+    d = data64.copy()
+    d[lab == 2] = np.nan                                                       # all-NaN label: never selected
+    a, b = alg.label.label_min_index(d, lab), oracle.label_min_index(d, lab)
+    assert a["row"][2] == -1 and np.array_equal(a["row"], b["row"]) and np.array_equal(a["col"], b["col"])
+    with pytest.raises(ValueError):
+        alg.label.label_stats(data32, lab, 3)                                  # label outside [0, nlabels]
+
+
+def test_keep_labels_mutates_and_masks_like_the_reference(alg):
+    lab = np.array([[0, 1, 1], [2, 0, 3]], np.int32)
+    keep = [True, True, False, True]
+    mask = alg.label.keep_labels(lab, keep)
+    assert keep[0] is False                                                    # label.py:91 side effect
+    assert mask.dtype == bool and mask.tolist() == [[False, True, True], [False, False, True]]

@@ -62,9 +62,10 @@ __device__ __forceinline__ double from_right(double v)
 }
 
 // ---- one row-sequential pass over the register window -------------------------------------------
-// plain f32: every lane computes; halo lanes hold d == w so they cannot move.
+// plain f32.  `upd`: lane holds an updatable column (not a halo lane); `rowok` bit r: window row r is updatable.
 template <bool DOWN>
-__device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN], uint64_t &any, uint64_t &first, uint64_t &last)
+__device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, uint64_t &any,
+                                           uint64_t &first, uint64_t &last)
 {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -74,7 +75,8 @@ __device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN],
         float n = fminf(fminf(from_left(dn), from_right(dn)), dn);
         float o = fminf(fminf(from_left(cu), from_right(cu)), cu);
         m = fminf(fminf(m, n), o);
-        const float nv = fmaxf(m, d[r]);
+        float nv = fmaxf(m, d[r]);
+        nv = (upd && ((rowok >> r) & 1ull)) ? nv : cu;
         const uint64_t ch = __ballot(nv != cu);
         w[r] = nv;
         any |= ch;
@@ -111,6 +113,53 @@ __device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
 #endif
     }
+}
+
+// wave shifts that deliver `fill` to the lane without a source lane (lane 0 / lane 63).  NOTE: a DPP read of a lane
+// that is disabled in EXEC returns 0 (bound_ctrl) -- never put a wave shift inside a divergent `?:` or `if`.
+__device__ __forceinline__ float from_left_or(float v, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), DPP_WF_SR1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_right_or(float v, float fill)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), DPP_WF_SL1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double from_left_or(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), DPP_WF_SR1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), DPP_WF_SR1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_right_or(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), DPP_WF_SL1, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), DPP_WF_SL1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// ---- halo probe: which cells of the halo rows 0 / 63 (they belong to neighbouring tiles) would drop if their owner
+// revisited them now, given this tile's interior rows 1 / 62?  Only those neighbours need to be re-queued.  The halo
+// values in the window may be stale, i.e. too high, so the test errs on the side of re-queueing.
+__device__ __forceinline__ void probe_plain(const float (&w)[WN], const float (&d)[WN], bool upd, uint64_t &drop_first, uint64_t &drop_last)
+{
+    const float INF = __builtin_inff();
+    const float a = upd ? w[1] : INF, b = upd ? w[TI] : INF;
+    const float al = from_left_or(a, INF), ar = from_right_or(a, INF), bl = from_left_or(b, INF), br = from_right_or(b, INF);
+    const float ma = fminf(fminf(al, ar), a), mb = fminf(fminf(bl, br), b);
+    drop_first = __ballot(fmaxf(d[0], fminf(w[0], ma)) < w[0]);
+    drop_last = __ballot(fmaxf(d[WN - 1], fminf(w[WN - 1], mb)) < w[WN - 1]);
+}
+__device__ __forceinline__ void probe_noflat(const double (&w)[WN], const float (&d)[WN], bool upd, double sh, double dg,
+                                             uint64_t &drop_first, uint64_t &drop_last)
+{
+    const double INF = __builtin_inf();
+    const double a = upd ? w[1] : INF, b = upd ? w[TI] : INF;
+    const double al = from_left_or(a, INF), ar = from_right_or(a, INF), bl = from_left_or(b, INF), br = from_right_or(b, INF);
+    const double ca = fmin(__dadd_rn(a, sh), __dadd_rn(fmin(al, ar), dg));
+    const double cb = fmin(__dadd_rn(b, sh), __dadd_rn(fmin(bl, br), dg));
+    drop_first = __ballot(fmax((double)d[0], fmin(w[0], ca)) < w[0]);
+    drop_last = __ballot(fmax((double)d[WN - 1], fmin(w[WN - 1], cb)) < w[WN - 1]);
 }
 
 // ---- 64x64 transpose of 32-bit words through a wave-private LDS scratch [64][65] ------------------
@@ -235,20 +284,8 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             // is never updated (`fv > NaN` is false): both behave like +inf inside the window.
             if (dv != dv) dv = __builtin_inff();
             if (wv != wv) wv = INF;
-            if constexpr (!NOFLAT) {
-                if ((a.fixed_top && rr == 0) || (a.fixed_bot && rr == H - 1)) dv = wv;  // halo row of a band: frozen
-            }
             w[r] = wv;
             d[r] = dv;
-        }
-        if constexpr (!NOFLAT) {
-            // freeze the halo ring: d == w makes max(min(..), d) a no-op there (both layouts: rows 0/63, lanes 0/63)
-            d[0] = w[0];
-            d[WN - 1] = w[WN - 1];
-            if (!upd) {
-#pragma unroll
-                for (int r = 0; r < WN; ++r) d[r] = w[r];
-            }
         }
     }
 
@@ -258,7 +295,7 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
     if (a.fixed_top && r0 == 0) rowok &= ~1ull;
     if (a.fixed_bot && H - 1 - r0 < WN) rowok &= ~(1ull << (H - 1 - r0));
     const bool upd_t = upd && ((rowok >> lane) & 1ull);
-    uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;
+    uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;  // any*: change masks; the others: halo probes
     bool capped = true;
     int ncyc = 0;
     for (int cyc = 0; cyc < MAXCYC; ++cyc) {
@@ -271,16 +308,22 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
                 pass_noflat<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any, first, last);
                 pass_noflat<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any, first, last);
             } else {
-                pass_plain<true>(w, d, any, first, last);
-                pass_plain<false>(w, d, any, first, last);
+                pass_plain<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any, first, last);
+                pass_plain<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any, first, last);
             }
+            // neighbour impact of the current state (the last cycle changes nothing, so its probes are final)
+            uint64_t p0, p1;
+            if constexpr (NOFLAT) probe_noflat(w, d, half ? upd_t : upd, a.sh, a.dg, p0, p1);
+            else probe_plain(w, d, half ? upd_t : upd, p0, p1);
             transpose(w, scr, lane);
             transpose(d, scr, lane);
             if (half == 0) {
-                anyN |= any; topN |= first; botN |= last;
+                anyN |= any; topN = p0; botN = p1;
             } else {
-                anyT |= any; leftT |= first; rightT |= last;
+                // a band's halo rows are frozen here: their owner is the neighbouring band, nobody to re-queue locally
+                anyT |= any; leftT = p0 & rowok; rightT = p1 & rowok;
             }
+            (void)first; (void)last;
             chg |= any;
         }
         if (chg == 0) {
@@ -324,14 +367,16 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             }
         }
     }
-    if (changed) {
-        // which neighbours saw their halo change?  N layout masks are indexed by column, T layout by row.
+    {
+        // which neighbours would be lowered by this tile's current state?  (a pure function of the window, so it is
+        // evaluated on every visit: a visit that changed nothing still re-queues a neighbour whose cells lag behind)  N layout masks are indexed by column, T layout by row.
         // Lane k (k < 9) owns neighbour k, so the returning atomics of all directions are in flight together.
-        const uint64_t B1 = 1ull << 1, BT = 1ull << TI;
-        const bool top = topN != 0 || (anyT & B1), bot = botN != 0 || (anyT & BT);
-        const bool left = leftT != 0 || (anyN & B1), right = rightT != 0 || (anyN & BT);
-        const bool tl = (topN & B1) || (leftT & B1), tr = (topN & BT) || (rightT & B1);
-        const bool bl = (botN & B1) || (leftT & BT), br = (botN & BT) || (rightT & BT);
+        // topN/botN: halo-row cells (bit = column 0..63) that would drop; leftT/rightT: halo-column cells (bit = row).
+        // Bits 1..62 belong to the edge neighbour, bits 0 / 63 are the corner cells of the diagonal neighbours.
+        const uint64_t INNER = ((1ull << TI) - 1) << 1, C0 = 1ull, C63 = 1ull << (WN - 1);
+        const bool top = (topN & INNER) != 0, bot = (botN & INNER) != 0, left = (leftT & INNER) != 0, right = (rightT & INNER) != 0;
+        const bool tl = ((topN | leftT) & C0) != 0, tr = (topN & C63) || (rightT & C0);
+        const bool bl = (botN & C0) || (leftT & C63), br = ((botN | rightT) & C63) != 0;
         const unsigned bits = (tl ? 1u : 0u) | (top ? 2u : 0u) | (tr ? 4u : 0u) | (left ? 8u : 0u) | (capped ? 16u : 0u) |
                               (right ? 32u : 0u) | (bl ? 64u : 0u) | (bot ? 128u : 0u) | (br ? 256u : 0u);
         if (lane < 9 && ((bits >> lane) & 1u)) {

@@ -68,16 +68,23 @@ __device__ __forceinline__ unsigned d8_code(double z, double u, double ur, doubl
                                             double l, double ul)
 {
     const double INV_SQRT2 = 0.7071067811865475;  // 1 / 2**0.5, _flow.pyx:93-94
+    // `if dz > dzmax: dzmax = dz; i = k` in the reference's order.  The running maximum is a v_max_f64 (same value as the
+    // conditional move: it only changes when dz > dzmax; NaN drops are ignored by both), the index a 32-bit select.
     unsigned i = 8;
     double dzmax = 0.0, dz;
-    dz = __dsub_rn(z, u);                       if (dz > dzmax) { dzmax = dz; i = 0; }
-    dz = __dmul_rn(__dsub_rn(z, ur), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 1; }
-    dz = __dsub_rn(z, r);                       if (dz > dzmax) { dzmax = dz; i = 2; }
-    dz = __dmul_rn(__dsub_rn(z, dr), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 3; }
-    dz = __dsub_rn(z, d);                       if (dz > dzmax) { dzmax = dz; i = 4; }
-    dz = __dmul_rn(__dsub_rn(z, dl), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 5; }
-    dz = __dsub_rn(z, l);                       if (dz > dzmax) { dzmax = dz; i = 6; }
-    dz = __dmul_rn(__dsub_rn(z, ul), INV_SQRT2); if (dz > dzmax) { dzmax = dz; i = 7; }
+#define MH_D8_STEP(expr, k)          \
+    dz = (expr);                     \
+    i = dz > dzmax ? (k) : i;        \
+    dzmax = fmax(dzmax, dz);
+    MH_D8_STEP(__dsub_rn(z, u), 0u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, ur), INV_SQRT2), 1u)
+    MH_D8_STEP(__dsub_rn(z, r), 2u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, dr), INV_SQRT2), 3u)
+    MH_D8_STEP(__dsub_rn(z, d), 4u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, dl), INV_SQRT2), 5u)
+    MH_D8_STEP(__dsub_rn(z, l), 6u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, ul), INV_SQRT2), 7u)
+#undef MH_D8_STEP
     return i;
 }
 

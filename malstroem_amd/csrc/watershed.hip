@@ -62,29 +62,43 @@ __global__ __launch_bounds__(256) void ws_init_kernel(const uint8_t *__restrict_
     }
 }
 
+// One launch performs up to HOPS pointer jumps per cell (P[i] <- P[P[i]] repeatedly): the raster is read once per launch
+// while the path length covered grows by 2**HOPS.  Racing updates are benign: every value a thread can observe in
+// P[] / Q[] is a cell further down the same flow path (or the final terminal).
+constexpr int HOPS = 3;
 __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, int64_t n, unsigned int *changed)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool ch = false;
-    const int32_t t = P[i];
+    int32_t t = P[i];
     if (t != NONE && t != (int32_t)i) {
-        const int32_t pt = P[t];
-        if (pt != t) {  // t is not a labelled fixed point yet: skip over it
-            P[i] = pt;
+        const int32_t t0 = t;
+#pragma unroll
+        for (int h = 0; h < HOPS; ++h) {
+            if (t == NONE) break;
+            const int32_t pt = P[t];
+            if (pt == t) break;  // t is a labelled fixed point: resolved
+            t = pt;              // skip over t
+        }
+        if (t != t0) {
+            P[i] = t;
             ch = true;
         }
     }
     if (Q) {
-        const uint32_t q = Q[i];
-        const uint32_t qt_idx = q & QMASK;
-        if (qt_idx != QTERM) {
-            const uint32_t qt = Q[qt_idx];
-            const uint32_t nq = ((q | qt) & QFLAG) | (qt & QMASK);
-            if (nq != q) {
-                Q[i] = nq;
-                ch = true;
-            }
+        uint32_t q = Q[i];
+        const uint32_t q0 = q;
+#pragma unroll
+        for (int h = 0; h < HOPS; ++h) {
+            const uint32_t idx = q & QMASK;
+            if (idx == QTERM) break;
+            const uint32_t qt = Q[idx];
+            q = ((q | qt) & QFLAG) | (qt & QMASK);
+        }
+        if (q != q0) {
+            Q[i] = q;
+            ch = true;
         }
     }
     if (ch) *changed = 1u;
@@ -161,7 +175,7 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
         q = Q.as<uint32_t>();
     }
     hipLaunchKernelGGL(ws_init_kernel, dim3(grid), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), q, H, W, unassigned);
-    constexpr int MAX_ROUNDS = 40, CHECK_EVERY = 4;
+    constexpr int MAX_ROUNDS = 40, CHECK_EVERY = 2;   // 40 launches x 3 hops each: paths up to 2**120 cells
     for (int round = 0; round < MAX_ROUNDS; round += CHECK_EVERY) {
         MH_HIP(hipMemsetAsync(d_changed, 0, 4, s));
         for (int k = 0; k < CHECK_EVERY; ++k)

@@ -17,7 +17,9 @@
 //            64-bit "pending count | sum" walk as before, but over ~4 % of the cells.
 //   phase 3  per tile, in LDS again: the Kahn walk with every entry cell pre-loaded with its external inflow
 //            produces the final values, written once as float64.
-// One state word: bit 63 = source (pending 0 at start), bits 56..59 = pending arrivals, bits 0..55 = running sum.
+// One LDS state word per cell: bit 63 = source (pending 0 at start), bits 59..62 = the cell's own flow code (so a walker
+// learns where to go next from the value its atomic returns: one LDS round trip per step), bits 55..58 = pending
+// arrivals, bits 0..54 = running sum.
 #include "common.hpp"
 
 namespace mh {
@@ -28,7 +30,8 @@ constexpr int PERIM = 4 * AT - 4;     // perimeter cells of a tile
 constexpr int NODE_STRIDE = 256;      // perimeter slots per tile in the global node arrays
 constexpr int FS = AT + 4;            // LDS row stride of the flow-direction window (66 used)
 constexpr uint64_t SRC = 1ull << 63;
-constexpr int DEG_SHIFT = 56;
+constexpr int DEG_SHIFT = 55;
+constexpr int CODE_SHIFT = 59;
 constexpr uint64_t ONE_PENDING = 1ull << DEG_SHIFT;
 constexpr uint64_t SUM_MASK = ONE_PENDING - 1;
 constexpr uint16_t NO_EXIT = 0xffffu;
@@ -117,26 +120,50 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             if (nd.arrived[node] == deg_ext) sum += nd.inflow[node];
             else pending += 1;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
         }
-        st[i] = (pending << DEG_SHIFT) | sum | (pending == 0 ? SRC : 0ull);
+        st[i] = ((uint64_t)win[(r + 1) * FS + c + 1] << CODE_SHIFT) | (pending << DEG_SHIFT) | sum | (pending == 0 ? SRC : 0ull);
     }
     __syncthreads();
 
-    // Kahn walk inside the tile: the last arriver at a cell owns its complete sum and carries on
-    for (int i = tid; i < AT * AT; i += 256) {
-        if (!(st[i] & SRC)) continue;  // SRC is only written above
-        int r = i / AT, c = i - r * AT;
-        uint64_t total = st[i] & SUM_MASK;
-        for (;;) {
-            const unsigned code = win[(r + 1) * FS + c + 1];
-            if (code > 7u) break;
-            r += dir_dr((int)code);
-            c += dir_dc((int)code);
-            if (r < 0 || r >= AT || c < 0 || c >= AT) break;  // leaves the tile (or the raster)
-            if (halo_row(r0 + r)) break;                       // flows into the neighbouring band
-            const uint64_t delta = total - ONE_PENDING;
-            const uint64_t now = atomicAdd(reinterpret_cast<unsigned long long *>(&st[r * AT + c]), (unsigned long long)delta) + delta;
-            if ((now >> DEG_SHIFT) & 0xf) break;
-            total = now & SUM_MASK;
+    // Kahn walk inside the tile: the last arriver at a cell owns its complete sum and carries on.  Every lane is a small
+    // state machine (walking / looking for its next source cell), so a lane that finishes a short path picks up new work
+    // immediately.  (Measured: all four wavefronts walking beats a single walking wavefront 2:1 -- the phase is bound by
+    // the number of steps, not by the longest chain.)
+    {
+        int next_i = tid;
+        bool walking = false;
+        int r = 0, c = 0;
+        unsigned code = 8;
+        uint64_t total = 0;
+        while (__any(walking || next_i < AT * AT)) {
+            if (walking) {
+                // branch-free step: (dr+1, dc+1) of the 8 codes packed 2 bits each (NODIR decodes to garbage, masked by `go`)
+                constexpr unsigned DRP = (0u << 0) | (0u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (2u << 10) | (1u << 12) | (0u << 14);
+                constexpr unsigned DCP = (1u << 0) | (2u << 2) | (2u << 4) | (2u << 6) | (1u << 8) | (0u << 10) | (0u << 12) | (0u << 14);
+                const unsigned sh2 = (code & 7u) * 2u;
+                r += (int)((DRP >> sh2) & 3u) - 1;
+                c += (int)((DCP >> sh2) & 3u) - 1;
+                // stays inside the tile, the raster and the band?
+                const bool go = (code < 8u) & ((unsigned)r < (unsigned)AT) & ((unsigned)c < (unsigned)AT) & !halo_row(r0 + r);
+                bool cont = false;
+                if (go) {
+                    const uint64_t delta = total - ONE_PENDING;
+                    const uint64_t now = atomicAdd(reinterpret_cast<unsigned long long *>(&st[r * AT + c]), (unsigned long long)delta) + delta;
+                    cont = ((now >> DEG_SHIFT) & 0xf) == 0;  // else somebody else still has to arrive
+                    total = cont ? (now & SUM_MASK) : total;
+                    code = cont ? ((unsigned)(now >> CODE_SHIFT) & 0xfu) : code;
+                }
+                walking = cont;
+            } else if (next_i < AT * AT) {
+                const uint64_t s0 = st[next_i];
+                if (s0 & SRC) {  // SRC is only written by the initialisation above
+                    r = next_i / AT;
+                    c = next_i - r * AT;
+                    total = s0 & SUM_MASK;
+                    code = (unsigned)(s0 >> CODE_SHIFT) & 0xfu;
+                    walking = true;
+                }
+                next_i += 256;
+            }
         }
     }
     __syncthreads();

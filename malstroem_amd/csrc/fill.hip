@@ -73,8 +73,7 @@ __device__ __forceinline__ bool is_nan_bits(double v)
 // ---- one row-sequential pass over the register window -------------------------------------------
 // plain f32.  `upd`: lane holds an updatable column (not a halo lane); `rowok` bit r: window row r is updatable.
 template <bool DOWN>
-__device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, uint64_t &any,
-                                           uint64_t &first, uint64_t &last)
+__device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, uint64_t &any)
 {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -89,8 +88,6 @@ __device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN],
         const uint64_t ch = __ballot(nv != cu);
         w[r] = nv;
         any |= ch;
-        if (r == 1) first |= ch;
-        if (r == TI) last |= ch;
 #if MH_ROW_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
 #endif
@@ -100,7 +97,7 @@ __device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN],
 // no-flats f64: min4(diagonals)+diag, min4(edges)+short, self; single IEEE adds (_fill.pyx:107-117).
 template <bool DOWN>
 __device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, double sh,
-                                            double dg, uint64_t &any, uint64_t &first, uint64_t &last)
+                                            double dg, uint64_t &any)
 {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -116,8 +113,6 @@ __device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN
         const uint64_t ch = __ballot(nv != cu);
         w[r] = nv;
         any |= ch;
-        if (r == 1) first |= ch;
-        if (r == TI) last |= ch;
 #if MH_ROW_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
 #endif
@@ -312,13 +307,13 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
         uint64_t chg = 0;
 #pragma nounroll
         for (int half = 0; half < 2; ++half) {
-            uint64_t any = 0, first = 0, last = 0;
+            uint64_t any = 0;
             if constexpr (NOFLAT) {
-                pass_noflat<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any, first, last);
-                pass_noflat<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any, first, last);
+                pass_noflat<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any);
+                pass_noflat<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any);
             } else {
-                pass_plain<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any, first, last);
-                pass_plain<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any, first, last);
+                pass_plain<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any);
+                pass_plain<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any);
             }
             // neighbour impact of the current state (the last cycle changes nothing, so its probes are final)
             uint64_t p0, p1;
@@ -332,7 +327,6 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
                 // a band's halo rows are frozen here: their owner is the neighbouring band, nobody to re-queue locally
                 anyT |= any; leftT = p0 & rowok; rightT = p1 & rowok;
             }
-            (void)first; (void)last;
             chg |= any;
         }
         if (chg == 0) {

@@ -21,6 +21,7 @@
 // the update is lane-masked (no-flats).  Raster border cells have W == dem from the start and therefore
 // never move; cells outside the raster are +inf and never win a min.
 #include "common.hpp"
+#include <vector>
 
 namespace mh {
 
@@ -71,23 +72,61 @@ __device__ __forceinline__ bool is_nan_bits(double v)
 }
 
 // ---- one row-sequential pass over the register window -------------------------------------------
-// plain f32.  `upd`: lane holds an updatable column (not a halo lane); `rowok` bit r: window row r is updatable.
-template <bool DOWN>
-__device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, uint64_t &any)
+// A pass walks the rows in order (DOWN: 1..62, else 62..1).  For the row being updated the three rows
+// "behind" (already updated in this pass), "current" and "ahead" contribute; what a row contributes
+// through its horizontal neighbours is computed once when the row enters the 3-row window and carried
+// in registers: per row 2 fresh horizontal reductions (the row ahead, the updated row) instead of 3.
+// Lanes 0 / 63 read a zero from the missing DPP source lane: they are halo lanes whose own results are
+// thrown away by the lane mask, and nobody reads a reduction across lanes.
+//   updmask: ballot of the lanes that hold an updatable column; `frozen`: the one window row (-1: none) that
+//   must not move (a band's halo row inside the window).
+// The select is an explicit v_cndmask on an SGPR-pair mask: left to itself the compiler wraps the row in
+// an EXEC-masked branch (SALU + s_nop filler on the critical path of every row).
+__device__ __forceinline__ float sel_mask(float if_clear, float if_set, uint64_t mask)
 {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ double sel_mask(double if_clear, double if_set, uint64_t mask)
+{
+    int lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(if_clear)), "v"(__double2loint(if_set)), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(if_clear)), "v"(__double2hiint(if_set)), "s"(mask));
+    return __hiloint2double(hi, lo);
+}
+// min(x, left(x), right(x)) as two v_min_f32_dpp (the opaque asm keeps the compiler from forming a v_min3, which
+// cannot carry a DPP modifier and would need two extra v_mov_dpp)
+__device__ __forceinline__ float hmin3(float x)
+{
+    float t = fminf(from_left(x), x);
+    asm volatile("" : "+v"(t));
+    return fminf(from_right(x), t);
+}
+__device__ __forceinline__ double hmin2(double x) { return fmin(from_left(x), from_right(x)); }
+
+template <bool DOWN>
+__device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN], uint64_t updmask, int frozen, uint64_t &any)
+{
+    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
+    asm volatile("" : "+s"(frozen));   // recompute the row masks in every pass: 62 live SGPR pairs would be spilled
+    // new names for the rows: otherwise the horizontal reductions of the previous pass are kept alive (CSE) for the
+    // rows that did not change since -- 62 extra live registers, i.e. spills inside the row loop
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(w[r]));
+    float h_behind = hmin3(w[first - dir]);
+    float h_cur = hmin3(w[first]);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int r = DOWN ? 1 + i : TI - i;
-        const float up = w[r - 1], cu = w[r], dn = w[r + 1];
-        float m = fminf(fminf(from_left(up), from_right(up)), up);
-        float n = fminf(fminf(from_left(dn), from_right(dn)), dn);
-        float o = fminf(fminf(from_left(cu), from_right(cu)), cu);
-        m = fminf(fminf(m, n), o);
-        float nv = fmaxf(m, d[r]);
-        nv = (upd && ((rowok >> r) & 1ull)) ? nv : cu;
-        const uint64_t ch = __ballot(nv != cu);
+        const int r = first + dir * i;
+        const float cu = w[r];
+        const float h_ahead = hmin3(w[r + dir]);
+        float nv = fmaxf(fminf(fminf(h_behind, h_cur), h_ahead), d[r]);
+        nv = sel_mask(cu, nv, r == frozen ? 0ull : updmask);
+        any |= __ballot(__float_as_uint(nv) != __float_as_uint(cu));
         w[r] = nv;
-        any |= ch;
+        h_behind = hmin3(nv);
+        h_cur = h_ahead;
 #if MH_ROW_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
 #endif
@@ -96,23 +135,28 @@ __device__ __forceinline__ void pass_plain(float (&w)[WN], const float (&d)[WN],
 
 // no-flats f64: min4(diagonals)+diag, min4(edges)+short, self; single IEEE adds (_fill.pyx:107-117).
 template <bool DOWN>
-__device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN], bool upd, uint64_t rowok, double sh,
+__device__ __forceinline__ void pass_noflat(double (&w)[WN], const float (&d)[WN], uint64_t updmask, int frozen, double sh,
                                             double dg, uint64_t &any)
 {
+    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
+    asm volatile("" : "+s"(frozen));
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(w[r]));   // see pass_plain
+    double h_behind = hmin2(w[first - dir]);
+    double h_cur = hmin2(w[first]);
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int r = DOWN ? 1 + i : TI - i;
-        const double up = w[r - 1], cu = w[r], dn = w[r + 1];
-        double md = fmin(fmin(from_left(up), from_right(up)), fmin(from_left(dn), from_right(dn)));
-        double me = fmin(fmin(up, dn), fmin(from_left(cu), from_right(cu)));
-        md = __dadd_rn(md, dg);
-        me = __dadd_rn(me, sh);
-        double m = fmin(fmin(md, me), cu);
-        double nv = fmax(m, (double)d[r]);
-        nv = (upd && ((rowok >> r) & 1ull)) ? nv : cu;
-        const uint64_t ch = __ballot(nv != cu);
+        const int r = first + dir * i;
+        const double cu = w[r], behind = w[r - dir], ahead = w[r + dir];
+        const double h_ahead = hmin2(ahead);
+        const double md = __dadd_rn(fmin(h_behind, h_ahead), dg);
+        const double me = __dadd_rn(fmin(fmin(behind, ahead), h_cur), sh);
+        double nv = fmax(fmin(fmin(md, me), cu), (double)d[r]);
+        nv = sel_mask(cu, nv, r == frozen ? 0ull : updmask);
+        any |= __ballot(nv != cu);
         w[r] = nv;
-        any |= ch;
+        h_behind = hmin2(nv);
+        h_cur = h_ahead;
 #if MH_ROW_BARRIER
         __builtin_amdgcn_sched_barrier(0);  // keep rows in program order: hoisted DPP shifts blow the VGPR budget
 #endif
@@ -229,11 +273,25 @@ struct RoundArgs {
 };
 enum { INIT_NONE = 0, INIT_INF = 1, INIT_SEED = 2 };
 
+// Development aid (-DMH_PROFILE_VISIT): per-wave time stamps around the phases of a visit, summed in registers and
+// added to stats[128..] when the wave leaves; finish() prints the averages.
+#ifdef MH_PROFILE_VISIT
+#define MH_STAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long var = __builtin_amdgcn_s_memtime()
+struct Prof { long long load = 0, pass = 0, tr = 0, store = 0, push = 0; };
+#define MH_PROF_ARG , Prof &pf
+#define MH_PROF_PASS , pf
+#else
+#define MH_STAMP(var)
+#define MH_PROF_ARG
+#define MH_PROF_PASS
+#endif
+
 template <typename WT, bool NOFLAT, int INIT>
 __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__restrict__ dem, const float *__restrict__ seed,
                                            WT *__restrict__ W, int64_t tile, uint32_t *scr, int lane, unsigned &visits,
-                                           unsigned &cycles)
+                                           unsigned &cycles MH_PROF_ARG)
 {
+    MH_STAMP(tp0);
     const int64_t H = a.H, Wd = a.Wd;
     const int ntr = a.ntr, ntc = a.ntc;
     constexpr bool first_round = INIT != INIT_NONE;  // compile time: keeps the 128 row loads straight-line
@@ -293,12 +351,16 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
         }
     }
 
+    MH_STAMP(tp1);
     // ---- local solve: (down, up) passes in the row layout, transpose, (down, up) = (right, left), transpose
     // window rows that may be updated (all but a band's halo rows); after the transpose rows <-> lanes swap roles
     uint64_t rowok = ~0ull;
     if (a.fixed_top && r0 == 0) rowok &= ~1ull;
     if (a.fixed_bot && H - 1 - r0 < WN) rowok &= ~(1ull << (H - 1 - r0));
     const bool upd_t = upd && ((rowok >> lane) & 1ull);
+    const uint64_t updmask = __ballot(upd), updmask_t = __ballot(upd_t);
+    // rows 0 / 63 are never updated by a pass; a frozen row in between can only be a band's bottom halo row
+    const int frozen = (a.fixed_bot && H - 1 - r0 < WN - 1) ? (int)(H - 1 - r0) : -1;
     uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;  // any*: change masks; the others: halo probes
     bool capped = true;
     int ncyc = 0;
@@ -308,19 +370,25 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
 #pragma nounroll
         for (int half = 0; half < 2; ++half) {
             uint64_t any = 0;
+            MH_STAMP(q0);
             if constexpr (NOFLAT) {
-                pass_noflat<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any);
-                pass_noflat<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, a.sh, a.dg, any);
+                pass_noflat<true>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, a.sh, a.dg, any);
+                pass_noflat<false>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, a.sh, a.dg, any);
             } else {
-                pass_plain<true>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any);
-                pass_plain<false>(w, d, half ? upd_t : upd, half ? ~0ull : rowok, any);
+                pass_plain<true>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, any);
+                pass_plain<false>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, any);
             }
             // neighbour impact of the current state (the last cycle changes nothing, so its probes are final)
             uint64_t p0, p1;
             if constexpr (NOFLAT) probe_noflat(w, d, half ? upd_t : upd, a.sh, a.dg, p0, p1);
             else probe_plain(w, d, half ? upd_t : upd, p0, p1);
+            MH_STAMP(q1);
             transpose(w, scr, lane);
             transpose(d, scr, lane);
+            MH_STAMP(q2);
+#ifdef MH_PROFILE_VISIT
+            pf.pass += q1 - q0; pf.tr += q2 - q1;
+#endif
             if (half == 0) {
                 anyN |= any; topN = p0; botN = p1;
             } else {
@@ -336,6 +404,7 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
     }
 
     const bool changed = (anyN | anyT) != 0;
+    MH_STAMP(tp2);
     visits += 1;
     cycles += ncyc;
     // ---- stage-out: interior cells that are not raster border cells (those never move)
@@ -370,6 +439,7 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             }
         }
     }
+    MH_STAMP(tp3);
     {
         // which neighbours would be lowered by this tile's current state?  (a pure function of the window, so it is
         // evaluated on every visit: a visit that changed nothing still re-queues a neighbour whose cells lag behind)  N layout masks are indexed by column, T layout by row.
@@ -391,6 +461,10 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             }
         }
     }
+#ifdef MH_PROFILE_VISIT
+    MH_STAMP(tp4);
+    pf.load += tp1 - tp0; pf.store += tp3 - tp2; pf.push += tp4 - tp3;
+#endif
 }
 
 template <typename WT, bool NOFLAT, int INIT>
@@ -404,10 +478,14 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
     const int64_t nt = (int64_t)a.ntr * a.ntc;
     const int64_t g = (int64_t)blockIdx.x * 4 + wave;
     unsigned visits = 0, cycles = 0;
+#ifdef MH_PROFILE_VISIT
+    Prof pf;
+    const long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (INIT != INIT_NONE) {
         // first round: every tile, statically strided (uniform work)
         const int64_t nwaves = (int64_t)gridDim.x * 4;
-        for (int64_t t = g; t < nt; t += nwaves) visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, t, scr, lane, visits, cycles);
+        for (int64_t t = g; t < nt; t += nwaves) visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, t, scr, lane, visits, cycles MH_PROF_PASS);
     } else {
         // own shard first; then one vector look at all (head, count) pairs picks the shards that still hold work
         // (a stale head only costs one wasted pop), so an idle wave leaves after ~2 memory round trips
@@ -421,7 +499,7 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
                 if (i >= n) break;
                 const int tile = a.list_cur[(size_t)sh * a.shard_cap + i];
                 if (lane == 0) a.mark_cur[tile] = 0u;
-                visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, tile, scr, lane, visits, cycles);
+                visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, tile, scr, lane, visits, cycles MH_PROF_PASS);
             }
             bool more = false;
             if (lane < NSHARD) more = __hip_atomic_load(&a.head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.count_cur[lane];
@@ -438,6 +516,13 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
         unsigned long long *sh = a.stats + 2 * (g & 63);
         atomicAdd(&sh[0], (unsigned long long)visits);
         atomicAdd(&sh[1], (unsigned long long)cycles);
+#ifdef MH_PROFILE_VISIT
+        unsigned long long *pr = a.stats + 128;
+        atomicAdd(&pr[0], (unsigned long long)pf.load); atomicAdd(&pr[1], (unsigned long long)pf.pass);
+        atomicAdd(&pr[2], (unsigned long long)pf.tr); atomicAdd(&pr[3], (unsigned long long)pf.store);
+        atomicAdd(&pr[4], (unsigned long long)pf.push); atomicAdd(&pr[5], (unsigned long long)visits);
+        atomicAdd(&pr[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - tk0));
+#endif
     }
 }
 
@@ -537,8 +622,8 @@ int FillRun::begin(hipStream_t s, bool *active)
     const size_t off_marks = align16(m.list_elems * 2 * 4), off_count = align16(off_marks + (size_t)m.nt * 2 * 4);
     const size_t off_head = align16(off_count + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
     const size_t off_stats = align16(off_head + (size_t)(MAX_ROUNDS + 1) * NSHARD * 4);
-    MH_TRY(m.ws.alloc(off_stats + 64 * 16));
-    MH_HIP(hipMemsetAsync(m.ws.as<char>() + off_marks, 0, off_stats + 64 * 16 - off_marks, s));
+    MH_TRY(m.ws.alloc(off_stats + 64 * 16 + 128));   // + profile words (MH_PROFILE_VISIT builds)
+    MH_HIP(hipMemsetAsync(m.ws.as<char>() + off_marks, 0, off_stats + 64 * 16 + 128 - off_marks, s));
     m.lists = m.ws.as<int>();
     m.marks = reinterpret_cast<unsigned int *>(m.ws.as<char>() + off_marks);
     m.count = reinterpret_cast<unsigned int *>(m.ws.as<char>() + off_count);
@@ -611,6 +696,28 @@ int FillRun::finish(hipStream_t s, FillStats *st)
             MH_HIP(hipMemcpyAsync(h_stats, m.d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
             MH_HIP(hipStreamSynchronize(s));
             st->rounds = m.rounds_used;
+#ifdef MH_PROFILE_VISIT
+            {
+                unsigned long long pr[8];
+                MH_HIP(hipMemcpy(pr, m.d_stats + 128, sizeof(pr), hipMemcpyDeviceToHost));
+                const double v = (double)(pr[5] ? pr[5] : 1);
+                fprintf(stderr, "[visit profile %s] visits=%llu ticks/visit: load=%.0f passes=%.0f transposes=%.0f store=%.0f push=%.0f | wave busy ticks/visit=%.0f\n",
+                        noflat ? "noflat" : "plain", pr[5], pr[0] / v, pr[1] / v, pr[2] / v, pr[3] / v, pr[4] / v, pr[6] / v);
+                // active tiles per round
+                std::vector<unsigned int> cnt((size_t)(m.round + 1) * NSHARD);
+                MH_HIP(hipMemcpy(cnt.data(), m.count, cnt.size() * 4, hipMemcpyDeviceToHost));
+                const long edges[6] = {256, 1024, 2048, 4096, 16384, 1L << 40};
+                long nr[6] = {0}, nt_[6] = {0};
+                for (int r = 1; r <= m.round; ++r) {
+                    long t = 0;
+                    for (int k = 0; k < NSHARD; ++k) t += cnt[(size_t)r * NSHARD + k];
+                    if (!t) continue;
+                    for (int e = 0; e < 6; ++e) if (t < edges[e]) { nr[e]++; nt_[e] += t; break; }
+                }
+                fprintf(stderr, "[rounds by active tiles] <256: %ld (%ld) <1024: %ld (%ld) <2048: %ld (%ld) <4096: %ld (%ld) <16384: %ld (%ld) more: %ld (%ld)\n",
+                        nr[0], nt_[0], nr[1], nt_[1], nr[2], nt_[2], nr[3], nt_[3], nr[4], nt_[4], nr[5], nt_[5]);
+            }
+#endif
             for (int k = 0; k < 64; ++k) {
                 st->visits += (int64_t)h_stats[2 * k];
                 st->cycles += (int64_t)h_stats[2 * k + 1];

@@ -167,9 +167,9 @@ def main():
                 if record:
                     stage_ms[name] += (time.perf_counter() - t) * 1e3
         else:
-            pipe.run("fill", "noflat", "flowdir", "accum", "label")
-            pipe.apply_keep(None)
-            pipe.run("watershed", "pourpoints")
+            # one request for the whole chain: the library runs the bluespot branch (label, watershed) on a second
+            # stream next to no-flats fill -> D8 -> accumulation ("stage DAG"); all labels are kept
+            pipe.run("fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints")
             pipe.sync()
             if record:
                 for s in stage_names:

@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "common.hpp"
+#include <future>
+#include <thread>
 
 namespace mh {
 
@@ -383,6 +385,9 @@ struct mhip_ctx {
     FillStats fill_st, noflat_st;
     std::map<int, std::pair<hipEvent_t, hipEvent_t>> ev;
     std::map<int, bool> ev_valid;
+    // second stream + fork/join events of the stage DAG (mhip_ctx_run)
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr;
 };
 
 static size_t raster_elem(int which)
@@ -461,6 +466,12 @@ int mhip_ctx_destroy(mhip_ctx *c)
         (void)hipEventDestroy(kv.second.second);
     }
     (void)hipStreamDestroy(c->stream);
+    if (c->stream_b) {
+        (void)hipStreamSynchronize(c->stream_b);
+        (void)hipStreamDestroy(c->stream_b);
+    }
+    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join})
+        if (e) (void)hipEventDestroy(e);
     delete c->run[0];
     delete c->run[1];
     delete c;
@@ -683,143 +694,256 @@ int mhip_ctx_sync(mhip_ctx *c)
     return MHIP_OK;
 }
 
-static int ctx_ensure_labels_final(mhip_ctx *c)
+static int ctx_apply_keep_on(mhip_ctx *c, const uint8_t *keep, hipStream_t s);
+
+static int ctx_ensure_labels_final(mhip_ctx *c, hipStream_t s)
 {
-    if (!c->labels_filtered) return mhip_ctx_apply_keep(c, nullptr);
+    if (!c->labels_filtered) return ctx_apply_keep_on(c, nullptr, s);
     return MHIP_OK;
 }
 
-static int ctx_label_max(mhip_ctx *c)
+static int ctx_label_max(mhip_ctx *c, hipStream_t s)
 {
     if (c->nlabels < 0) {
         int32_t m = 0;
-        MH_TRY(label_max_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, &m, c->stream));
+        MH_TRY(label_max_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, &m, s));
         c->nlabels = m < 0 ? 0 : m;
     }
     return MHIP_OK;
 }
 
+// ---- the stages; each runs on the stream it is given and brackets itself with its pair of events ----------------
+static int stage_begin(mhip_ctx *c, int stage, hipStream_t s, hipEvent_t **e1)
+{
+    hipEvent_t *e0;
+    MH_TRY(ctx_events(c, stage, &e0, e1));
+    MH_HIP(hipEventRecord(*e0, s));
+    return MHIP_OK;
+}
+
+static int stage_fill(mhip_ctx *c, hipStream_t s)
+{
+    const int64_t H = c->H, W = c->W, n = H * W;
+    MH_ARG(c->have[MHIP_R_DEM], "FILL needs the DEM");
+    MH_TRY(ctx_raster(c, MHIP_R_FILLED));
+    MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_FILL, s, &e1));
+    FillStats st;
+    MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st));
+    MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(), n, s));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_FILL] = true;
+    c->fill_rounds = st.rounds;
+    c->fill_st = st;
+    c->have[MHIP_R_FILLED] = c->have[MHIP_R_DEPTHS] = true;
+    return MHIP_OK;
+}
+
+static int stage_noflat(mhip_ctx *c, hipStream_t s)
+{
+    const int64_t H = c->H, W = c->W, n = H * W;
+    MH_ARG(c->have[MHIP_R_DEM], "NOFLAT needs the DEM");
+    MH_TRY(ctx_raster(c, MHIP_R_NOFLAT));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_NOFLAT, s, &e1));
+    MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), n, &c->sh, &c->dg, s));
+    FillStats st;
+    if (!c->have[MHIP_R_FILLED]) {  // the plain fill seeds the no-flats iteration (fill_noflat_dev)
+        MH_TRY(ctx_raster(c, MHIP_R_FILLED));
+        FillStats st0;
+        MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st0));
+        c->have[MHIP_R_FILLED] = true;
+    }
+    MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st,
+                           c->r[MHIP_R_FILLED].as<float>()));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_NOFLAT] = true;
+    c->noflat_rounds = st.rounds;
+    c->noflat_st = st;
+    c->have[MHIP_R_NOFLAT] = true;
+    return MHIP_OK;
+}
+
+static int stage_flowdir(mhip_ctx *c, hipStream_t s)
+{
+    MH_ARG(c->have[MHIP_R_NOFLAT], "FLOWDIR needs the no-flats surface");
+    MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_FLOWDIR, s, &e1));
+    MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->H, c->W, 1, s, c->row0 - c->ht,
+                  c->H_global));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
+    c->have[MHIP_R_FLOWDIR] = true;
+    return MHIP_OK;
+}
+
+static int stage_accum(mhip_ctx *c, hipStream_t s)
+{
+    MH_ARG(c->have[MHIP_R_FLOWDIR], "ACCUM needs flow directions");
+    MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_ACCUM, s, &e1));
+    MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, s, c->ht, c->hb));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_ACCUM] = true;
+    c->have[MHIP_R_ACCUM] = true;
+    return MHIP_OK;
+}
+
+static int stage_label(mhip_ctx *c, hipStream_t s)
+{
+    const int64_t H = c->H, W = c->W, n = H * W;
+    MH_ARG(c->have[MHIP_R_DEPTHS], "LABEL needs bluespot depths");
+    MH_TRY(ctx_raster(c, MHIP_R_LABELS));
+    if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)n));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_LABEL, s, &e1));
+    MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), H, W,
+                        &c->nlabels_raw, s));
+    MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
+    MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
+                           c->raw_stats.as<mhip_stat_record>(), s));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_LABEL] = true;
+    c->have[MHIP_R_LABELS] = true;
+    c->labels_filtered = false;
+    c->nlabels = c->nlabels_raw;
+    return MHIP_OK;
+}
+
+static int stage_watershed(mhip_ctx *c, hipStream_t s)
+{
+    const int64_t H = c->H, W = c->W, n = H * W;
+    MH_ARG(c->have[MHIP_R_LABELS] && c->have[MHIP_R_FLOWDIR], "WATERSHED needs labels and flow directions");
+    MH_TRY(ctx_ensure_labels_final(c, s));
+    MH_TRY(ctx_label_max(c, s));
+    MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_WATERSHED, s, &e1));
+    MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
+    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s));
+    MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
+    MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_WATERSHED] = true;
+    c->have[MHIP_R_WATERSHEDS] = true;
+    return MHIP_OK;
+}
+
+static int stage_pourpoints(mhip_ctx *c, hipStream_t s)
+{
+    const int64_t H = c->H, W = c->W;
+    MH_ARG(c->have[MHIP_R_LABELS] && (c->have[MHIP_R_ACCUM] || c->have[MHIP_R_NOFLAT]),
+           "POURPOINTS needs labels and accumulated flow or the no-flats surface");
+    MH_TRY(ctx_ensure_labels_final(c, s));
+    MH_TRY(ctx_label_max(c, s));
+    MH_TRY(c->pour.alloc(sizeof(mhip_index_record) * (size_t)(c->nlabels + 1)));
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_POURPOINTS, s, &e1));
+    // bluespots.py:195-206: max accumulated flow if available, else min of the no-flats surface
+    if (c->have[MHIP_R_ACCUM])
+        MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, true,
+                             c->pour.as<mhip_index_record>(), s));
+    else
+        MH_TRY(label_arg_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, false,
+                             c->pour.as<mhip_index_record>(), s));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_POURPOINTS] = true;
+    return MHIP_OK;
+}
+
+// Stage DAG:  FILL -> NOFLAT -> FLOWDIR -> ACCUM ------.
+//                \-> LABEL ----------\-> WATERSHED ----+-> POURPOINTS
+// A request that holds both sides runs the bluespot branch (LABEL, WATERSHED) on a second stream driven by a
+// second host thread (both branches read back small results between launches), so the latency-bound rounds of the
+// no-flats fill and the walks of the accumulation share the GPU with the labelling instead of queueing behind each
+// other.  MHIP_SERIAL=1 in the environment keeps everything on the context's stream.
 int mhip_ctx_run(mhip_ctx *c, int mask)
 {
     MH_ARG(c, "ctx");
     MH_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const int64_t H = c->H, W = c->W, n = H * W;
-    hipEvent_t *e0, *e1;
     if (c->nranks > 1 || c->ht || c->hb) {
         // row-band mode: the fills run through mhip_ctx_fill_begin/batch (halo refreshes in between); stages whose
         // cross-band protocol is not built yet are refused instead of silently computing band-local results
         MH_ARG((mask & ~(MHIP_STAGE_FLOWDIR | MHIP_STAGE_ACCUM)) == 0,
                "this stage runs through the band entry points on a row band (mhip_ctx_fill_*, mhip_ctx_band_*)");
     }
+    static const bool serial_env = [] { const char *e = getenv("MHIP_SERIAL"); return e && e[0] == '1'; }();
+    const int side_a = mask & (MHIP_STAGE_NOFLAT | MHIP_STAGE_FLOWDIR | MHIP_STAGE_ACCUM);
+    const int side_b = mask & (MHIP_STAGE_LABEL | MHIP_STAGE_WATERSHED);
+    const bool overlap = side_a && side_b && !serial_env;
 
-    if (mask & MHIP_STAGE_FILL) {
-        MH_ARG(c->have[MHIP_R_DEM], "FILL needs the DEM");
-        MH_TRY(ctx_raster(c, MHIP_R_FILLED));
-        MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
-        MH_TRY(ctx_events(c, MHIP_STAGE_FILL, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        FillStats st;
-        MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st));
-        MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(), n, s));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_FILL] = true;
-        c->fill_rounds = st.rounds;
-        c->fill_st = st;
-        c->have[MHIP_R_FILLED] = c->have[MHIP_R_DEPTHS] = true;
+    if (mask & MHIP_STAGE_FILL) MH_TRY(stage_fill(c, s));
+    if (!overlap) {
+        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s));
+        if (mask & MHIP_STAGE_FLOWDIR) MH_TRY(stage_flowdir(c, s));
+        if (mask & MHIP_STAGE_ACCUM) MH_TRY(stage_accum(c, s));
+        if (mask & MHIP_STAGE_LABEL) MH_TRY(stage_label(c, s));
+        if (mask & MHIP_STAGE_WATERSHED) MH_TRY(stage_watershed(c, s));
+        if (mask & MHIP_STAGE_POURPOINTS) MH_TRY(stage_pourpoints(c, s));
+        return MHIP_OK;
     }
-    if (mask & MHIP_STAGE_NOFLAT) {
-        MH_ARG(c->have[MHIP_R_DEM], "NOFLAT needs the DEM");
-        MH_TRY(ctx_raster(c, MHIP_R_NOFLAT));
-        MH_TRY(ctx_events(c, MHIP_STAGE_NOFLAT, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), n, &c->sh, &c->dg, s));
-        FillStats st;
-        if (!c->have[MHIP_R_FILLED]) {  // the plain fill seeds the no-flats iteration (fill_noflat_dev)
-            MH_TRY(ctx_raster(c, MHIP_R_FILLED));
-            FillStats st0;
-            MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st0));
-            c->have[MHIP_R_FILLED] = true;
+
+    // events and the second stream are created here, on the calling thread: the maps are not touched concurrently
+    hipEvent_t *ea, *eb;
+    for (int st : {MHIP_STAGE_NOFLAT, MHIP_STAGE_FLOWDIR, MHIP_STAGE_ACCUM, MHIP_STAGE_LABEL, MHIP_STAGE_WATERSHED}) {
+        if (mask & st) {
+            MH_TRY(ctx_events(c, st, &ea, &eb));
+            c->ev_valid[st];   // creates the key
         }
-        MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st,
-                               c->r[MHIP_R_FILLED].as<float>()));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_NOFLAT] = true;
-        c->noflat_rounds = st.rounds;
-        c->noflat_st = st;
-        c->have[MHIP_R_NOFLAT] = true;
     }
-    if (mask & MHIP_STAGE_FLOWDIR) {
-        MH_ARG(c->have[MHIP_R_NOFLAT], "FLOWDIR needs the no-flats surface");
-        MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
-        MH_TRY(ctx_events(c, MHIP_STAGE_FLOWDIR, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), H, W, 1, s, c->row0 - c->ht,
-                      c->H_global));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
-        c->have[MHIP_R_FLOWDIR] = true;
+    if (!c->stream_b) MH_HIP(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    if (!c->ev_fork) {
+        MH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
-    if (mask & MHIP_STAGE_ACCUM) {
-        MH_ARG(c->have[MHIP_R_FLOWDIR], "ACCUM needs flow directions");
-        MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
-        MH_TRY(ctx_events(c, MHIP_STAGE_ACCUM, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), H, W, s, c->ht, c->hb));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_ACCUM] = true;
-        c->have[MHIP_R_ACCUM] = true;
+    hipStream_t sb = c->stream_b;
+    MH_HIP(hipEventRecord(c->ev_fork, s));
+    MH_HIP(hipStreamWaitEvent(sb, c->ev_fork, 0));
+
+    std::promise<int> flowdir_ready;   // value: MHIP_OK once ev_flowdir has been recorded on the main stream
+    std::future<int> flowdir_fut = flowdir_ready.get_future();
+    const bool ws_needs_new_flowdir = (mask & MHIP_STAGE_WATERSHED) && (mask & MHIP_STAGE_FLOWDIR);
+    int rc_b = MHIP_OK;
+    char err_b[512] = "";
+    std::thread tb([&] {
+        rc_b = [&]() -> int {
+            MH_HIP(hipSetDevice(c->device));
+            if (mask & MHIP_STAGE_LABEL) MH_TRY(stage_label(c, sb));
+            if (mask & MHIP_STAGE_WATERSHED) {
+                if (ws_needs_new_flowdir) {
+                    MH_TRY(flowdir_fut.get());
+                    MH_HIP(hipStreamWaitEvent(sb, c->ev_flowdir, 0));
+                }
+                MH_TRY(stage_watershed(c, sb));
+            }
+            MH_HIP(hipEventRecord(c->ev_join, sb));
+            return MHIP_OK;
+        }();
+        if (rc_b != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
+    });
+    int rc_a = [&]() -> int {
+        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s));
+        if (mask & MHIP_STAGE_FLOWDIR) {
+            MH_TRY(stage_flowdir(c, s));
+            MH_HIP(hipEventRecord(c->ev_flowdir, s));
+        }
+        return MHIP_OK;
+    }();
+    flowdir_ready.set_value(rc_a);   // releases the other thread in either case
+    if (rc_a == MHIP_OK && (mask & MHIP_STAGE_ACCUM)) rc_a = stage_accum(c, s);
+    tb.join();
+    if (rc_a != MHIP_OK) return rc_a;
+    if (rc_b != MHIP_OK) {
+        set_error("%s", err_b);
+        return rc_b;
     }
-    if (mask & MHIP_STAGE_LABEL) {
-        MH_ARG(c->have[MHIP_R_DEPTHS], "LABEL needs bluespot depths");
-        MH_TRY(ctx_raster(c, MHIP_R_LABELS));
-        if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)n));
-        MH_TRY(ctx_events(c, MHIP_STAGE_LABEL, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), H, W,
-                            &c->nlabels_raw, s));
-        MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
-        MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
-                               c->raw_stats.as<mhip_stat_record>(), s));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_LABEL] = true;
-        c->have[MHIP_R_LABELS] = true;
-        c->labels_filtered = false;
-        c->nlabels = c->nlabels_raw;
-    }
-    if (mask & MHIP_STAGE_WATERSHED) {
-        MH_ARG(c->have[MHIP_R_LABELS] && c->have[MHIP_R_FLOWDIR], "WATERSHED needs labels and flow directions");
-        MH_TRY(ctx_ensure_labels_final(c));
-        MH_TRY(ctx_label_max(c));
-        MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
-        MH_TRY(ctx_events(c, MHIP_STAGE_WATERSHED, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
-        MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s));
-        MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
-        MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_WATERSHED] = true;
-        c->have[MHIP_R_WATERSHEDS] = true;
-    }
-    if (mask & MHIP_STAGE_POURPOINTS) {
-        MH_ARG(c->have[MHIP_R_LABELS] && (c->have[MHIP_R_ACCUM] || c->have[MHIP_R_NOFLAT]),
-               "POURPOINTS needs labels and accumulated flow or the no-flats surface");
-        MH_TRY(ctx_ensure_labels_final(c));
-        MH_TRY(ctx_label_max(c));
-        MH_TRY(c->pour.alloc(sizeof(mhip_index_record) * (size_t)(c->nlabels + 1)));
-        MH_TRY(ctx_events(c, MHIP_STAGE_POURPOINTS, &e0, &e1));
-        MH_HIP(hipEventRecord(*e0, s));
-        // bluespots.py:195-206: max accumulated flow if available, else min of the no-flats surface
-        if (c->have[MHIP_R_ACCUM])
-            MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, true,
-                                 c->pour.as<mhip_index_record>(), s));
-        else
-            MH_TRY(label_arg_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, false,
-                                 c->pour.as<mhip_index_record>(), s));
-        MH_HIP(hipEventRecord(*e1, s));
-        c->ev_valid[MHIP_STAGE_POURPOINTS] = true;
-    }
+    MH_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+    if (mask & MHIP_STAGE_POURPOINTS) MH_TRY(stage_pourpoints(c, s));
     return MHIP_OK;
 }
 
@@ -899,9 +1023,14 @@ int mhip_ctx_raw_stats(mhip_ctx *c, mhip_stat_record *records)
 
 int mhip_ctx_apply_keep(mhip_ctx *c, const uint8_t *keep)
 {
-    MH_ARG(c && c->have[MHIP_R_LABELS] && c->nlabels_raw >= 0 && !c->labels_filtered, "ctx_apply_keep needs a fresh LABEL run");
+    MH_ARG(c, "ctx");
     MH_HIP(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
+    return ctx_apply_keep_on(c, keep, c->stream);
+}
+
+static int ctx_apply_keep_on(mhip_ctx *c, const uint8_t *keep, hipStream_t s)
+{
+    MH_ARG(c && c->have[MHIP_R_LABELS] && c->nlabels_raw >= 0 && !c->labels_filtered, "ctx_apply_keep needs a fresh LABEL run");
     const int64_t n = c->H * c->W;
     if (keep) {
         std::vector<int32_t> lut;

@@ -259,3 +259,43 @@ def test_tools_run_on_the_device_pipeline(alg, fx):
     assert set(p) >= {"bspot_id", "cell_row", "cell_col", "bspot_dmax", "bspot_area", "bspot_vol", "wshed_area", "bspot_fumm"}
     m = lab2 > 0
     assert np.array_equal(ws2[m], lab2[m])
+
+
+# ---- the whole chain in ONE request: label/watershed run on a second stream next to no-flats/D8/accumulation ----------
+
+@pytest.mark.parametrize("shape", [(700, 450), (1024, 1024), (1500, 1300)])
+def test_whole_chain_in_one_request_matches_oracle(alg, shape):
+    """mhip_ctx_run with every stage bit set takes the overlapped path of the stage DAG (api.hip): same bits as the
+    oracle run stage by stage."""
+    from malstroem_amd.pipeline import HydroPipeline
+    dem = fbm(shape[0], shape[1], seed=7)
+    with HydroPipeline(dem.shape) as pipe:
+        pipe.upload("dem", dem)
+        for _ in range(2):   # the second pass reuses streams, events and pooled buffers
+            pipe.run("fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints")
+        pipe.sync()
+        got = {k: pipe.download(k) for k in ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")}
+        stats, counts, pour = pipe.stats(), pipe.watershed_counts(), pipe.pourpoints()
+        nlabels = pipe.get_int("nlabels")
+
+    filled = oracle.fill_terrain(dem)
+    short, diag = oracle.minimum_safe_short_and_diag(dem)
+    noflat = oracle.fill_terrain_no_flats(dem, short, diag)
+    flowdir = oracle.terrain_flowdirection(noflat)
+    accum = oracle.accumulated_flow(flowdir)
+    dep = oracle.depths(filled, dem)
+    lab, n = oracle.connected_components(dep)
+    ws = lab.copy()
+    oracle.watersheds_from_labels(flowdir, ws)   # in place, like the reference
+    assert np.array_equal(got["filled"], filled) and np.array_equal(got["depths"], dep)
+    assert np.array_equal(got["noflat"], noflat) and np.array_equal(got["flowdir"], flowdir)
+    assert np.array_equal(got["accum"], accum)
+    assert nlabels == n and np.array_equal(got["labels"], lab) and np.array_equal(got["watersheds"], ws)
+    ost = oracle.label_stats(dep, lab, n)
+    for f in ("min", "max", "count"):
+        assert np.array_equal(stats[f], ost[f]), f
+    assert np.allclose(stats["sum"], ost["sum"], rtol=1e-12, atol=0)
+    assert np.array_equal(counts, oracle.label_count(ws))   # every label owns at least its own cells: max(ws) == n
+    opour = oracle.label_max_index(accum, lab, n)
+    for f in opour.dtype.names:
+        assert np.array_equal(pour[f], opour[f]), f

@@ -9,17 +9,21 @@
 //
 // A single global "last arriver continues" walk needs one returning 64-bit global atomic per cell (measured:
 // ~5.4 G atomics/s, 50 ms at 16384^2).  Instead (after Barnes 2017, restated for LDS):
-//   phase 1  per 64x64 tile, in LDS: Kahn walk restricted to the tile (external inflow ignored) gives every cell's
+//   phase 1  per 64x64 tile, in LDS: the tile-local accumulation (external inflow ignored) gives every cell's
 //            tile-local sum; for each perimeter cell we publish {local sum, resolved?, leaves-the-tile?} and for each
 //            ENTRY cell (has an upstream neighbour outside the tile) the perimeter cell where its local path exits.
 //   phase 2  global, on perimeter cells only (~1/16 of the raster): exit cell x forwards F(x) = local(x) + all flux
 //            routed through x to the entry cell it flows into, and on to that entry's exit: the same packed
 //            64-bit "pending count | sum" walk as before, but over ~4 % of the cells.
-//   phase 3  per tile, in LDS again: the Kahn walk with every entry cell pre-loaded with its external inflow
-//            produces the final values, written once as float64.
-// One LDS state word per cell: bit 63 = source (pending 0 at start), bits 59..62 = the cell's own flow code (so a walker
-// learns where to go next from the value its atomic returns: one LDS round trip per step), bits 55..58 = pending
-// arrivals, bits 0..54 = running sum.
+//   phase 3  per tile, in LDS again: the same accumulation with every entry cell pre-loaded with its external
+//            inflow produces the final values, written once as float64.
+// Tile-local accumulation = pointer doubling on the in-tile flow forest (a Kahn walk was measured chain-bound: the
+// longest in-tile flow path, ~260 cells on fBm terrain, at ~570 cycles per step with 0.3 of 64 lanes busy).  With
+// A_k[w] the 2**k-th downstream cell of w (SENT once the path has left the tile / ended) and S_k[v] the sum over the
+// cells at most 2**k - 1 steps upstream of v:   S_{k+1}[A_k[w]] += S_k[w]  for every w,  A_{k+1}[w] = A_k[A_k[w]].
+// ~log2(longest path) rounds of independent LDS atomics instead of a dependent chain.  Bit 63 of S is a taint flag
+// (a cell that can never be resolved: unknown band halo, entry whose inflow never arrives, flow cycle); it travels
+// downstream with the sums and turns the result into the reference's 0.
 #include "common.hpp"
 
 namespace mh {
@@ -29,12 +33,13 @@ constexpr int AT = 64;                // tile edge
 constexpr int PERIM = 4 * AT - 4;     // perimeter cells of a tile
 constexpr int NODE_STRIDE = 256;      // perimeter slots per tile in the global node arrays
 constexpr int FS = AT + 4;            // LDS row stride of the flow-direction window (66 used)
-constexpr uint64_t SRC = 1ull << 63;
-constexpr int DEG_SHIFT = 55;
-constexpr int CODE_SHIFT = 59;
-constexpr uint64_t ONE_PENDING = 1ull << DEG_SHIFT;
-constexpr uint64_t SUM_MASK = ONE_PENDING - 1;
+constexpr uint64_t SRC = 1ull << 63;      // phase-2 node word: source flag
+constexpr uint64_t TAINT = 1ull << 63;    // tile word: never resolved
+constexpr uint64_t SUM_MASK = (1ull << 55) - 1;
 constexpr uint16_t NO_EXIT = 0xffffu;
+constexpr uint16_t SENT = 0xffffu;        // "no further downstream cell inside this tile"
+constexpr int CPT = AT * AT / 256;        // cells per thread
+constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simple path
 // phase-2 node word: an exit cell can be fed by every entry of its tile (hundreds), so the pending field is wider
 constexpr int G_SHIFT = 44;
 constexpr uint64_t G_ONE = 1ull << G_SHIFT, G_SUM = G_ONE - 1, G_PEND = 0x7ffffull;
@@ -69,6 +74,13 @@ struct Nodes {           // global perimeter-node arrays, index = tile * NODE_ST
     uint8_t *flags;
 };
 
+#ifdef MH_PROFILE_ACCUM   // development aid: per-phase ticks of thread 0 of every block
+__device__ unsigned long long g_accum_prof[2][8];
+#define MH_ASTAMP(k) do { if (threadIdx.x == 0) { const long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_accum_prof[FINAL][k], (unsigned long long)(t_ - tprev_)); tprev_ = t_; } } while (0)
+#else
+#define MH_ASTAMP(k)
+#endif
+
 // ---- the tile kernel (phase 1 when FINAL == false, phase 3 when FINAL == true) ------------------------------
 template <bool FINAL>
 // Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
@@ -78,12 +90,17 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
                                                         int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot)
 {
     auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
-    __shared__ uint64_t st[AT * AT];
+    __shared__ uint64_t S[AT * AT];
+    __shared__ uint16_t A[AT * AT];
+    __shared__ uint16_t R[FINAL ? 1 : AT * AT];   // phase 1: last in-tile cell of the path that starts here
     __shared__ uint8_t win[(AT + 2) * FS];
     const int tile = blockIdx.x;
     const int ti = tile / ntc, tj = tile - ti * ntc;
     const int64_t r0 = (int64_t)ti * AT, c0 = (int64_t)tj * AT;
     const int tid = threadIdx.x;
+#ifdef MH_PROFILE_ACCUM
+    long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
 
     // flow-direction window incl. the 1-cell ring; outside the raster = NODIR (never flows, never receives)
     for (int i = tid; i < (AT + 2) * (AT + 2); i += 256) {
@@ -92,90 +109,108 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         win[wr * FS + wc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? fd[rr * W + cc] : (uint8_t)8;
     }
     __syncthreads();
+    MH_ASTAMP(0);
 
-    // initial state of my 16 cells
-    for (int i = tid; i < AT * AT; i += 256) {
+    // my CPT cells: i = tid + 256 j (consecutive lanes = consecutive LDS words)
+    uint64_t sreg[CPT];
+    uint16_t areg[CPT], rreg[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int i = tid + 256 * j;
         const int r = i / AT, c = i - r * AT;
         const bool inside = (r0 + r) < H && (c0 + c) < W;
-        unsigned deg_in = 0, deg_ext = 0;
+        unsigned deg_ext = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int nr = r + dir_dr(k), nc = c + dir_dc(k);
-            const bool f = flows_into(win[(nr + 1) * FS + nc + 1], k);
             const bool in_tile = nr >= 0 && nr < AT && nc >= 0 && nc < AT;
-            deg_in += (f && in_tile) ? 1u : 0u;
-            deg_ext += (f && !in_tile) ? 1u : 0u;
+            deg_ext += (!in_tile && flows_into(win[(nr + 1) * FS + nc + 1], k)) ? 1u : 0u;
         }
-        uint64_t sum = 1, pending = deg_in;
-        if (!inside) pending = 15;  // not a raster cell: never fires
+        uint64_t v = inside ? 1ull : TAINT;   // not a raster cell: nothing flows into it (its neighbours see NODIR... it has none)
         const bool halo = inside && halo_row(r0 + r);
-        if (halo) {
+        if (halo) {  // the neighbouring band's cell: known (> 0) = a source of that much flux, else it blocks its path
             const double ext = out[(r0 + r) * W + c0 + c];
-            pending = ext > 0.0 ? 0 : 15;
-            sum = ext > 0.0 ? (uint64_t)ext : 0;
+            v = ext > 0.0 ? (uint64_t)ext : TAINT;
             deg_ext = 0;
         }
         if (FINAL && deg_ext && inside) {
             const int64_t node = (int64_t)tile * NODE_STRIDE + perim_slot(r, c);
-            if (nd.arrived[node] == deg_ext) sum += nd.inflow[node];
-            else pending += 1;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
+            if (nd.arrived[node] == deg_ext) v += nd.inflow[node];
+            else v |= TAINT;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
         }
-        st[i] = ((uint64_t)win[(r + 1) * FS + c + 1] << CODE_SHIFT) | (pending << DEG_SHIFT) | sum | (pending == 0 ? SRC : 0ull);
+        // downstream cell: inside the tile, the raster and the band, else the path ends here
+        const unsigned code = win[(r + 1) * FS + c + 1];
+        uint16_t nx = SENT;
+        if (inside && code <= 7u) {
+            const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
+            if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr))
+                nx = (uint16_t)(nr * AT + nc);
+        }
+        S[i] = v;
+        A[i] = nx;
+        if (!FINAL) R[i] = (uint16_t)i;
+        sreg[j] = v;
+        areg[j] = nx;
+        rreg[j] = (uint16_t)i;
     }
     __syncthreads();
+    MH_ASTAMP(1);
 
-    // Kahn walk inside the tile: the last arriver at a cell owns its complete sum and carries on.  Every lane is a small
-    // state machine (walking / looking for its next source cell), so a lane that finishes a short path picks up new work
-    // immediately.  (Measured: all four wavefronts walking beats a single walking wavefront 2:1 -- the phase is bound by
-    // the number of steps, not by the longest chain.)
-    {
-        int next_i = tid;
-        bool walking = false;
-        int r = 0, c = 0;
-        unsigned code = 8;
-        uint64_t total = 0;
-        while (__any(walking || next_i < AT * AT)) {
-            if (walking) {
-                // branch-free step: (dr+1, dc+1) of the 8 codes packed 2 bits each (NODIR decodes to garbage, masked by `go`)
-                constexpr unsigned DRP = (0u << 0) | (0u << 2) | (1u << 4) | (2u << 6) | (2u << 8) | (2u << 10) | (1u << 12) | (0u << 14);
-                constexpr unsigned DCP = (1u << 0) | (2u << 2) | (2u << 4) | (2u << 6) | (1u << 8) | (0u << 10) | (0u << 12) | (0u << 14);
-                const unsigned sh2 = (code & 7u) * 2u;
-                r += (int)((DRP >> sh2) & 3u) - 1;
-                c += (int)((DCP >> sh2) & 3u) - 1;
-                // stays inside the tile, the raster and the band?
-                const bool go = (code < 8u) & ((unsigned)r < (unsigned)AT) & ((unsigned)c < (unsigned)AT) & !halo_row(r0 + r);
-                bool cont = false;
-                if (go) {
-                    const uint64_t delta = total - ONE_PENDING;
-                    const uint64_t now = atomicAdd(reinterpret_cast<unsigned long long *>(&st[r * AT + c]), (unsigned long long)delta) + delta;
-                    cont = ((now >> DEG_SHIFT) & 0xf) == 0;  // else somebody else still has to arrive
-                    total = cont ? (now & SUM_MASK) : total;
-                    code = cont ? ((unsigned)(now >> CODE_SHIFT) & 0xfu) : code;
-                }
-                walking = cont;
-            } else if (next_i < AT * AT) {
-                const uint64_t s0 = st[next_i];
-                if (s0 & SRC) {  // SRC is only written by the initialisation above
-                    r = next_i / AT;
-                    c = next_i - r * AT;
-                    total = s0 & SUM_MASK;
-                    code = (unsigned)(s0 >> CODE_SHIFT) & 0xfu;
-                    walking = true;
-                }
-                next_i += 256;
+    bool more = true;
+    for (int round = 0; round < MAX_DOUBLINGS && more; ++round) {
+        uint16_t na[CPT], nr_[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const uint16_t a = areg[j];
+            na[j] = SENT;
+            nr_[j] = rreg[j];
+            if (a != SENT) {
+                const uint64_t v = sreg[j];
+                atomicAdd(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)(v & SUM_MASK));
+                if (v & TAINT) atomicOr(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)TAINT);
+                na[j] = A[a];
+                if (!FINAL) nr_[j] = R[a];
             }
         }
+        __syncthreads();   // every push and every ancestor read of this round is done
+        bool mine = false;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int i = tid + 256 * j;
+            if (areg[j] != SENT) {
+                A[i] = na[j];
+                if (!FINAL) R[i] = nr_[j];
+                areg[j] = na[j];
+                rreg[j] = nr_[j];
+                if (na[j] != SENT) {
+                    sreg[j] = S[i];   // S_{k+1}: what I push next round
+                    mine = true;
+                }
+            }
+        }
+        more = __syncthreads_or(mine) != 0;
     }
-    __syncthreads();
+    if (more) {
+        // still walking after 2**12 steps: the path has entered a flow cycle, and A is a cell ON the cycle; over all
+        // such paths these ancestors cover every cell of the cycle (a rotation of the cycle is onto)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (areg[j] != SENT) atomicOr(reinterpret_cast<unsigned long long *>(&S[areg[j]]), (unsigned long long)TAINT);
+        __syncthreads();
+    }
+    MH_ASTAMP(2);
 
     if (FINAL) {
-        for (int i = tid; i < AT * AT; i += 256) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int i = tid + 256 * j;
             const int r = i / AT, c = i - r * AT;
             if ((r0 + r) < H && (c0 + c) < W && !halo_row(r0 + r)) {
-                const uint64_t s = st[i];
-                out[(r0 + r) * W + c0 + c] = ((s >> DEG_SHIFT) & 0xf) ? 0.0 : (double)(s & SUM_MASK);
+                const uint64_t s = S[i];
+                out[(r0 + r) * W + c0 + c] = (s & TAINT) ? 0.0 : (double)(s & SUM_MASK);
             }
         }
+        MH_ASTAMP(3);
         return;
     }
 
@@ -185,8 +220,8 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         perim_cell(tid, r, c);
         const int64_t node = (int64_t)tile * NODE_STRIDE + tid;
         const bool inside = (r0 + r) < H && (c0 + c) < W;
-        const uint64_t s = st[r * AT + c];
-        const bool resolved = inside && ((s >> DEG_SHIFT) & 0xf) == 0;
+        const uint64_t s = S[r * AT + c];
+        const bool resolved = inside && !(s & TAINT);
         const unsigned code = win[(r + 1) * FS + c + 1];
         uint8_t fl = resolved ? F_RESOLVED : 0;
         int32_t dst = -1;
@@ -211,19 +246,18 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         uint16_t ex = NO_EXIT;
         if (entry) {
             fl |= F_ENTRY;
-            int pr = r, pc = c;
-            for (int step = 0; step < AT * AT; ++step) {
+            // the last in-tile cell of my path (doubling above); the path leaves through it iff that cell flows into a
+            // raster cell outside the tile.  A path that ends in a sink, leaves the raster, continues in the neighbouring
+            // band or runs into a flow cycle has no exit.
+            if (A[r * AT + c] == SENT) {
+                const int last = R[r * AT + c];
+                const int pr = last / AT, pc = last - pr * AT;
                 const unsigned cd = win[(pr + 1) * FS + pc + 1];
-                if (cd > 7u) break;  // sink inside the tile
-                const int nr = pr + dir_dr((int)cd), nc = pc + dir_dc((int)cd);
-                if (nr < 0 || nr >= AT || nc < 0 || nc >= AT) {
+                if (cd <= 7u) {
+                    const int nr = pr + dir_dr((int)cd), nc = pc + dir_dc((int)cd);
                     const int64_t gr = r0 + nr, gc = c0 + nc;
-                    if (gr >= 0 && gr < H && gc >= 0 && gc < W) ex = (uint16_t)perim_slot(pr, pc);  // else: leaves the raster
-                    break;
+                    if ((nr < 0 || nr >= AT || nc < 0 || nc >= AT) && gr >= 0 && gr < H && gc >= 0 && gc < W) ex = (uint16_t)perim_slot(pr, pc);
                 }
-                if (halo_row(r0 + nr)) break;  // continues in the neighbouring band
-                pr = nr;
-                pc = nc;
             }
         }
         nd.flags[node] = fl;
@@ -234,6 +268,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         nd.arrived[node] = 0;
         nd.next[node] = -1;
     }
+    MH_ASTAMP(3);
 }
 
 // ---- phase 2: the perimeter graph -------------------------------------------------------------------------
@@ -311,6 +346,17 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
+#ifdef MH_PROFILE_ACCUM
+    {
+        unsigned long long pr[2][8];
+        MH_HIP(hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_accum_prof), sizeof(pr)));
+        for (int f = 0; f < 2; ++f)
+            fprintf(stderr, "[accum profile phase %d] ticks/tile (thread 0): load=%.0f init=%.0f solve=%.0f publish/write=%.0f\n", f ? 3 : 1,
+                    pr[f][0] / (double)ntiles, pr[f][1] / (double)ntiles, pr[f][2] / (double)ntiles, pr[f][3] / (double)ntiles);
+        unsigned long long z[2][8] = {};
+        MH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_accum_prof), z, sizeof(z)));
+    }
+#endif
     return MHIP_OK;
 }
 

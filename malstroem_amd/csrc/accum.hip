@@ -21,7 +21,8 @@
 // longest in-tile flow path, ~260 cells on fBm terrain, at ~570 cycles per step with 0.3 of 64 lanes busy).  With
 // A_k[w] the 2**k-th downstream cell of w (SENT once the path has left the tile / ended) and S_k[v] the sum over the
 // cells at most 2**k - 1 steps upstream of v:   S_{k+1}[A_k[w]] += S_k[w]  for every w,  A_{k+1}[w] = A_k[A_k[w]].
-// ~log2(longest path) rounds of independent LDS atomics instead of a dependent chain.  Bit 63 of S is a taint flag
+// ~log2(longest path) rounds of independent LDS atomics instead of a dependent chain.  A and S share one 64-bit LDS
+// word, so the push and the read of A_k[A_k[w]] are ONE returning atomic add.  Bit 63 of S is a taint flag
 // (a cell that can never be resolved: unknown band halo, entry whose inflow never arrives, flow cycle); it travels
 // downstream with the sums and turns the result into the reference's 0.
 #include "common.hpp"
@@ -32,12 +33,18 @@ namespace {
 constexpr int AT = 64;                // tile edge
 constexpr int PERIM = 4 * AT - 4;     // perimeter cells of a tile
 constexpr int NODE_STRIDE = 256;      // perimeter slots per tile in the global node arrays
-constexpr int FS = AT + 4;            // LDS row stride of the flow-direction window (66 used)
+constexpr int FS = AT + 32;           // LDS row stride of the flow-direction window: column c sits at byte c + 16, so the
+                                      // 16-byte chunks of a row land 16-byte aligned (ring columns at 15 and AT + 16)
+constexpr int WOFF = 16;
 constexpr uint64_t SRC = 1ull << 63;      // phase-2 node word: source flag
-constexpr uint64_t TAINT = 1ull << 63;    // tile word: never resolved
-constexpr uint64_t SUM_MASK = (1ull << 55) - 1;
+// tile word (LDS, one per cell): bits 0..37 running sum | 38..50 A (2**k-th downstream cell, SENT13 = none) |
+// 51..62 R (last in-tile cell reached so far) | 63 taint.  Sums stay below 2**38 (accum_dev refuses larger rasters).
+constexpr uint64_t TAINT = 1ull << 63;    // never resolved
+constexpr int A_SHIFT = 38, R_SHIFT = 51;
+constexpr uint64_t SUM_MASK = (1ull << A_SHIFT) - 1;
+constexpr uint64_t A_MASK = 0x1fffull, R_MASK = 0xfffull, SENT13 = A_MASK;
+constexpr uint64_t FIELDS = (A_MASK << A_SHIFT) | (R_MASK << R_SHIFT);
 constexpr uint16_t NO_EXIT = 0xffffu;
-constexpr uint16_t SENT = 0xffffu;        // "no further downstream cell inside this tile"
 constexpr int CPT = AT * AT / 256;        // cells per thread
 constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simple path
 // phase-2 node word: an exit cell can be fed by every entry of its tile (hundreds), so the pending field is wider
@@ -91,9 +98,6 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
 {
     auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
     __shared__ uint64_t S[AT * AT];
-    __shared__ uint16_t A[AT * AT];
-    __shared__ uint16_t R[FINAL ? 1 : AT * AT];   // phase 1: last in-tile cell of the path that starts here
-    __shared__ uint8_t win[(AT + 2) * FS];
     const int tile = blockIdx.x;
     const int ti = tile / ntc, tj = tile - ti * ntc;
     const int64_t r0 = (int64_t)ti * AT, c0 = (int64_t)tj * AT;
@@ -102,30 +106,68 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
 
-    // flow-direction window incl. the 1-cell ring; outside the raster = NODIR (never flows, never receives)
-    for (int i = tid; i < (AT + 2) * (AT + 2); i += 256) {
-        const int wr = i / (AT + 2), wc = i - wr * (AT + 2);
-        const int64_t rr = r0 + wr - 1, cc = c0 + wc - 1;
-        win[wr * FS + wc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? fd[rr * W + cc] : (uint8_t)8;
+    // flow-direction window incl. the 1-cell ring; outside the raster = NODIR (never flows, never receives).
+    // Per window row: four 16-byte chunks (the tile's own columns) + the two ring bytes.
+    __shared__ __attribute__((aligned(16))) uint8_t win[(AT + 2) * FS];
+    __shared__ uint64_t inflow_l[FINAL ? NODE_STRIDE : 1];
+    __shared__ uint32_t arrived_l[FINAL ? NODE_STRIDE : 1];
+    if (FINAL) {  // what phase 2 delivered to my perimeter cells: one coalesced read per array
+        inflow_l[tid] = nd.inflow[(int64_t)tile * NODE_STRIDE + tid];
+        arrived_l[tid] = nd.arrived[(int64_t)tile * NODE_STRIDE + tid];
+    }
+    const bool wide = (W % 16) == 0 && c0 + AT <= W;   // c0 is a multiple of 64: chunks are 16-byte aligned in global memory
+    for (int q = tid; q < (AT + 2) * 6; q += 256) {
+        const int wr = q / 6, k = q - wr * 6;
+        const int64_t rr = r0 + wr - 1;
+        const bool row_in = rr >= 0 && rr < H;
+        if (k < 4) {
+            uint4 v = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
+            if (row_in) {
+                if (wide) v = *reinterpret_cast<const uint4 *>(fd + rr * W + c0 + 16 * k);
+                else {
+                    uint8_t b[16];
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int64_t cc = c0 + 16 * k + t;
+                        b[t] = cc < W ? fd[rr * W + cc] : (uint8_t)8;
+                    }
+                    memcpy(&v, b, 16);
+                }
+            }
+            *reinterpret_cast<uint4 *>(&win[wr * FS + WOFF + 16 * k]) = v;
+        } else {
+            const int64_t cc = k == 4 ? c0 - 1 : c0 + AT;
+            win[wr * FS + (k == 4 ? WOFF - 1 : WOFF + AT)] = (row_in && cc >= 0 && cc < W) ? fd[rr * W + cc] : (uint8_t)8;
+        }
     }
     __syncthreads();
     MH_ASTAMP(0);
 
+    // external in-degree of the perimeter cells (upstream neighbours outside the tile)
+    __shared__ uint8_t dext_l[NODE_STRIDE];
+    if (tid < PERIM) {
+        int r, c;
+        perim_cell(tid, r, c);
+        unsigned d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int nr = r + dir_dr(k), nc = c + dir_dc(k);
+            const bool in_tile = nr >= 0 && nr < AT && nc >= 0 && nc < AT;
+            d += (!in_tile && flows_into(win[(nr + 1) * FS + nc + WOFF], k)) ? 1u : 0u;
+        }
+        dext_l[tid] = (uint8_t)d;
+    }
+    __syncthreads();
+
     // my CPT cells: i = tid + 256 j (consecutive lanes = consecutive LDS words)
-    uint64_t sreg[CPT];
-    uint16_t areg[CPT], rreg[CPT];
+    uint64_t sreg[CPT];   // my cells' words as of the last barrier (what I push)
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int i = tid + 256 * j;
         const int r = i / AT, c = i - r * AT;
         const bool inside = (r0 + r) < H && (c0 + c) < W;
-        unsigned deg_ext = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int nr = r + dir_dr(k), nc = c + dir_dc(k);
-            const bool in_tile = nr >= 0 && nr < AT && nc >= 0 && nc < AT;
-            deg_ext += (!in_tile && flows_into(win[(nr + 1) * FS + nc + 1], k)) ? 1u : 0u;
-        }
+        const int slot = perim_slot(r, c);
+        unsigned deg_ext = slot >= 0 ? dext_l[slot] : 0u;
         uint64_t v = inside ? 1ull : TAINT;   // not a raster cell: nothing flows into it (its neighbours see NODIR... it has none)
         const bool halo = inside && halo_row(r0 + r);
         if (halo) {  // the neighbouring band's cell: known (> 0) = a source of that much flux, else it blocks its path
@@ -134,58 +176,47 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             deg_ext = 0;
         }
         if (FINAL && deg_ext && inside) {
-            const int64_t node = (int64_t)tile * NODE_STRIDE + perim_slot(r, c);
-            if (nd.arrived[node] == deg_ext) v += nd.inflow[node];
+            if (arrived_l[slot] == deg_ext) v += inflow_l[slot];
             else v |= TAINT;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
         }
         // downstream cell: inside the tile, the raster and the band, else the path ends here
-        const unsigned code = win[(r + 1) * FS + c + 1];
-        uint16_t nx = SENT;
+        const unsigned code = win[(r + 1) * FS + c + WOFF];
+        uint64_t nx = SENT13;
         if (inside && code <= 7u) {
             const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
             if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr))
-                nx = (uint16_t)(nr * AT + nc);
+                nx = (uint64_t)(nr * AT + nc);
         }
+        v |= (nx << A_SHIFT) | ((uint64_t)i << R_SHIFT);
         S[i] = v;
-        A[i] = nx;
-        if (!FINAL) R[i] = (uint16_t)i;
         sreg[j] = v;
-        areg[j] = nx;
-        rreg[j] = (uint16_t)i;
     }
     __syncthreads();
     MH_ASTAMP(1);
 
     bool more = true;
     for (int round = 0; round < MAX_DOUBLINGS && more; ++round) {
-        uint16_t na[CPT], nr_[CPT];
+        uint64_t got[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const uint16_t a = areg[j];
-            na[j] = SENT;
-            nr_[j] = rreg[j];
-            if (a != SENT) {
-                const uint64_t v = sreg[j];
-                atomicAdd(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)(v & SUM_MASK));
+            const uint64_t v = sreg[j], a = (v >> A_SHIFT) & A_MASK;
+            got[j] = 0;
+            if (a != SENT13) {
+                // push my sum to A_k[me]; the word that comes back carries A_k and R_k of that cell
+                got[j] = atomicAdd(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)(v & SUM_MASK));
                 if (v & TAINT) atomicOr(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)TAINT);
-                na[j] = A[a];
-                if (!FINAL) nr_[j] = R[a];
             }
         }
-        __syncthreads();   // every push and every ancestor read of this round is done
+        __syncthreads();   // every push of this round is done; nobody but its owner touches a word until the next barrier
         bool mine = false;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int i = tid + 256 * j;
-            if (areg[j] != SENT) {
-                A[i] = na[j];
-                if (!FINAL) R[i] = nr_[j];
-                areg[j] = na[j];
-                rreg[j] = nr_[j];
-                if (na[j] != SENT) {
-                    sreg[j] = S[i];   // S_{k+1}: what I push next round
-                    mine = true;
-                }
+            if (((sreg[j] >> A_SHIFT) & A_MASK) != SENT13) {
+                const uint64_t w = (S[i] & ~FIELDS) | (got[j] & FIELDS);   // S_{k+1} | A_{k+1} | R_{k+1}
+                S[i] = w;
+                sreg[j] = w;
+                mine |= ((w >> A_SHIFT) & A_MASK) != SENT13;
             }
         }
         more = __syncthreads_or(mine) != 0;
@@ -194,8 +225,10 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         // still walking after 2**12 steps: the path has entered a flow cycle, and A is a cell ON the cycle; over all
         // such paths these ancestors cover every cell of the cycle (a rotation of the cycle is onto)
 #pragma unroll
-        for (int j = 0; j < CPT; ++j)
-            if (areg[j] != SENT) atomicOr(reinterpret_cast<unsigned long long *>(&S[areg[j]]), (unsigned long long)TAINT);
+        for (int j = 0; j < CPT; ++j) {
+            const uint64_t a = (sreg[j] >> A_SHIFT) & A_MASK;
+            if (a != SENT13) atomicOr(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)TAINT);
+        }
         __syncthreads();
     }
     MH_ASTAMP(2);
@@ -222,7 +255,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         const bool inside = (r0 + r) < H && (c0 + c) < W;
         const uint64_t s = S[r * AT + c];
         const bool resolved = inside && !(s & TAINT);
-        const unsigned code = win[(r + 1) * FS + c + 1];
+        const unsigned code = win[(r + 1) * FS + c + WOFF];
         uint8_t fl = resolved ? F_RESOLVED : 0;
         int32_t dst = -1;
         if (inside && code <= 7u) {
@@ -240,7 +273,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int nr = r + dir_dr(k), nc = c + dir_dc(k);
-                if ((nr < 0 || nr >= AT || nc < 0 || nc >= AT) && flows_into(win[(nr + 1) * FS + nc + 1], k)) entry = true;
+                if ((nr < 0 || nr >= AT || nc < 0 || nc >= AT) && flows_into(win[(nr + 1) * FS + nc + WOFF], k)) entry = true;
             }
         }
         uint16_t ex = NO_EXIT;
@@ -249,10 +282,10 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             // the last in-tile cell of my path (doubling above); the path leaves through it iff that cell flows into a
             // raster cell outside the tile.  A path that ends in a sink, leaves the raster, continues in the neighbouring
             // band or runs into a flow cycle has no exit.
-            if (A[r * AT + c] == SENT) {
-                const int last = R[r * AT + c];
+            if (((s >> A_SHIFT) & A_MASK) == SENT13) {
+                const int last = (int)((s >> R_SHIFT) & R_MASK);
                 const int pr = last / AT, pc = last - pr * AT;
-                const unsigned cd = win[(pr + 1) * FS + pc + 1];
+                const unsigned cd = win[(pr + 1) * FS + pc + WOFF];
                 if (cd <= 7u) {
                     const int nr = pr + dir_dr((int)cd), nc = pc + dir_dc((int)cd);
                     const int64_t gr = r0 + nr, gc = c0 + nc;
@@ -319,7 +352,7 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
 {
     const int ntr = (int)cdiv(H, AT), ntc = (int)cdiv(W, AT);
     const int64_t ntiles = (int64_t)ntr * ntc, nnodes = ntiles * NODE_STRIDE;
-    if (nnodes >= (int64_t)INT32_MAX) {
+    if (nnodes >= (int64_t)INT32_MAX || H * W >= (1ll << 37)) {   // + the 38-bit sum field of the tile words
         set_error("accumulated_flow: raster too large for the int32 perimeter-node domain");
         return MHIP_ELIMIT;
     }

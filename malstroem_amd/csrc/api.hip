@@ -804,7 +804,7 @@ static int stage_label(mhip_ctx *c, hipStream_t s)
                         &c->nlabels_raw, s));
     MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
     MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
-                           c->raw_stats.as<mhip_stat_record>(), s));
+                           c->raw_stats.as<mhip_stat_record>(), s, W));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_LABEL] = true;
     c->have[MHIP_R_LABELS] = true;
@@ -825,7 +825,7 @@ static int stage_watershed(mhip_ctx *c, hipStream_t s)
     MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
     MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s));
     MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
-    MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s));
+    MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s, W));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_WATERSHED] = true;
     c->have[MHIP_R_WATERSHEDS] = true;
@@ -1041,7 +1041,7 @@ static int ctx_apply_keep_on(mhip_ctx *c, const uint8_t *keep, hipStream_t s)
         MH_TRY(relabel_lut_dev(c->r[MHIP_R_LABELS].as<int32_t>(), d_lut.as<int32_t>(), c->nlabels_raw, n, s));
         MH_TRY(c->stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1)));
         MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels,
-                               c->stats.as<mhip_stat_record>(), s));
+                               c->stats.as<mhip_stat_record>(), s, c->W));
     } else {
         // keep everything (background excluded by construction): labels and stats are the raw ones
         c->nlabels = c->nlabels_raw;

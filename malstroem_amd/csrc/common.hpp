@@ -154,11 +154,12 @@ int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_
 int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64_t n, hipStream_t s);
 int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask,
                   hipStream_t s);
+// W: raster width if the caller knows it (2-D tiles combine a label's rows before the global atomics), 0 = flat array
 int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
-                    hipStream_t s);
+                    hipStream_t s, int64_t W = 0);
 int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
                   mhip_index_record *d_rec, hipStream_t s);
-int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s);
+int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s, int64_t W = 0);
 int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
 // watershed.hip
 int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s,

@@ -737,49 +737,6 @@ static int fill_run_to_convergence(FillRun &f, hipStream_t s, FillStats *st)
     return f.finish(s, st);
 }
 
-namespace {
-
-// ---- min/max reduction for minimum_safe_short_and_diag -------------------------------------------
-__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned int *out)
-{
-    float mx = -__builtin_inff(), mn = __builtin_inff();
-    bool has_nan = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = x[i];
-        has_nan |= is_nan_bits(v);
-        mx = fmaxf(mx, v);
-        mn = fminf(mn, v);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mx = fmaxf(mx, __shfl_xor(mx, o));
-        mn = fminf(mn, __shfl_xor(mn, o));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&out[0], f32_key(mx));
-        atomicMin(&out[1], f32_key(mn));
-    }
-    if (has_nan) atomicOr(&out[2], 1u);
-}
-
-__global__ void depths_kernel(const float *__restrict__ f, const float *__restrict__ d, float *__restrict__ o, int64_t n)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t n4 = n >> 2;
-    if (i < n4) {
-        const float4 a = reinterpret_cast<const float4 *>(f)[i], b = reinterpret_cast<const float4 *>(d)[i];
-        float4 r;
-        r.x = __fsub_rn(a.x, b.x);
-        r.y = __fsub_rn(a.y, b.y);
-        r.z = __fsub_rn(a.z, b.z);
-        r.w = __fsub_rn(a.w, b.w);
-        reinterpret_cast<float4 *>(o)[i] = r;
-    }
-    if (i == 0)
-        for (int64_t k = n4 << 2; k < n; ++k) o[k] = __fsub_rn(f[k], d[k]);
-}
-
-}  // namespace
 
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st)
 {
@@ -809,83 +766,6 @@ int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, dou
     f.noflat = true; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W; f.sh = sh; f.dg = dg;
     noflat_seed(f, d_filled, sh, dg, H * W);
     return fill_run_to_convergence(f, s, st);
-}
-
-int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s)
-{
-    DevBuf acc;
-    MH_TRY(acc.alloc(sizeof(unsigned int) * 4));
-    unsigned int init[4] = {0u, 0xffffffffu, 0u, 0u};
-    MH_HIP(hipMemcpyAsync(acc.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-    const unsigned grid = (unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
-    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, d_x, n, acc.as<unsigned int>());
-    MH_HIP(hipGetLastError());
-    unsigned int h[4];
-    MH_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
-    *mx = key_f32(h[0]);
-    *mn = key_f32(h[1]);
-    *has_nan = h[2] != 0;
-    return MHIP_OK;
-}
-
-namespace {
-__global__ void row_update_kernel(uint8_t *dst, const uint8_t *src, int64_t n, int *changed)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t v = src[i];
-    if (dst[i] != v) {
-        dst[i] = v;
-        *changed = 1;
-    }
-}
-}  // namespace
-
-// dst[0..nbytes) = src[0..nbytes); *changed = 1 if any byte differed (band halo refresh)
-int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s)
-{
-    DevBuf flag;
-    MH_TRY(flag.alloc(4));
-    MH_HIP(hipMemsetAsync(flag.p, 0, 4, s));
-    hipLaunchKernelGGL(row_update_kernel, dim3((unsigned)cdiv(nbytes, 256)), dim3(256), 0, s, (uint8_t *)d_dst, (const uint8_t *)d_src,
-                       nbytes, flag.as<int>());
-    MH_HIP(hipGetLastError());
-    MH_HIP(hipMemcpyAsync(changed, flag.p, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
-    return MHIP_OK;
-}
-
-// fill.py:235-250: maxval = f64(max(|amax|,|amin|)); short = (nextafter(maxval, inf) - maxval) * 1024; diag = short * 2**0.5
-int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s)
-{
-    DevBuf acc;
-    MH_TRY(acc.alloc(sizeof(unsigned int) * 4));
-    unsigned int init[4] = {0u, 0xffffffffu, 0u, 0u};
-    MH_HIP(hipMemcpyAsync(acc.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-    const unsigned grid = (unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
-    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, d_dem, n, acc.as<unsigned int>());
-    MH_HIP(hipGetLastError());
-    unsigned int h[4];
-    MH_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
-    double amax = (double)key_f32(h[0]), amin = (double)key_f32(h[1]);
-    if (h[2]) amax = amin = __builtin_nan("");  // np.amax/np.amin propagate NaN
-    double a = __builtin_fabs(amax), b = __builtin_fabs(amin);
-    double maxval = a > b ? a : b;  // python max(): first wins on ties/NaN ordering is irrelevant here
-    double nextval = __builtin_nextafter(maxval, __builtin_inf());
-    *sh = (nextval - maxval) * 1024.0;
-    *dg = *sh * __builtin_pow(2.0, 0.5);
-    return MHIP_OK;
-}
-
-int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s)
-{
-    const int64_t n4 = n >> 2;
-    const unsigned grid = (unsigned)(cdiv(n4 > 0 ? n4 : 1, 256));
-    hipLaunchKernelGGL(depths_kernel, dim3(grid), dim3(256), 0, s, d_filled, d_dem, d_out, n);
-    MH_HIP(hipGetLastError());
-    return MHIP_OK;
 }
 
 }  // namespace mh

@@ -8,8 +8,10 @@
 //   label.keep_labels      label.py:78-98   : keep[background] = False; mask = keep[labelled]
 //
 // All of them are scatter reductions keyed by label.  Label 0 (background) typically owns ~90 % of the
-// cells, so every kernel first combines equal-label runs inside a wavefront (segmented shuffle reduction)
-// and only the run heads touch global atomics.  min/max go through monotone integer keys; counts are
+// cells, so every kernel first combines equal-label runs inside a wavefront (segmented shuffle reduction).
+// label_stats / label_count then combine the runs of a 32-row x 256-column tile in an LDS hash table keyed by
+// label (labels are spatially compact: a bluespot or watershed crosses many rows of few tiles), and only one
+// record per (label, tile) goes to the global atomics; the other kernels send their run heads there directly.  min/max go through monotone integer keys; counts are
 // integers; the f64 sum uses global float atomics (order independent whenever every partial sum is exactly
 // representable, which holds for bluespot depths -- SURVEY.md 8a row S; otherwise within 1 ulp-scale
 // rounding of the sequential sum, see tests).
@@ -75,58 +77,124 @@ __global__ __launch_bounds__(256) void stats_init_kernel(StatAcc a, int64_t nrec
     a.count[i] = 0ull;
 }
 
-// Background (label 0) is accumulated in registers over the whole grid-stride range and leaves as one
-// atomic set per wavefront; other labels leave as one atomic set per equal-label run, and the min/max
-// atomics are skipped when a (possibly stale, hence conservative) read shows they cannot improve the record.
-__global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
-                                                   int64_t n, int64_t nlab, StatAcc a, unsigned int *bad)
+// ---- tile geometry shared by the LDS-table kernels ----------------------------------------------------------------
+// The raster (width W, n cells; a flat array is treated as 256 columns wide) is cut into tiles of TR rows x 256 columns;
+// a block owns a tile, its four wavefronts the four 64-column strips of every row.
+constexpr int TR = 32;
+struct TileGeom {
+    int64_t n, W;
+    int64_t ntr, ntc;
+};
+__host__ __device__ inline TileGeom tile_geom(int64_t n, int64_t W)
 {
+    TileGeom g;
+    g.n = n;
+    g.W = (W > 0 && n % W == 0) ? W : 256;
+    const int64_t H = cdiv(n, g.W);
+    g.ntr = cdiv(H, TR);
+    g.ntc = cdiv(g.W, 256);
+    return g;
+}
+
+// open-addressing slot of `key` in an LDS table of TS (power of two) slots, -1 when the probe limit is hit (the caller
+// then falls back to the global atomics); keys[] holds -1 for an empty slot
+template <int TS> __device__ __forceinline__ int table_slot(int *keys, int key)
+{
+    unsigned h = ((unsigned)key * 2654435761u) >> 7;
+#pragma unroll 1
+    for (int probe = 0; probe < 16; ++probe) {
+        h &= (unsigned)(TS - 1);
+        const int prev = atomicCAS(&keys[h], -1, key);
+        if (prev == -1 || prev == key) return (int)h;
+        ++h;
+    }
+    return -1;
+}
+
+// Background (label 0) is accumulated in registers over all tiles of a block and leaves as one atomic set per
+// wavefront; other labels are combined per equal-label run (wavefront shuffles), then per tile (LDS table), and leave
+// as one atomic set per (label, tile); the min/max atomics are skipped when a (possibly stale, hence conservative)
+// read shows they cannot improve the record.
+constexpr int STATS_TS = 1024;
+__global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
+                                                   TileGeom g, int64_t nlab, StatAcc a, unsigned int *bad)
+{
+    __shared__ int keys[STATS_TS];
+    __shared__ unsigned int tcnt[STATS_TS], tmin[STATS_TS], tmax[STATS_TS];
+    __shared__ double tsum[STATS_TS];
     const int lane = threadIdx.x & 63;
     float bmin = __builtin_inff(), bmax = -__builtin_inff();
     double bsum = 0.0;
     unsigned long long bcnt = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nloop = cdiv(n, stride) * stride;  // keep whole waves in the loop (shuffles need all lanes)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
-        const bool valid = i < n;
-        int32_t l = valid ? lab[i] : -1;
-        const float v = valid ? data[i] : 0.0f;
-        if (valid && (l < 0 || l > nlab)) {
-            atomicOr(bad, 1u);
-            l = -1;
+    auto to_global = [&](int32_t l, uint32_t kmin, uint32_t kmax, double sum, unsigned long long cnt) {
+        if (kmin < a.minkey[l]) atomicMin(&a.minkey[l], kmin);
+        if (kmax > a.maxkey[l]) atomicMax(&a.maxkey[l], kmax);
+        atomicAdd(&a.sum[l], sum);
+        atomicAdd(&a.count[l], cnt);
+    };
+    const int64_t ntiles = g.ntr * g.ntc;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int k = threadIdx.x; k < STATS_TS; k += 256) {
+            keys[k] = -1;
+            tcnt[k] = 0u;
+            tmin[k] = 0xffffffffu;
+            tmax[k] = 0u;
+            tsum[k] = 0.0;
         }
-        const bool isnan = v != v;
-        // NaN never wins `val < min` / `val > max` in the reference; it does poison the sum.
-        float vmin = isnan ? __builtin_inff() : v, vmax = isnan ? -__builtin_inff() : v;
-        if (__all(l <= 0)) {  // wave-uniform fast path: only background (or padding) in this wave
-            if (l == 0) {
-                bmin = fminf(bmin, vmin);
-                bmax = fmaxf(bmax, vmax);
-                bsum += (double)v;
-                ++bcnt;
+        __syncthreads();
+        const int64_t tr = tile / g.ntc, tc = tile - tr * g.ntc;
+        const int64_t col = tc * 256 + threadIdx.x;
+        for (int rr = 0; rr < TR; ++rr) {
+            const int64_t i = (tr * TR + rr) * g.W + col;
+            const bool valid = col < g.W && i < g.n;
+            int32_t l = valid ? lab[i] : -1;
+            const float v = valid ? data[i] : 0.0f;
+            if (valid && (l < 0 || l > nlab)) {
+                atomicOr(bad, 1u);
+                l = -1;
             }
-            continue;
-        }
-        const bool ok = l >= 0;
-        const int len = run_length_from(l, lane, ok);
-        const bool head = is_run_head(l, lane, ok);
-        vmin = seg_reduce(vmin, len, [](float x, float y) { return fminf(x, y); });
-        vmax = seg_reduce(vmax, len, [](float x, float y) { return fmaxf(x, y); });
-        const double s = seg_reduce((double)v, len, [](double x, double y) { return x + y; });
-        if (head && ok) {
-            if (l == 0) {
-                bmin = fminf(bmin, vmin);
-                bmax = fmaxf(bmax, vmax);
-                bsum += s;
-                bcnt += (unsigned long long)len;
-            } else {
-                const uint32_t kmin = f32_key(vmin), kmax = f32_key(vmax);
-                if (kmin < a.minkey[l]) atomicMin(&a.minkey[l], kmin);
-                if (kmax > a.maxkey[l]) atomicMax(&a.maxkey[l], kmax);
-                atomicAdd(&a.sum[l], s);
-                atomicAdd(&a.count[l], (unsigned long long)len);
+            const bool isnan = v != v;
+            // NaN never wins `val < min` / `val > max` in the reference; it does poison the sum.
+            float vmin = isnan ? __builtin_inff() : v, vmax = isnan ? -__builtin_inff() : v;
+            if (__all(l <= 0)) {  // wave-uniform fast path: only background (or padding) in this wave
+                if (l == 0) {
+                    bmin = fminf(bmin, vmin);
+                    bmax = fmaxf(bmax, vmax);
+                    bsum += (double)v;
+                    ++bcnt;
+                }
+                continue;
+            }
+            const bool ok = l >= 0;
+            const int len = run_length_from(l, lane, ok);
+            const bool head = is_run_head(l, lane, ok);
+            vmin = seg_reduce(vmin, len, [](float x, float y) { return fminf(x, y); });
+            vmax = seg_reduce(vmax, len, [](float x, float y) { return fmaxf(x, y); });
+            const double sm = seg_reduce((double)v, len, [](double x, double y) { return x + y; });
+            if (head && ok) {
+                if (l == 0) {
+                    bmin = fminf(bmin, vmin);
+                    bmax = fmaxf(bmax, vmax);
+                    bsum += sm;
+                    bcnt += (unsigned long long)len;
+                } else {
+                    const uint32_t kmin = f32_key(vmin), kmax = f32_key(vmax);
+                    const int h = table_slot<STATS_TS>(keys, l);
+                    if (h >= 0) {
+                        atomicMin(&tmin[h], kmin);
+                        atomicMax(&tmax[h], kmax);
+                        atomicAdd(&tsum[h], sm);
+                        atomicAdd(&tcnt[h], (unsigned int)len);
+                    } else {
+                        to_global(l, kmin, kmax, sm, (unsigned long long)len);
+                    }
+                }
             }
         }
+        __syncthreads();
+        for (int k = threadIdx.x; k < STATS_TS; k += 256)
+            if (keys[k] >= 0) to_global(keys[k], tmin[k], tmax[k], tsum[k], (unsigned long long)tcnt[k]);
+        __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -250,30 +318,50 @@ __global__ __launch_bounds__(256) void arg_finish_kernel(const double *__restric
 }
 
 // ---- bincount / max / lut / mask -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void count_kernel(const int32_t *__restrict__ lab, int64_t n, int64_t nlab,
+constexpr int COUNT_TS = 2048;
+__global__ __launch_bounds__(256) void count_kernel(const int32_t *__restrict__ lab, TileGeom g, int64_t nlab,
                                                    unsigned long long *counts, unsigned int *bad)
 {
+    __shared__ int keys[COUNT_TS];
+    __shared__ unsigned int tcnt[COUNT_TS];
     const int lane = threadIdx.x & 63;
     unsigned long long bcnt = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nloop = cdiv(n, stride) * stride;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
-        const bool valid = i < n;
-        int32_t l = valid ? lab[i] : -1;
-        if (valid && (l < 0 || l > nlab)) {
-            atomicOr(bad, 1u);
-            l = -1;
+    const int64_t ntiles = g.ntr * g.ntc;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int k = threadIdx.x; k < COUNT_TS; k += 256) {
+            keys[k] = -1;
+            tcnt[k] = 0u;
         }
-        if (__all(l <= 0)) {
-            bcnt += l == 0;
-            continue;
+        __syncthreads();
+        const int64_t tr = tile / g.ntc, tc = tile - tr * g.ntc;
+        const int64_t col = tc * 256 + threadIdx.x;
+        for (int rr = 0; rr < TR; ++rr) {
+            const int64_t i = (tr * TR + rr) * g.W + col;
+            const bool valid = col < g.W && i < g.n;
+            int32_t l = valid ? lab[i] : -1;
+            if (valid && (l < 0 || l > nlab)) {
+                atomicOr(bad, 1u);
+                l = -1;
+            }
+            if (__all(l <= 0)) {
+                bcnt += l == 0;
+                continue;
+            }
+            const bool ok = l >= 0;
+            const int len = run_length_from(l, lane, ok);
+            if (is_run_head(l, lane, ok) && ok) {
+                if (l == 0) bcnt += (unsigned long long)len;
+                else {
+                    const int h = table_slot<COUNT_TS>(keys, l);
+                    if (h >= 0) atomicAdd(&tcnt[h], (unsigned int)len);
+                    else atomicAdd(&counts[l], (unsigned long long)len);
+                }
+            }
         }
-        const bool ok = l >= 0;
-        const int len = run_length_from(l, lane, ok);
-        if (is_run_head(l, lane, ok) && ok) {
-            if (l == 0) bcnt += (unsigned long long)len;
-            else atomicAdd(&counts[l], (unsigned long long)len);
-        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < COUNT_TS; k += 256)
+            if (keys[k] >= 0) atomicAdd(&counts[keys[k]], (unsigned long long)tcnt[k]);
+        __syncthreads();
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bcnt += __shfl_xor(bcnt, o);
@@ -336,8 +424,15 @@ int check_bad(DevBuf &bad, hipStream_t s, const char *what)
 
 }  // namespace
 
+// one block per tile up to 256 CUs x 8 blocks, then tile-stride
+static unsigned tile_grid(const TileGeom &g)
+{
+    const int64_t nt = g.ntr * g.ntc;
+    return (unsigned)(nt < 2048 ? (nt > 0 ? nt : 1) : 2048);
+}
+
 int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
-                    hipStream_t s)
+                    hipStream_t s, int64_t W)
 {
     const int64_t nrec = nlab + 1;
     DevBuf mn, mx, sm, ct, bad;
@@ -349,8 +444,8 @@ int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int
     MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
     StatAcc a{mn.as<uint32_t>(), mx.as<uint32_t>(), sm.as<double>(), ct.as<unsigned long long>()};
     hipLaunchKernelGGL(stats_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
-    hipLaunchKernelGGL(stats_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_data, d_labels, n, nlab, a,
-                       bad.as<unsigned int>());
+    const TileGeom g = tile_geom(n, W);
+    hipLaunchKernelGGL(stats_kernel, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
     hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "label_stats");
@@ -377,13 +472,14 @@ int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int6
     return check_bad(bad, s, "label_min/max_index");
 }
 
-int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s)
+int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s, int64_t W)
 {
     DevBuf bad;
     MH_TRY(bad.alloc(4));
     MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
     MH_HIP(hipMemsetAsync(d_counts, 0, 8 * (size_t)(nlab + 1), s));
-    hipLaunchKernelGGL(count_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_labels, n, nlab,
+    const TileGeom g = tile_geom(n, W);
+    hipLaunchKernelGGL(count_kernel, dim3(tile_grid(g)), dim3(256), 0, s, d_labels, g, nlab,
                        reinterpret_cast<unsigned long long *>(d_counts), bad.as<unsigned int>());
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "label_count");

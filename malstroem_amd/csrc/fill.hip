@@ -35,7 +35,6 @@ constexpr int TI = 62;  // tile interior edge
 #ifndef MH_ROW_BARRIER
 #define MH_ROW_BARRIER 1
 #endif
-constexpr int MAXCYC = MH_MAXCYC;
 constexpr int DPP_WF_SL1 = 0x130;  // lane i <- lane i+1
 constexpr int DPP_WF_SR1 = 0x138;  // lane i <- lane i-1
 
@@ -247,20 +246,65 @@ __device__ __forceinline__ void transpose(double (&x)[WN], uint32_t *scr, int la
     for (int r = 0; r < WN; ++r) x[r] = __hiloint2double((int)hi[r], (int)lo[r]);
 }
 
+// columns 1 and TI of the window (lane = row) without a full transpose: rows go to the scratch, two strided reads back
+__device__ __forceinline__ void extract_cols(const float (&x)[WN], uint32_t *scr, int lane, float &c1, float &c62)
+{
+#pragma unroll
+    for (int r = 0; r < WN; ++r) scr[r * (WN + 1) + lane] = __float_as_uint(x[r]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    c1 = __uint_as_float(scr[lane * (WN + 1) + 1]);
+    c62 = __uint_as_float(scr[lane * (WN + 1) + TI]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void extract_cols(const double (&x)[WN], uint32_t *scr, int lane, double &c1, double &c62)
+{
+    int lo1, lo62, hi1, hi62;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int r = 0; r < WN; ++r) scr[r * (WN + 1) + lane] = (uint32_t)(half ? __double2hiint(x[r]) : __double2loint(x[r]));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int a1 = (int)scr[lane * (WN + 1) + 1], a62 = (int)scr[lane * (WN + 1) + TI];
+        if (half) { hi1 = a1; hi62 = a62; } else { lo1 = a1; lo62 = a62; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    c1 = __hiloint2double(hi1, lo1);
+    c62 = __hiloint2double(hi62, lo62);
+}
+
 template <typename WT> struct Inf;
 template <> struct Inf<float> { static __device__ __forceinline__ float v() { return __builtin_inff(); } };
 template <> struct Inf<double> { static __device__ __forceinline__ double v() { return __builtin_inf(); } };
 
-// ---- one round: a resident grid of wavefronts pulls the active tiles from sharded worklists ----------------
-// Round k consumes list[k&1][shard][..] (count[k][shard] entries) and appends the tiles whose halo it changed to
-// list[(k+1)&1][shard'] where shard' = tile % NSHARD; mark[][] de-duplicates appends (a tile clears its own mark
-// when it is visited).  Wave g starts pulling at shard g % NSHARD and walks the other shards when its own runs dry,
+// ---- one round: a resident grid of workgroups pulls the active MACRO TILES from sharded worklists ------------
+// The scheduling unit is a macro tile = 2 x 2 tiles = one workgroup of four wavefronts, one tile each.  Inside a visit
+// the four waves iterate: one local cycle each, then they publish their tiles' edge rows / columns in LDS, refresh
+// the halos that face a sibling from there, and repeat until no sibling changed (or a cap): information crosses the
+// macro tile at LDS speed and one HBM load / store / worklist round trip is amortised over several cycles.
+// Round k consumes list[k&1][shard][..] (count[k][shard] entries) and appends the macro tiles whose halo it changed to
+// list[(k+1)&1][shard'] where shard' = id % NSHARD; mark[][] de-duplicates appends (a macro tile clears its own mark
+// when it is visited).  Block g starts pulling at shard g % NSHARD and walks the other shards when its own runs dry,
 // so the work is balanced while every queue head / append counter only sees 1/NSHARD of the traffic (one shared
 // word saturates at ~90 atomics per microsecond on this chip).  sum(count[k+1][*]) == 0  <=>  converged.
 constexpr int NSHARD = 8;
+#ifndef MH_MAXIT
+#define MH_MAXIT 2
+#endif
+constexpr int MAXIT = MH_MAXIT;   // sibling-exchange iterations per macro visit (measured: 2 is best for the f32 fill)
+constexpr int MAXCYC = MH_MAXCYC; // local cycles per visit of a single tile (MT == 1)
+enum { E_ROW1 = 0, E_ROW62 = 1, E_COL1 = 2, E_COL62 = 3 };
 struct RoundArgs {
     int64_t H, Wd;
-    int ntr, ntc;
+    int ntr, ntc;               // tiles
+    int mtr, mtc;               // macro tiles
     int shard_cap;              // list capacity per shard
     int *list_cur, *list_nxt;   // [NSHARD][shard_cap]
     unsigned int *mark_cur, *mark_nxt;
@@ -286,27 +330,36 @@ struct Prof { long long load = 0, pass = 0, tr = 0, store = 0, push = 0; };
 #define MH_PROF_PASS
 #endif
 
-template <typename WT, bool NOFLAT, int INIT>
-__device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__restrict__ dem, const float *__restrict__ seed,
-                                           WT *__restrict__ W, int64_t tile, uint32_t *scr, int lane, unsigned &visits,
-                                           unsigned &cycles MH_PROF_ARG)
+// One macro-tile visit; called by all four waves of the block (it contains block barriers).  `X`: the exchange area
+// [2 parities][4 waves][4 edges][64] of WT in LDS.
+// MT == 2: as described above.  MT == 1: the scheduling unit is a single tile and a single wavefront (no barriers, no
+// exchange, up to MAXCYC local cycles) -- the f64 kernel runs one wave per SIMD, where a block that waits for its slowest
+// sibling leaves whole SIMDs idle (measured: no-flats 20.4 ms with MT == 1, 24.5-31 ms with MT == 2).
+template <typename WT, bool NOFLAT, int INIT, int MT>
+__device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__restrict__ dem, const float *__restrict__ seed,
+                                            WT *__restrict__ W, int macro, unsigned flags, uint32_t *scr, WT *X, int lane, int wave,
+                                            unsigned &visits, unsigned &cycles MH_PROF_ARG)
 {
     MH_STAMP(tp0);
     const int64_t H = a.H, Wd = a.Wd;
     const int ntr = a.ntr, ntc = a.ntc;
     constexpr bool first_round = INIT != INIT_NONE;  // compile time: keeps the 128 row loads straight-line
-    const int ti = (int)(tile / ntc), tj = (int)(tile % ntc);
+    const int mi = macro / a.mtc, mj = macro - mi * a.mtc;
+    constexpr bool MACRO = MT == 2;
+    const int qi = MACRO ? wave >> 1 : 0, qj = MACRO ? wave & 1 : 0;
+    const int ti = MT * mi + qi, tj = MT * mj + qj;
+    const bool has_tile = !MACRO || (ti < ntr && tj < ntc);   // wave-uniform; a wave without a tile only keeps the barriers company
     const int64_t r0 = (int64_t)ti * TI, c0 = (int64_t)tj * TI;  // raster coords of window (0,0)
     const int64_t cc = c0 + lane;
     const bool col_in = cc < Wd;
     const bool upd = lane >= 1 && lane <= TI;
+    const WT INF = Inf<WT>::v();
 
     // ---- stage-in: all 128 row loads are issued back to back (scalar row base + one shared per-lane offset keeps
     // them off the VGPR address budget); a visit's latency is dominated by this one round trip to HBM/L2.
     WT w[WN];
     float d[WN];
-    {
-        const WT INF = Inf<WT>::v();
+    if (has_tile) {
         // Unconditional loads from clamped (always in-raster) addresses + selects: no exec-masked branches, so all
         // 128 loads are in flight together.  Row pointers advance incrementally in SGPRs (opaque asm keeps the
         // compiler from hoisting 64 row offsets out of the persistent tile loop and spilling them).
@@ -349,6 +402,12 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             w[r] = wv;
             d[r] = dv;
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            w[r] = INF;
+            d[r] = __builtin_inff();
+        }
     }
 
     MH_STAMP(tp1);
@@ -358,57 +417,110 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
     if (a.fixed_top && r0 == 0) rowok &= ~1ull;
     if (a.fixed_bot && H - 1 - r0 < WN) rowok &= ~(1ull << (H - 1 - r0));
     const bool upd_t = upd && ((rowok >> lane) & 1ull);
-    const uint64_t updmask = __ballot(upd), updmask_t = __ballot(upd_t);
+    const uint64_t updmask = has_tile ? __ballot(upd) : 0ull, updmask_t = has_tile ? __ballot(upd_t) : 0ull;
     // rows 0 / 63 are never updated by a pass; a frozen row in between can only be a band's bottom halo row
     const int frozen = (a.fixed_bot && H - 1 - r0 < WN - 1) ? (int)(H - 1 - r0) : -1;
-    uint64_t anyN = 0, topN = 0, botN = 0, anyT = 0, leftT = 0, rightT = 0;  // any*: change masks; the others: halo probes
-    bool capped = true;
+    uint64_t anyAll = 0, topN = 0, botN = 0, leftT = 0, rightT = 0;  // change mask; halo probes
+    bool capped = true;   // block-uniform: the sibling exchange was cut off while something still moved
     int ncyc = 0;
-    for (int cyc = 0; cyc < MAXCYC; ++cyc) {
-        ++ncyc;
-        uint64_t chg = 0;
-#pragma nounroll
-        for (int half = 0; half < 2; ++half) {
-            uint64_t any = 0;
-            MH_STAMP(q0);
-            if constexpr (NOFLAT) {
-                pass_noflat<true>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, a.sh, a.dg, any);
-                pass_noflat<false>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, a.sh, a.dg, any);
-            } else {
-                pass_plain<true>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, any);
-                pass_plain<false>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, any);
-            }
-            // neighbour impact of the current state (the last cycle changes nothing, so its probes are final)
-            uint64_t p0, p1;
-            if constexpr (NOFLAT) probe_noflat(w, d, half ? upd_t : upd, a.sh, a.dg, p0, p1);
-            else probe_plain(w, d, half ? upd_t : upd, p0, p1);
-            MH_STAMP(q1);
-            transpose(w, scr, lane);
-            transpose(d, scr, lane);
-            MH_STAMP(q2);
-#ifdef MH_PROFILE_VISIT
-            pf.pass += q1 - q0; pf.tr += q2 - q1;
-#endif
-            if (half == 0) {
-                anyN |= any; topN = p0; botN = p1;
-            } else {
-                // a band's halo rows are frozen here: their owner is the neighbouring band, nobody to re-queue locally
-                anyT |= any; leftT = p0 & rowok; rightT = p1 & rowok;
-            }
-            chg |= any;
+    auto edge = [&](int parity, int wv, int e) { return X + ((parity * 4 + wv) * 4 + e) * WN; };
+    if (MACRO && !has_tile) {  // my published edges never win a min
+        for (int e = 0; e < 4; ++e) {
+            edge(0, wave, e)[lane] = INF;
+            edge(1, wave, e)[lane] = INF;
         }
-        if (chg == 0) {
+    }
+    bool moved = true;   // did my previous cycle change anything?
+#pragma nounroll
+    for (int it = 0; it < (MACRO ? MAXIT : MAXCYC); ++it) {
+        const int cur = it & 1, prev = cur ^ 1;
+        uint64_t chg = 0;
+        // A cycle can only change something if my last cycle did, or if a sibling's edge moved between its last two
+        // publications (parity `cur` still holds the one before last).  The corner cells of the diagonal sibling
+        // arrive through the halo lanes of those edges.
+        bool need = has_tile;
+        if (MACRO && it == 0) need = has_tile && ((flags >> wave) & 1u);   // nobody asked for this tile: its window is consistent
+        if (MACRO && has_tile && it >= 2 && !moved) {
+            const WT *v1 = edge(prev, qi ? wave - 2 : wave + 2, qi ? E_ROW62 : E_ROW1), *v0 = edge(cur, qi ? wave - 2 : wave + 2, qi ? E_ROW62 : E_ROW1);
+            const WT *h1 = edge(prev, qj ? wave - 1 : wave + 1, qj ? E_COL62 : E_COL1), *h0 = edge(cur, qj ? wave - 1 : wave + 1, qj ? E_COL62 : E_COL1);
+            need = __any(v1[lane] != v0[lane] || h1[lane] != h0[lane]) != 0;
+        }
+        if (MACRO) __builtin_amdgcn_s_barrier();   // everybody has compared parity `cur` before anybody overwrites it
+        if (need) {
+            ++ncyc;
+            // the two halves share one copy of the pass code (the unrolled passes are most of the kernel: two copies
+            // overflow the instruction cache, measured +10 % on the f64 kernel)
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
+                // halos that face a sibling: its edge as of the end of the previous iteration (min: never raise a cell);
+                // half 0 = row layout / vertical sibling, half 1 = column layout / horizontal sibling
+                if (MACRO && it > 0) {
+                    const int q = half ? qj : qi, step = half ? 1 : 2;
+                    if (q == 1) {
+                        const WT x = edge(prev, wave - step, half ? E_COL62 : E_ROW62)[lane];
+                        w[0] = x < w[0] ? x : w[0];
+                    } else {
+                        const WT x = edge(prev, wave + step, half ? E_COL1 : E_ROW1)[lane];
+                        w[WN - 1] = x < w[WN - 1] ? x : w[WN - 1];
+                    }
+                }
+                uint64_t any = 0, p0, p1;
+                if constexpr (NOFLAT) {
+                    pass_noflat<true>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, a.sh, a.dg, any);
+                    pass_noflat<false>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, a.sh, a.dg, any);
+                    probe_noflat(w, d, half ? upd_t : upd, a.sh, a.dg, p0, p1);
+                } else {
+                    pass_plain<true>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, any);
+                    pass_plain<false>(w, d, half ? updmask_t : updmask, half ? -1 : frozen, any);
+                    probe_plain(w, d, half ? upd_t : upd, p0, p1);
+                }
+                chg |= any;
+                if (half == 0) {
+                    topN = p0;
+                    botN = p1;
+                } else {
+                    // a band's halo rows are frozen here: their owner is the neighbouring band, nobody to re-queue locally
+                    leftT = p0 & rowok;
+                    rightT = p1 & rowok;
+                    if (MACRO) {
+                        edge(cur, wave, E_COL1)[lane] = w[1];
+                        edge(cur, wave, E_COL62)[lane] = w[TI];
+                    }
+                }
+                transpose(w, scr, lane);
+                transpose(d, scr, lane);
+                if (MACRO && half == 1) {
+                    edge(cur, wave, E_ROW1)[lane] = w[1];
+                    edge(cur, wave, E_ROW62)[lane] = w[TI];
+                }
+            }
+            anyAll |= chg;
+        } else if (MACRO && has_tile) {
+            if (it == 0) {   // not asked for: publish the edges of the window as loaded
+                WT c1, c62;
+                extract_cols(w, scr, lane, c1, c62);
+                edge(cur, wave, E_COL1)[lane] = c1;
+                edge(cur, wave, E_COL62)[lane] = c62;
+                edge(cur, wave, E_ROW1)[lane] = w[1];
+                edge(cur, wave, E_ROW62)[lane] = w[TI];
+            } else {
+                for (int e = 0; e < 4; ++e) edge(cur, wave, e)[lane] = edge(prev, wave, e)[lane];   // unchanged
+            }
+        }
+        moved = chg != 0;
+        // one barrier per iteration: publishes parity `cur`, and nobody writes parity `prev` before everybody read it
+        if (MACRO ? __syncthreads_or(chg != 0) == 0 : chg == 0) {
             capped = false;
             break;
         }
     }
 
-    const bool changed = (anyN | anyT) != 0;
+    const bool changed = anyAll != 0;
     MH_STAMP(tp2);
-    visits += 1;
+    visits += has_tile ? 1 : 0;
     cycles += ncyc;
     // ---- stage-out: interior cells that are not raster border cells (those never move)
-    if (changed || first_round) {
+    if (has_tile && (changed || first_round)) {
         const bool lane_ok = upd && col_in && cc != 0 && cc != Wd - 1;
         typedef WT __attribute__((address_space(1))) *gwsp;
         gwsp wst = (gwsp)(W + ((r0 + 1) * Wd + c0));
@@ -420,7 +532,7 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
             asm volatile("" : "+s"(wst));
         }
     }
-    if (first_round) {
+    if (first_round && has_tile) {
         // raster border cells are written once, straight from dem, wherever they sit in the window (halo included);
         // a band's halo rows get their start value (+inf / seed) until the neighbour's first exchange arrives
 #pragma unroll 2
@@ -440,80 +552,134 @@ __device__ __forceinline__ void visit_tile(const RoundArgs &a, const float *__re
         }
     }
     MH_STAMP(tp3);
-    {
+    if (has_tile) {
         // which neighbours would be lowered by this tile's current state?  (a pure function of the window, so it is
-        // evaluated on every visit: a visit that changed nothing still re-queues a neighbour whose cells lag behind)  N layout masks are indexed by column, T layout by row.
-        // Lane k (k < 9) owns neighbour k, so the returning atomics of all directions are in flight together.
+        // evaluated on every visit: a visit that changed nothing still re-queues a neighbour whose cells lag behind)
+        // N layout masks are indexed by column, T layout by row.
+        // Lane k (k < 9) owns neighbour tile k, so the returning atomics of all directions are in flight together.
         // topN/botN: halo-row cells (bit = column 0..63) that would drop; leftT/rightT: halo-column cells (bit = row).
         // Bits 1..62 belong to the edge neighbour, bits 0 / 63 are the corner cells of the diagonal neighbours.
+        // A neighbour tile inside my own macro tile is a sibling: it has seen my edges unless the exchange was capped.
         const uint64_t INNER = ((1ull << TI) - 1) << 1, C0 = 1ull, C63 = 1ull << (WN - 1);
         const bool top = (topN & INNER) != 0, bot = (botN & INNER) != 0, left = (leftT & INNER) != 0, right = (rightT & INNER) != 0;
         const bool tl = ((topN | leftT) & C0) != 0, tr = (topN & C63) || (rightT & C0);
         const bool bl = (botN & C0) || (leftT & C63), br = ((botN | rightT) & C63) != 0;
         const unsigned bits = (tl ? 1u : 0u) | (top ? 2u : 0u) | (tr ? 4u : 0u) | (left ? 8u : 0u) | (capped ? 16u : 0u) |
                               (right ? 32u : 0u) | (bl ? 64u : 0u) | (bot ? 128u : 0u) | (br ? 256u : 0u);
-        if (lane < 9 && ((bits >> lane) & 1u)) {
+        if (lane < 9) {
             const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
             if (p >= 0 && p < ntr && q >= 0 && q < ntc) {
-                const int t = p * ntc + q, sh = t % NSHARD;
-                if (atomicExch(&a.mark_nxt[t], 1u) == 0u)
+                const int t = MACRO ? (p >> 1) * a.mtc + (q >> 1) : p * ntc + q, sh = t % NSHARD;
+                const bool want = t == macro ? capped : ((bits >> lane) & 1u) != 0;
+                // the mark word carries one bit per tile of the macro tile: which of them has a reason to run
+                if (want && atomicOr(&a.mark_nxt[t], MACRO ? 1u << ((p & 1) * 2 + (q & 1)) : 1u) == 0u)
                     a.list_nxt[(size_t)sh * a.shard_cap + atomicAdd(&a.count_nxt[sh], 1u)] = t;
             }
         }
     }
 #ifdef MH_PROFILE_VISIT
     MH_STAMP(tp4);
-    pf.load += tp1 - tp0; pf.store += tp3 - tp2; pf.push += tp4 - tp3;
+    pf.load += tp1 - tp0; pf.pass += tp2 - tp1; pf.store += tp3 - tp2; pf.push += tp4 - tp3;
 #endif
 }
 
-template <typename WT, bool NOFLAT, int INIT>
+template <typename WT, bool NOFLAT, int INIT, int MT>
 __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundArgs a, const float *__restrict__ dem,
                                                                          const float *__restrict__ seed, WT *__restrict__ W)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ int s_idx, s_macro, s_shard;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform => scalar addressing
     uint32_t *scr = lds + wave * (WN * (WN + 1));
-    const int64_t nt = (int64_t)a.ntr * a.ntc;
-    const int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    WT *X = reinterpret_cast<WT *>(lds + 4 * (WN * (WN + 1)));           // [2][4][4][64] edge exchange
+    const int nmt = a.mtr * a.mtc;
+    const int g = (int)blockIdx.x;
     unsigned visits = 0, cycles = 0;
 #ifdef MH_PROFILE_VISIT
     Prof pf;
     const long long tk0 = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (INIT != INIT_NONE) {
-        // first round: every tile, statically strided (uniform work)
-        const int64_t nwaves = (int64_t)gridDim.x * 4;
-        for (int64_t t = g; t < nt; t += nwaves) visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, t, scr, lane, visits, cycles MH_PROF_PASS);
+    if constexpr (MT == 1) {
+        // single tiles: every wavefront schedules itself
+        const int64_t gw = (int64_t)g * 4 + wave;
+        if constexpr (INIT != INIT_NONE) {
+            const int64_t nwaves = (int64_t)gridDim.x * 4;
+            for (int64_t t = gw; t < nmt; t += nwaves)
+                visit_macro<WT, NOFLAT, INIT, MT>(a, dem, seed, W, (int)t, 1u, scr, X, lane, wave, visits, cycles MH_PROF_PASS);
+        } else {
+            int sh = (int)(gw % NSHARD);
+            for (int pass = 0; pass < 4; ++pass) {
+                const unsigned int n = a.count_cur[sh];
+                for (;;) {
+                    unsigned int i = 0;
+                    if (lane == 0) i = atomicAdd(&a.head[sh], 1u);
+                    i = __builtin_amdgcn_readfirstlane(i);
+                    if (i >= n) break;
+                    const int tile = a.list_cur[(size_t)sh * a.shard_cap + i];
+                    if (lane == 0) a.mark_cur[tile] = 0u;
+                    visit_macro<WT, NOFLAT, INIT, MT>(a, dem, seed, W, tile, 1u, scr, X, lane, wave, visits, cycles MH_PROF_PASS);
+                }
+                bool more = false;
+                if (lane < NSHARD) more = __hip_atomic_load(&a.head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.count_cur[lane];
+                const uint64_t left = __ballot(more);
+                if (!left) break;
+                int want = (int)(gw % __builtin_popcountll(left));   // spread the helpers over the shards that still have work
+                uint64_t mm = left;
+                while (want--) mm &= mm - 1;
+                sh = __builtin_ctzll(mm);
+            }
+        }
+    } else if constexpr (INIT != INIT_NONE) {
+        // first round: every macro tile, statically strided (uniform work)
+        for (int t = g; t < nmt; t += (int)gridDim.x) {
+            visit_macro<WT, NOFLAT, INIT, MT>(a, dem, seed, W, t, 0xfu, scr, X, lane, wave, visits, cycles MH_PROF_PASS);
+            __syncthreads();   // the exchange area is reused by the next visit
+        }
     } else {
         // own shard first; then one vector look at all (head, count) pairs picks the shards that still hold work
-        // (a stale head only costs one wasted pop), so an idle wave leaves after ~2 memory round trips
-        int sh = (int)(g % NSHARD);
+        // (a stale head only costs one wasted pop), so an idle block leaves after ~2 memory round trips
+        int sh = g % NSHARD;
         for (int pass = 0; pass < 4; ++pass) {
             const unsigned int n = a.count_cur[sh];
             for (;;) {
-                unsigned int i = 0;
-                if (lane == 0) i = atomicAdd(&a.head[sh], 1u);
-                i = __builtin_amdgcn_readfirstlane(i);
-                if (i >= n) break;
-                const int tile = a.list_cur[(size_t)sh * a.shard_cap + i];
-                if (lane == 0) a.mark_cur[tile] = 0u;
-                visit_tile<WT, NOFLAT, INIT>(a, dem, seed, W, tile, scr, lane, visits, cycles MH_PROF_PASS);
+                if (threadIdx.x == 0) {
+                    const unsigned int i = atomicAdd(&a.head[sh], 1u);
+                    int m = -1;
+                    if (i < n) {
+                        m = a.list_cur[(size_t)sh * a.shard_cap + i];
+                        s_idx = (int)a.mark_cur[m];   // nobody else touches this round's marks
+                        a.mark_cur[m] = 0u;
+                    }
+                    s_macro = m;
+                }
+                __syncthreads();
+                const int m = s_macro;
+                if (m < 0) break;
+                visit_macro<WT, NOFLAT, INIT, MT>(a, dem, seed, W, m, (unsigned)s_idx, scr, X, lane, wave, visits, cycles MH_PROF_PASS);
+                __syncthreads();   // s_macro and the exchange area are reused
             }
-            bool more = false;
-            if (lane < NSHARD) more = __hip_atomic_load(&a.head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.count_cur[lane];
-            const uint64_t left = __ballot(more);
-            if (!left) break;
-            // spread the helpers: pick the (g mod popcount)-th shard that still has work
-            int want = (int)(g % __builtin_popcountll(left));
-            uint64_t m = left;
-            while (want--) m &= m - 1;
-            sh = __builtin_ctzll(m);
+            if (wave == 0) {
+                bool more = false;
+                if (lane < NSHARD) more = __hip_atomic_load(&a.head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.count_cur[lane];
+                const uint64_t left = __ballot(more);
+                int nxt = -1;
+                if (left) {  // spread the helpers: pick the (g mod popcount)-th shard that still has work
+                    int want = g % __builtin_popcountll(left);
+                    uint64_t mm = left;
+                    while (want--) mm &= mm - 1;
+                    nxt = __builtin_ctzll(mm);
+                }
+                if (lane == 0) s_shard = nxt;
+            }
+            __syncthreads();
+            sh = s_shard;
+            __syncthreads();
+            if (sh < 0) break;
         }
     }
     if (lane == 0 && visits) {
-        unsigned long long *sh = a.stats + 2 * (g & 63);
+        unsigned long long *sh = a.stats + 2 * ((g * 4 + wave) & 63);
         atomicAdd(&sh[0], (unsigned long long)visits);
         atomicAdd(&sh[1], (unsigned long long)cycles);
 #ifdef MH_PROFILE_VISIT
@@ -535,13 +701,13 @@ template <typename WT> __global__ void copy_dem_kernel(const float *dem, WT *out
 constexpr int MAX_ROUNDS = 1 << 15;
 constexpr int BATCH = 8;
 
-// marks every tile of tile-row `ti` active for the round that is launched next (band mode: a halo row changed)
+// marks every macro tile of macro row `ti` active for the round that is launched next (band mode: a halo row changed)
 __global__ void activate_tile_row_kernel(int ti, int ntc, int shard_cap, int *list, unsigned int *mark, unsigned int *count)
 {
     const int tj = blockIdx.x * blockDim.x + threadIdx.x;
     if (tj >= ntc) return;
     const int t = ti * ntc + tj, sh = t % NSHARD;
-    if (atomicExch(&mark[t], 1u) == 0u) list[(size_t)sh * shard_cap + atomicAdd(&count[sh], 1u)] = t;
+    if (atomicExch(&mark[t], 0xfu) == 0u) list[(size_t)sh * shard_cap + atomicAdd(&count[sh], 1u)] = t;
 }
 
 }  // namespace
@@ -552,8 +718,9 @@ struct FillRun::Impl {
     int *lists = nullptr;
     unsigned int *marks = nullptr, *count = nullptr, *head = nullptr;
     unsigned long long *d_stats = nullptr;
-    int ntr = 0, ntc = 0, shard_cap = 0, round = 0, rounds_used = 0;
-    int64_t nt = 0;
+    int ntr = 0, ntc = 0, mtr = 0, mtc = 0, shard_cap = 0, round = 0, rounds_used = 0;
+    int64_t nt = 0;    // macro tiles (the scheduling unit)
+    int64_t ntiles = 0;
     size_t list_elems = 0;
     bool trivial = false;  // no interior cell
 };
@@ -565,11 +732,12 @@ template <typename WT, bool NOFLAT>
 static int fill_launch(FillRun &f, int round, int init, hipStream_t s)
 {
     FillRun::Impl &m = *f.impl;
-    const size_t lds = 4 * WN * (WN + 1) * sizeof(uint32_t);
+    constexpr int MT = NOFLAT ? 1 : 2;
+    const size_t lds = 4 * WN * (WN + 1) * sizeof(uint32_t) + (MT == 2 ? 2 * 4 * 4 * WN * sizeof(WT) : 0);   // transposes + edge exchange
     const int resident_blocks = 256 * (NOFLAT ? 1 : 2);  // as many blocks as the chip holds at this kernel's occupancy
-    auto k_none = fill_round_kernel<WT, NOFLAT, INIT_NONE>;
-    auto k_inf = fill_round_kernel<WT, NOFLAT, INIT_INF>;
-    auto k_seed = fill_round_kernel<WT, NOFLAT, NOFLAT ? INIT_SEED : INIT_INF>;
+    auto k_none = fill_round_kernel<WT, NOFLAT, INIT_NONE, MT>;
+    auto k_inf = fill_round_kernel<WT, NOFLAT, INIT_INF, MT>;
+    auto k_seed = fill_round_kernel<WT, NOFLAT, NOFLAT ? INIT_SEED : INIT_INF, MT>;
     static bool attr_done = false;
     if (!attr_done) {
         MH_HIP(hipFuncSetAttribute((const void *)k_none, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -578,14 +746,14 @@ static int fill_launch(FillRun &f, int round, int init, hipStream_t s)
         attr_done = true;
     }
     RoundArgs a;
-    a.H = f.H; a.Wd = f.W; a.ntr = m.ntr; a.ntc = m.ntc; a.shard_cap = m.shard_cap;
+    a.H = f.H; a.Wd = f.W; a.ntr = m.ntr; a.ntc = m.ntc; a.mtr = m.mtr; a.mtc = m.mtc; a.shard_cap = m.shard_cap;
     a.list_cur = m.lists + (size_t)(round & 1) * m.list_elems; a.list_nxt = m.lists + (size_t)((round + 1) & 1) * m.list_elems;
     a.mark_cur = m.marks + (size_t)(round & 1) * m.nt; a.mark_nxt = m.marks + (size_t)((round + 1) & 1) * m.nt;
     a.count_cur = m.count + (size_t)round * NSHARD; a.count_nxt = m.count + (size_t)(round + 1) * NSHARD;
     a.head = m.head + (size_t)round * NSHARD;
     a.sh = f.sh; a.dg = f.dg; a.seed_add = f.seed_add; a.stats = m.d_stats;
     a.fixed_top = f.fixed_top; a.fixed_bot = f.fixed_bot;
-    const int64_t want = cdiv(m.nt, 4);
+    const int64_t want = MT == 2 ? m.nt : cdiv(m.nt, 4);
     const unsigned grid = (unsigned)(want < resident_blocks ? want : resident_blocks);
     auto kern = init == INIT_NONE ? k_none : (init == INIT_SEED ? k_seed : k_inf);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, f.dem, f.seed ? f.seed : f.dem, reinterpret_cast<WT *>(f.out));
@@ -614,7 +782,11 @@ int FillRun::begin(hipStream_t s, bool *active)
     }
     m.ntr = (int)cdiv(H - 2, TI);
     m.ntc = (int)cdiv(W - 2, TI);
-    m.nt = (int64_t)m.ntr * m.ntc;
+    const int mt = noflat ? 1 : 2;   // scheduling unit: single tiles for the f64 kernel (fill_launch)
+    m.mtr = (m.ntr + mt - 1) / mt;
+    m.mtc = (m.ntc + mt - 1) / mt;
+    m.ntiles = (int64_t)m.ntr * m.ntc;
+    m.nt = (int64_t)m.mtr * m.mtc;
     // workspace: lists[2][NSHARD][cap] | marks[2][nt] | count[MAX_ROUNDS+1][NSHARD] | head[MAX_ROUNDS+1][NSHARD] | stats[64][2]
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     m.shard_cap = (int)cdiv(m.nt, NSHARD) + 1;
@@ -678,8 +850,8 @@ int FillRun::activate_row(int side, hipStream_t s)
 {
     Impl &m = *impl;
     if (m.trivial) return MHIP_OK;
-    const int ti = side == 0 ? 0 : m.ntr - 1;
-    hipLaunchKernelGGL(activate_tile_row_kernel, dim3((unsigned)cdiv(m.ntc, 256)), dim3(256), 0, s, ti, m.ntc, m.shard_cap,
+    const int ti = side == 0 ? 0 : m.mtr - 1;
+    hipLaunchKernelGGL(activate_tile_row_kernel, dim3((unsigned)cdiv(m.mtc, 256)), dim3(256), 0, s, ti, m.mtc, m.shard_cap,
                        m.lists + (size_t)(m.round & 1) * m.list_elems, m.marks + (size_t)(m.round & 1) * m.nt,
                        m.count + (size_t)m.round * NSHARD);
     MH_HIP(hipGetLastError());
@@ -722,7 +894,7 @@ int FillRun::finish(hipStream_t s, FillStats *st)
                 st->visits += (int64_t)h_stats[2 * k];
                 st->cycles += (int64_t)h_stats[2 * k + 1];
             }
-            st->tiles = m.nt;
+            st->tiles = m.ntiles;
         }
     }
     m.ws.release();

@@ -64,22 +64,27 @@ __global__ __launch_bounds__(256) void ws_init_kernel(const uint8_t *__restrict_
 
 // One launch performs up to HOPS pointer jumps per cell (P[i] <- P[P[i]] repeatedly): the raster is read once per launch
 // while the path length covered grows by 2**HOPS.  Racing updates are benign: every value a thread can observe in
-// P[] / Q[] is a cell further down the same flow path (or the final terminal).
-constexpr int HOPS = 3;
+// P[] / Q[] is a cell further down the same flow path (or the final terminal).  A cell whose pointer has reached a
+// labelled cell stores it with the DONE bit: later launches then cost one coalesced read for it, no gather.
+constexpr int HOPS = 4;
+constexpr int32_t DONE = (int32_t)0x80000000;
 __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, int64_t n, unsigned int *changed)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool ch = false;
     int32_t t = P[i];
-    if (t != NONE && t != (int32_t)i) {
+    if (t >= 0 && t != NONE && t != (int32_t)i) {
         const int32_t t0 = t;
 #pragma unroll
         for (int h = 0; h < HOPS; ++h) {
-            if (t == NONE) break;
             const int32_t pt = P[t];
-            if (pt == t) break;  // t is a labelled fixed point: resolved
-            t = pt;              // skip over t
+            if (pt == t) {  // t is a labelled fixed point: resolved
+                t |= DONE;
+                break;
+            }
+            t = pt;         // skip over t (pt may be NONE, or already carry DONE)
+            if (t < 0 || t == NONE) break;
         }
         if (t != t0) {
             P[i] = t;
@@ -109,9 +114,9 @@ __global__ __launch_bounds__(256) void ws_assign_kernel(const int32_t *__restric
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int32_t t = P[i];
-    if (t == (int32_t)i || t == NONE) return;  // labelled cell, or flows out unlabelled
-    if (P[t] != t) return;                     // never resolved: flow cycle
+    const int32_t p = P[i];
+    if (p >= 0) return;                        // labelled cell, flows out unlabelled, or never resolved (flow cycle)
+    const int32_t t = p & ~DONE;
     if (Q && !(Q[t] & QFLAG)) return;          // labelled terminal whose path never meets an edge cell
     lab[i] = lab[t];                           // lab[t] is an input label: labelled cells are never written
 }
@@ -158,9 +163,9 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     const unsigned grid = (unsigned)cdiv(n, 256);
     DevBuf P, Q, flags;
     MH_TRY(P.alloc(4 * (size_t)n));
-    MH_TRY(flags.alloc(sizeof(unsigned int) * 2));
-    MH_HIP(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 2, s));
-    unsigned int *d_cnt = flags.as<unsigned int>(), *d_changed = d_cnt + 1;
+    MH_TRY(flags.alloc(sizeof(unsigned int) * 4));
+    MH_HIP(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, s));
+    unsigned int *d_cnt = flags.as<unsigned int>(), *d_changed = d_cnt + 2;
     hipLaunchKernelGGL(ws_count_interior_nodir, dim3(grid), dim3(256), 0, s, d_fd, H, W, d_cnt);
     unsigned int interior_nodir = 0;
     MH_HIP(hipMemcpyAsync(&interior_nodir, d_cnt, 4, hipMemcpyDeviceToHost, s));
@@ -175,15 +180,16 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
         q = Q.as<uint32_t>();
     }
     hipLaunchKernelGGL(ws_init_kernel, dim3(grid), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), q, H, W, unassigned);
-    constexpr int MAX_ROUNDS = 40, CHECK_EVERY = 2;   // 40 launches x 3 hops each: paths up to 2**120 cells
-    for (int round = 0; round < MAX_ROUNDS; round += CHECK_EVERY) {
-        MH_HIP(hipMemsetAsync(d_changed, 0, 4, s));
-        for (int k = 0; k < CHECK_EVERY; ++k)
-            hipLaunchKernelGGL(ws_jump_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, n, d_changed);
-        unsigned int h = 0;
-        MH_HIP(hipMemcpyAsync(&h, d_changed, 4, hipMemcpyDeviceToHost, s));
+    // launches come in pairs with one flag each: the pair is the last one as soon as its SECOND launch changed nothing
+    constexpr int MAX_ROUNDS = 40;   // 40 launches x 4 hops each: paths up to 2**160 cells
+    for (int round = 0; round < MAX_ROUNDS; round += 2) {
+        MH_HIP(hipMemsetAsync(d_changed, 0, 8, s));
+        for (int k = 0; k < 2; ++k)
+            hipLaunchKernelGGL(ws_jump_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, n, d_changed + k);
+        unsigned int h[2] = {0, 0};
+        MH_HIP(hipMemcpyAsync(h, d_changed, 8, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
-        if (!h) break;
+        if (!h[1]) break;
     }
     hipLaunchKernelGGL(ws_assign_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, d_labels, n, unassigned);
     MH_HIP(hipGetLastError());

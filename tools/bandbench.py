@@ -1,0 +1,37 @@
+"""Time the band chain on ONE GPU (development helper): `nbands` bands of size x size each, stacked to a
+(nbands*size) x size DEM, driven by threads over ThreadComm.  The bands share the GPU, so the wall time is roughly
+nbands x (one band's time) + protocol overhead; compare with nbands x the single-raster chain.
+    python tools/bandbench.py --size 8192 --bands 2"""
+import argparse, sys, threading, time
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import numpy as np
+from _cases import fbm
+from malstroem_amd.distributed import BandPipeline, ThreadComm
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=8192)
+ap.add_argument("--bands", type=int, default=2)
+ap.add_argument("--reps", type=int, default=2)
+args = ap.parse_args()
+tile = fbm(args.size, beta=2.0)
+dem = np.concatenate([tile if k % 2 == 0 else tile[::-1] for k in range(args.bands)])
+res = {}
+
+def work(comm):
+    p = BandPipeline(comm, dem.shape, device=0)
+    p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+    for rep in range(args.reps):
+        t = {}
+        for name, fn in (("fill", p.fill), ("noflat", p.noflat), ("flowdir", p.flowdir), ("accum", p.accum), ("label", p.label), ("watershed", p.watershed)):
+            t0 = time.perf_counter()
+            fn()
+            t[name] = round((time.perf_counter() - t0) * 1e3, 1)
+        t["total"] = round(sum(t.values()), 1)
+        t["exchanges"] = dict(p.exchanges)
+        res[(comm.rank, rep)] = t
+    p.close()
+
+ts = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(args.bands)]
+[t.start() for t in ts]; [t.join() for t in ts]
+for k in sorted(res):
+    print(k, res[k])

@@ -298,6 +298,70 @@ __global__ __launch_bounds__(256) void arg_pass2_kernel(const double *__restrict
     if (k == key[l] && (unsigned long long)i < idx[l]) atomicMin(&idx[l], (unsigned long long)i);
 }
 
+// ---- single-pass arg-max for integer-valued data (accumulated flow: the pour points, bluespots.py:195-206) -----------
+// value and position share one 64-bit key, (value << 32) | (0xffffffff - index): the largest key is the largest value at
+// its FIRST raster position, so one atomicMax per run replaces the two passes above.  Needs 0 <= value < 2**32 integral
+// and fewer than 2**32 - 1 cells; a cell that does not qualify raises `notint` and the caller falls back to the two passes.
+__global__ __launch_bounds__(256) void arg_packed_kernel(const double *__restrict__ data, const int32_t *__restrict__ lab,
+                                                        int64_t n, int64_t nlab, uint64_t *key, unsigned int *bad,
+                                                        unsigned int *notint)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t bkey = 0;  // background (label 0), kept in registers
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nloop = cdiv(n, stride) * stride;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
+        const bool valid = i < n;
+        int32_t l = valid ? lab[i] : -1;
+        if (valid && (l < 0 || l > nlab)) {
+            atomicOr(bad, 1u);
+            l = -1;
+        }
+        const double v = valid ? data[i] : 0.0;
+        const bool isint = v >= 0.0 && v < 4294967296.0 && (double)(uint32_t)v == v;   // false for NaN
+        if (valid && !isint) atomicOr(notint, 1u);
+        uint64_t k = ((uint64_t)(uint32_t)v << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+        if (__all(l <= 0)) {
+            if (l == 0) bkey = k > bkey ? k : bkey;
+            continue;
+        }
+        const bool ok = l >= 0;
+        const int len = run_length_from(l, lane, ok);
+        const bool head = is_run_head(l, lane, ok);
+        k = seg_reduce(k, len, [](uint64_t x, uint64_t y) { return x > y ? x : y; });
+        if (head && ok) {
+            if (l == 0) bkey = k > bkey ? k : bkey;
+            else if (k > key[l]) atomicMax(reinterpret_cast<unsigned long long *>(&key[l]), (unsigned long long)k);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t ob = __shfl_xor(bkey, o);
+        bkey = ob > bkey ? ob : bkey;
+    }
+    if (lane == 0 && bkey) atomicMax(reinterpret_cast<unsigned long long *>(&key[0]), (unsigned long long)bkey);
+}
+
+__global__ __launch_bounds__(256) void arg_packed_finish_kernel(const double *__restrict__ data, const uint64_t *__restrict__ key,
+                                                               int64_t nrec, int64_t W, mhip_index_record *rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    mhip_index_record r;
+    const uint64_t k = key[i];
+    if (k == 0) {  // no cell: a real key never is 0 (its low word is 0xffffffff - index > 0)
+        r.value = -__builtin_inf();
+        r.row = -1;
+        r.col = -1;
+    } else {
+        const uint64_t p = 0xffffffffu - (uint32_t)k;
+        r.value = data[p];
+        r.row = (int64_t)(p / (uint64_t)W);
+        r.col = (int64_t)(p % (uint64_t)W);
+    }
+    rec[i] = r;
+}
+
 __global__ __launch_bounds__(256) void arg_finish_kernel(const double *__restrict__ data, const unsigned long long *idx,
                                                         int64_t nrec, int64_t W, bool is_max, mhip_index_record *rec)
 {
@@ -461,6 +525,21 @@ int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int6
     MH_TRY(bad.alloc(4));
     MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
     const unsigned gr = (unsigned)cdiv(nrec, 256), gn = (unsigned)cdiv(n, 256);
+    if (is_max && n < 0xffffffffll) {
+        // integer-valued data (accumulated flow): value and position in one key, one pass; anything else falls through
+        DevBuf ni;
+        MH_TRY(ni.alloc(4));
+        MH_HIP(hipMemsetAsync(ni.p, 0, 4, s));
+        MH_HIP(hipMemsetAsync(key.p, 0, 8 * (size_t)nrec, s));
+        hipLaunchKernelGGL(arg_packed_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_data, d_labels, n, nlab, key.as<uint64_t>(),
+                           bad.as<unsigned int>(), ni.as<unsigned int>());
+        hipLaunchKernelGGL(arg_packed_finish_kernel, dim3(gr), dim3(256), 0, s, d_data, key.as<uint64_t>(), nrec, W, d_rec);
+        MH_HIP(hipGetLastError());
+        unsigned int h_ni = 0;
+        MH_HIP(hipMemcpyAsync(&h_ni, ni.p, 4, hipMemcpyDeviceToHost, s));
+        MH_TRY(check_bad(bad, s, "label_max_index"));   // synchronises the stream
+        if (!h_ni) return MHIP_OK;
+    }
     hipLaunchKernelGGL(arg_init_kernel, dim3(gr), dim3(256), 0, s, key.as<uint64_t>(), idx.as<unsigned long long>(), nrec, is_max);
     hipLaunchKernelGGL(arg_pass1_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_data, d_labels, n, nlab, key.as<uint64_t>(), is_max,
                        bad.as<unsigned int>());

@@ -65,22 +65,25 @@ def fbm(n, beta=2.0, seed=42):
 
 
 def pmc_traffic(stage, n):
-    """HBM bytes of the stage's kernels from the committed rocprofv3 PMC passes (profiles/r01c_pmc_hbm_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2; FETCH_SIZE doubled for the 16-byte-per-lane
-    streaming reads of d8 as MI355X_MICROARCH.md prescribes, left as reported for the 4-byte tile loads of the fills)."""
-    path = ROOT / "profiles" / "r01c_pmc_hbm_traffic.json"
-    if n != 16384 or not path.exists():
+    """HBM bytes of the stage's kernels from the newest committed rocprofv3 PMC table (profiles/*_pmc_hbm_traffic.json,
+    made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2; FETCH_SIZE doubled for
+    the 16-byte-per-lane streaming reads of d8 / depths as MI355X_MICROARCH.md prescribes, left as reported for the
+    4-byte tile loads of the fills)."""
+    tables = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
+    if n != 16384 or not tables:
         return None
-    kernels = {"flowdir": ("d8_kernel", 2.0), "fill": ("fill_round_kernel<float", 1.0), "noflat": ("fill_round_kernel<double", 1.0),
-               "accum": ("accum_", 1.0), "label": ("ccl_", 1.0), "watershed": ("ws_", 1.0)}
+    path = tables[-1]
+    kernels = {"flowdir": (("d8_kernel",), 2.0), "fill": (("fill_round_kernel<float",), 1.0),
+               "noflat": (("fill_round_kernel<double",), 1.0), "accum": (("accum_",), 1.0), "label": (("ccl_", "stats_"), 1.0),
+               "watershed": (("ws_", "count_kernel"), 1.0), "pourpoints": (("arg_",), 1.0)}
     if stage not in kernels:
         return None
-    prefix, fcorr = kernels[stage]
+    prefixes, fcorr = kernels[stage]
     tot = 0.0
     for row in json.loads(path.read_text()):
-        if row["kernel"].startswith(prefix):
+        if row["kernel"].startswith(prefixes):
             tot += (row["fetch_size_kb"] * fcorr + row["write_size_kb"]) * 1024.0
-    return {"hbm_bytes_per_stage": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "source": "profiles/r01c_pmc_hbm_traffic.json"}
+    return {"hbm_bytes_per_stage": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "source": "profiles/" + path.name}
 
 
 def cpu_baseline(dem, sample):

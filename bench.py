@@ -146,10 +146,16 @@ def main():
     band = None
     if world > 1:
         try:
-            from malstroem_amd.distributed import BandPipeline, TorchComm
-            band = BandPipeline(TorchComm(), (n * world, n), device=device)
+            from malstroem_amd.distributed import BandPipeline, RcclComm, TorchComm
+            # halo rows GPU -> GPU over RCCL when it passes its self test on every rank, else host-staged gloo
+            transport = os.environ.get("MALSTROEM_BAND_TRANSPORT", "auto")
+            if world > ndev:
+                transport = "gloo"   # ranks share a GPU (rehearsal on a small box): RCCL wants one device per rank
+            comm = TorchComm() if transport == "gloo" else RcclComm.create(device)
+            band = BandPipeline(comm, (n * world, n), device=device)
             band.upload_dem(dem if rank % 2 == 0 else dem[::-1])
-            parallelism = "row bands of one %dx%d DEM over %d GPUs, halo rows host-staged over gloo" % (n * world, n, world)
+            parallelism = "row bands of one %dx%d DEM over %d GPUs, halo rows %s" % (
+                n * world, n, world, "GPU->GPU over RCCL send/recv" if getattr(comm, "device_rows", False) else "host-staged over gloo")
             stage_names = ["fill", "noflat", "flowdir", "accum", "label", "watershed"]
         except Exception as e:  # pragma: no cover - only on a multi-GPU node
             band = None

@@ -131,13 +131,17 @@ int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t ro
                          int device, int rank, int nranks, const void *nccl_unique_id);
 int mhip_ctx_destroy(mhip_ctx *ctx);
 /* ---- row-band protocol.  A band context holds its owned rows plus one halo row per neighbour (a copy of
- * the neighbouring band's edge row).  The host launcher moves edge rows between neighbours (today through host
- * buffers + torch.distributed/gloo or any other transport; the RCCL device transport is not built in yet) and drives
+ * the neighbouring band's edge row).  The host launcher moves edge rows between neighbours (through host
+ * buffers + torch.distributed/gloo, or device buffers + RCCL send/recv: the *_dev variants below) and drives
  * the fills to a GLOBAL fixed point: begin -> { batch; exchange edge rows; halo_changed } until no band is active. */
 int mhip_ctx_band_info(mhip_ctx *ctx, int64_t *row_off, int64_t *rows_local, int32_t *halo_top, int32_t *halo_bottom);
 int mhip_ctx_get_edge_row(mhip_ctx *ctx, int which, int side, void *host);   /* side 0: first owned row, 1: last owned row,
                                                                                 2: top halo row, 3: bottom halo row */
 int mhip_ctx_set_halo_row(mhip_ctx *ctx, int which, int side, const void *host, int32_t *changed); /* 0: top halo, 1: bottom */
+/* the same with DEVICE buffers of the caller (W * element size bytes on the context's GPU): the launcher hands them to
+ * RCCL send/recv (torch.distributed "nccl" backend) so halo rows travel GPU -> GPU over xGMI without a host copy */
+int mhip_ctx_get_edge_row_dev(mhip_ctx *ctx, int which, int side, void *dev_dst);
+int mhip_ctx_set_halo_row_dev(mhip_ctx *ctx, int which, int side, const void *dev_src, int32_t *changed);
 int mhip_ctx_dem_minmax(mhip_ctx *ctx, float *mn, float *mx, int32_t *has_nan);   /* owned rows only */
 /* kind 0: fill.fill_terrain, kind 1: fill.fill_terrain_no_flats (short/diag from the GLOBAL dem extremes) */
 int mhip_ctx_fill_begin(mhip_ctx *ctx, int kind, double short_, double diag, int32_t *active);

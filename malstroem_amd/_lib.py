@@ -36,7 +36,8 @@ SYMBOLS = [
     "mhip_ctx_upload", "mhip_ctx_download", "mhip_ctx_run", "mhip_ctx_sync", "mhip_ctx_stage_ms",
     "mhip_ctx_kernel_ms", "mhip_ctx_get_i64", "mhip_ctx_get_f64", "mhip_ctx_raw_stats", "mhip_ctx_apply_keep",
     "mhip_ctx_stats", "mhip_ctx_watershed_counts", "mhip_ctx_pourpoints",
-    "mhip_ctx_band_info", "mhip_ctx_get_edge_row", "mhip_ctx_set_halo_row", "mhip_ctx_dem_minmax",
+    "mhip_ctx_band_info", "mhip_ctx_get_edge_row", "mhip_ctx_set_halo_row", "mhip_ctx_get_edge_row_dev",
+    "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_end",
     "mhip_ctx_zero_raster", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_watershed_local",
     "mhip_ctx_band_apply_neg_lut",

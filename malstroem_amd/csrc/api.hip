@@ -549,6 +549,34 @@ int mhip_ctx_set_halo_row(mhip_ctx *c, int which, int side, const void *host, in
     return MHIP_OK;
 }
 
+// the same two calls for a transport that moves DEVICE buffers (RCCL send/recv on tensors of the launcher)
+int mhip_ctx_get_edge_row_dev(mhip_ctx *c, int which, int side, void *dev_dst)
+{
+    MH_ARG(c && dev_dst && which >= 0 && which < MHIP_R_COUNT_ && side >= 0 && side <= 3, "ctx_get_edge_row_dev(ctx, which, side, dev)");
+    MH_ARG(c->r[which].p, "raster has not been computed or uploaded");
+    MH_ARG(side < 2 || (side == 2 ? c->ht : c->hb), "this band has no halo row on that side");
+    MH_HIP(hipSetDevice(c->device));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    const int64_t row = side == 0 ? c->ht : side == 1 ? c->ht + c->H_owned - 1 : side == 2 ? 0 : c->H - 1;
+    MH_HIP(hipMemcpyAsync(dev_dst, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToDevice, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));   // the transport reads the buffer on its own stream
+    return MHIP_OK;
+}
+
+int mhip_ctx_set_halo_row_dev(mhip_ctx *c, int which, int side, const void *dev_src, int32_t *changed)
+{
+    MH_ARG(c && dev_src && which >= 0 && which < MHIP_R_COUNT_ && (side == 0 || side == 1), "ctx_set_halo_row_dev(ctx, which, side, dev)");
+    MH_ARG(side == 0 ? c->ht : c->hb, "this band has no halo row on that side");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, which));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    const int64_t row = side == 0 ? 0 : c->H - 1;
+    int ch = 0;
+    MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, dev_src, (int64_t)rowb, &ch, c->stream));
+    if (changed) *changed = ch;
+    return MHIP_OK;
+}
+
 int mhip_ctx_zero_raster(mhip_ctx *c, int which)
 {
     MH_ARG(c && which >= 0 && which < MHIP_R_COUNT_, "ctx_zero_raster(ctx, which)");

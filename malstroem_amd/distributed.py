@@ -149,6 +149,105 @@ class TorchComm(Comm):
         return out
 
 
+class RcclComm(TorchComm):
+    """Halo rows travel GPU -> GPU over RCCL (``torch.distributed`` backend "nccl" IS RCCL on ROCm; band neighbours are
+    xGMI peers): the band copies its edge rows into small device tensors, one ``batch_isend_irecv`` per exchange moves
+    them, the band reads its halo rows back from device tensors -- no host staging.  The Python-object collectives of the
+    labelling / watershed protocols (a few rows per band) and the one-float all-reduce stay on the host group (gloo).
+
+    ``RcclComm.create(device)`` builds the extra process group and runs a self test (every rank sends a pattern to its
+    neighbours and checks what it receives); any failure on any rank makes ALL ranks fall back to ``TorchComm``."""
+
+    device_rows = True
+
+    def __init__(self, device, group=None, timeout_s=120, backend="nccl"):
+        """``backend="gloo"`` with ``device="cpu"`` runs the same protocol on host tensors (CPU tests of this class)."""
+        super(RcclComm, self).__init__(group)
+        import datetime
+        torch, dist = self._torch, self._dist
+        if backend == "nccl":
+            if not torch.cuda.is_available():
+                # torch bundles its own HIP runtime: it must be imported BEFORE libmalstroem_hip is loaded, then both share it
+                raise RuntimeError("torch sees no GPU (import torch before the first malstroem_amd call in this process)")
+            torch.cuda.set_device(int(device))
+            self.device = torch.device("cuda", int(device))
+        else:
+            self.device = torch.device("cpu")
+        self._pg = dist.new_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
+        self._bufs = {}
+
+    @classmethod
+    def create(cls, device, group=None, backend="nccl"):
+        """-> RcclComm, or a plain TorchComm when RCCL is unusable here (decided collectively)."""
+        host = TorchComm(group)
+        ok, comm, why = 1.0, None, ""
+        try:
+            comm = cls(device, group, backend=backend)
+            comm.self_test()
+        except Exception as e:  # any rank's failure is everybody's fallback
+            ok, why = 0.0, "%s: %s" % (type(e).__name__, e)
+        if host.allreduce_max(1.0 - ok) > 0.0:
+            if why and host.rank == 0:
+                import warnings
+                warnings.warn("RCCL halo transport unavailable (%s): using host-staged gloo" % why[:200], RuntimeWarning)
+            return host
+        return comm
+
+    def _pair(self, nbytes, key):
+        b = self._bufs.get((key, nbytes))
+        if b is None:
+            torch = self._torch
+            b = (torch.empty(nbytes, dtype=torch.uint8, device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+            self._bufs[(key, nbytes)] = b
+        return b
+
+    def exchange_device_rows(self, nbytes, fill_send, take_recv):
+        """``fill_send(side, ptr)`` writes my edge row for neighbour ``side`` (0 up, 1 down) to device address ``ptr``;
+        ``take_recv(side, ptr)`` consumes the row that arrived from that neighbour.  Returns take_recv's results."""
+        torch, dist = self._torch, self._dist
+        ops, sides = [], []
+        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
+            if 0 <= peer < self.size:
+                snd, rcv = self._pair(nbytes, side)
+                fill_send(side, snd.data_ptr())      # synchronous on the band's stream: the row is in `snd` on return
+                ops += [dist.P2POp(dist.isend, snd, peer, self._pg), dist.P2POp(dist.irecv, rcv, peer, self._pg)]
+                sides.append((side, rcv))
+        out = {0: False, 1: False}
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)  # RCCL ran on torch's stream; the band reads on its own
+            for side, rcv in sides:
+                out[side] = take_recv(side, rcv.data_ptr())
+        return out[0], out[1]
+
+    def self_test(self):
+        torch = self._torch
+        n = 4096
+        got = {}
+
+        def fill(side, ptr):
+            snd, _ = self._pair(n, side)
+            snd.fill_((self.rank * 2 + side) % 251)
+
+        def take(side, ptr):
+            _, rcv = self._pair(n, side)
+            got[side] = int(rcv[0].item()), bool((rcv == rcv[0]).all().item())
+            return True
+
+        self.exchange_device_rows(n, fill, take)
+        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
+            if 0 <= peer < self.size:
+                want = (peer * 2 + (1 - side)) % 251    # the neighbour's row for MY direction
+                if got.get(side) != (want, True):
+                    raise RuntimeError("RCCL self test: rank %d side %d received %r, expected %d" % (self.rank, side, got.get(side), want))
+        t = torch.ones(1, device=self.device)
+        self._dist.all_reduce(t, group=self._pg)
+        if int(t.item()) != self.size:
+            raise RuntimeError("RCCL self test: all_reduce returned %r" % (t.item(),))
+
+
 # ---- compute backend: one band context on one GPU -----------------------------------------------------------------
 
 class HipBand(object):
@@ -189,6 +288,19 @@ class HipBand(object):
         a = np.ascontiguousarray(row, dtype=RASTER_DTYPE[which])
         changed = ctypes.c_int32(0)
         _lib.call("mhip_ctx_set_halo_row", self._ctx, which, int(side), _lib.ptr(a), ctypes.byref(changed))
+        return bool(changed.value)
+
+    def row_bytes(self, name):
+        return self.W * np.dtype(RASTER_DTYPE[RASTERS[name]]).itemsize
+
+    def get_edge_row_dev(self, name, side, dev_ptr):
+        """Copy an edge row into a DEVICE buffer of the caller (W * itemsize bytes on this band's GPU)."""
+        _lib.call("mhip_ctx_get_edge_row_dev", self._ctx, RASTERS[name], int(side), ctypes.c_void_p(int(dev_ptr)))
+
+    def set_halo_row_dev(self, name, side, dev_ptr):
+        changed = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_set_halo_row_dev", self._ctx, RASTERS[name], int(side), ctypes.c_void_p(int(dev_ptr)),
+                  ctypes.byref(changed))
         return bool(changed.value)
 
     def dem_minmax(self):
@@ -268,6 +380,9 @@ class BandPipeline(object):
     def _swap_edges(self, name):
         """Neighbours trade edge rows of raster ``name``; returns which of my halo rows changed (top, bottom)."""
         b = self.band
+        if getattr(self.comm, "device_rows", False) and hasattr(b, "get_edge_row_dev"):
+            return self.comm.exchange_device_rows(b.row_bytes(name), lambda side, ptr: b.get_edge_row_dev(name, side, ptr),
+                                                  lambda side, ptr: b.set_halo_row_dev(name, side, ptr))
         to_up = b.get_edge_row(name, 0) if self.has_up else None
         to_down = b.get_edge_row(name, 1) if self.has_down else None
         from_up, from_down = self.comm.exchange_rows(to_up, to_down)

@@ -44,6 +44,21 @@ class CpuBand(object):
         a[i] = row
         return changed
 
+    # device-buffer variants (HipBand.get_edge_row_dev / set_halo_row_dev): here "device" memory is host memory
+    def row_bytes(self, name):
+        return self.W * self._raster(name).dtype.itemsize
+
+    def get_edge_row_dev(self, name, side, ptr):
+        import ctypes
+        row = np.ascontiguousarray(self.get_edge_row(name, side))
+        ctypes.memmove(int(ptr), row.ctypes.data, row.nbytes)
+
+    def set_halo_row_dev(self, name, side, ptr):
+        import ctypes
+        row = np.empty(self.W, dtype=self._raster(name).dtype)
+        ctypes.memmove(row.ctypes.data, int(ptr), row.nbytes)
+        return self.set_halo_row(name, side, row)
+
     def dem_minmax(self):
         d = self.r["dem"][self.ht:self.ht + self.nrows]
         return d.min(), d.max(), bool(np.isnan(d).any())

@@ -88,14 +88,23 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world", [2])
-def test_protocol_gloo_processes(world, tmp_path):
+WORKER_DEVROWS = WORKER.replace("from malstroem_amd.distributed import BandPipeline, TorchComm",
+                                "from malstroem_amd.distributed import BandPipeline, RcclComm").replace(
+    "p = BandPipeline(TorchComm(), dem.shape, backend_factory=CpuBand)",
+    "comm = RcclComm.create('cpu', backend='gloo')\nassert comm.device_rows\np = BandPipeline(comm, dem.shape, backend_factory=CpuBand)")
+
+
+@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_DEVROWS)], ids=["host_rows_2", "device_row_protocol_3"])
+def test_protocol_gloo_processes(world, worker, tmp_path):
+    """Band protocol over real processes.  The second case drives the device-row transport class (RcclComm: per-neighbour
+    device buffers, one batch_isend_irecv per exchange, self test) with host tensors over gloo -- on a GPU node the same
+    code runs with backend "nccl" on cuda tensors."""
     port = 29500 + (os.getpid() % 2000)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    REPO=str(ROOT), OUT=str(tmp_path))
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env))
+        procs.append(subprocess.Popen([sys.executable, "-c", worker], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
     dem = fbm(90, 70, beta=2.0, seed=4)

@@ -80,3 +80,74 @@ def test_bands_match_oracle(nbands, h, w):
     ws = lab.copy()
     oracle.watersheds_from_labels(fd, ws, 0)
     assert np.array_equal(np.concatenate([o["watersheds"] for o in out]), ws)
+
+
+def test_device_row_entry_points_match_host_ones():
+    """mhip_ctx_get_edge_row_dev / set_halo_row_dev (what the RCCL transport calls) against the host-buffer variants.
+    The device buffer comes straight from hipMalloc of the HIP runtime the library already uses (importing torch.cuda
+    AFTER libmalstroem_hip would bring a second HIP runtime into the process)."""
+    import ctypes
+    from malstroem_amd.distributed import HipBand
+    dem = fbm(96, 80, beta=2.0, seed=5)
+    top = HipBand(96, 80, 0, 48, device=0, rank=0, size=2)
+    bot = HipBand(96, 80, 48, 48, device=0, rank=1, size=2)
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    buf = ctypes.c_void_p()
+    nbytes = top.row_bytes("dem")
+    assert hip.hipMalloc(ctypes.byref(buf), ctypes.c_size_t(nbytes)) == 0
+    try:
+        top.upload("dem", dem[:48])
+        bot.upload("dem", dem[48:])
+        top.get_edge_row_dev("dem", 1, buf.value)          # last owned row of the upper band
+        host = np.empty(80, np.float32)
+        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), buf, ctypes.c_size_t(nbytes), 2) == 0   # 2 = device to host
+        assert np.array_equal(host, dem[47])
+        assert np.array_equal(top.get_edge_row("dem", 1), dem[47])
+        bot.set_halo_row_dev("dem", 0, buf.value)
+        assert np.array_equal(bot.get_edge_row("dem", 2), dem[47])
+        assert bot.set_halo_row_dev("dem", 0, buf.value) is False      # same bytes again: unchanged
+    finally:
+        hip.hipFree(buf)
+        top.close()
+        bot.close()
+
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+import numpy as np, torch.distributed as dist
+from _cases import fbm
+from malstroem_amd.distributed import BandPipeline, RcclComm
+dist.init_process_group("gloo", rank=0, world_size=1)
+comm = RcclComm.create(0)                      # backend "nccl" == RCCL: group creation, cuda buffers, self test
+assert getattr(comm, "device_rows", False), "RCCL transport fell back to gloo on a GPU box"
+dem = fbm(200, 150, beta=2.0, seed=9)
+p = BandPipeline(comm, dem.shape, device=0)
+p.upload_dem(dem)
+p.fill(); p.noflat(); p.flowdir(); p.accum(); n = p.label(); p.watershed()
+np.savez(os.environ["OUT"], nlabels=n, **{k: p.download(k) for k in ("filled", "noflat", "flowdir", "accum", "labels", "watersheds")})
+p.close(); dist.destroy_process_group()
+'''
+
+
+def test_rccl_transport_single_rank(tmp_path):
+    """The RCCL transport class on a real GPU with the only world size one box offers (1): process-group creation on the
+    "nccl" backend, device buffers, the self test and the band chain through it.  (Neighbour traffic itself is covered by
+    tests/test_distributed_cpu.py::test_protocol_gloo_processes[device_row_protocol_3] and the test above.)"""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    out = tmp_path / "rccl.npz"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), REPO=str(root), OUT=str(out))
+    r = subprocess.run([sys.executable, "-c", RCCL_WORKER], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    dem = fbm(200, 150, beta=2.0, seed=9)
+    filled = oracle.fill_terrain(dem)
+    short, diag = oracle.minimum_safe_short_and_diag(dem)
+    fnf = oracle.fill_terrain_no_flats(dem, short, diag)
+    fd = oracle.terrain_flowdirection(fnf)
+    assert np.array_equal(got["filled"], filled) and np.array_equal(got["noflat"], fnf) and np.array_equal(got["flowdir"], fd)
+    assert np.array_equal(got["accum"], oracle.accumulated_flow(fd))
+    lab, n = oracle.connected_components(oracle.depths(filled, dem))
+    assert int(got["nlabels"]) == n and np.array_equal(got["labels"], lab)

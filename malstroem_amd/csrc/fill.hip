@@ -320,8 +320,10 @@ enum { INIT_NONE = 0, INIT_INF = 1, INIT_SEED = 2 };
 // Development aid (-DMH_PROFILE_VISIT): per-wave time stamps around the phases of a visit, summed in registers and
 // added to stats[128..] when the wave leaves; finish() prints the averages.
 #ifdef MH_PROFILE_VISIT
-#define MH_STAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long var = __builtin_amdgcn_s_memtime()
-struct Prof { long long load = 0, pass = 0, tr = 0, store = 0, push = 0; };
+// (f32 kernel only: with the stamps the f64 kernel faults on its first worklist round -- not understood, most likely the
+// compiler's handling of the extra SMEM results under ~500 SGPR spills; the shipped kernels contain no s_memtime)
+#define MH_STAMP(var) long long var = 0; if constexpr (!NOFLAT) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); }
+struct Prof { long long load, pass, tr, store, push; };   // per-lane (VGPR) accumulators: the kernels have no SGPRs to spare
 #define MH_PROF_ARG , Prof &pf
 #define MH_PROF_PASS , pf
 #else
@@ -597,8 +599,10 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
     const int g = (int)blockIdx.x;
     unsigned visits = 0, cycles = 0;
 #ifdef MH_PROFILE_VISIT
-    Prof pf;
-    const long long tk0 = __builtin_amdgcn_s_memtime();
+    long long vz = 0;
+    asm volatile("" : "+v"(vz));   // opaque per-lane zero
+    Prof pf{vz, vz, vz, vz, vz};
+    const long long tk0 = (NOFLAT ? 0 : __builtin_amdgcn_s_memtime()) + vz;
 #endif
     if constexpr (MT == 1) {
         // single tiles: every wavefront schedules itself
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
         atomicAdd(&pr[0], (unsigned long long)pf.load); atomicAdd(&pr[1], (unsigned long long)pf.pass);
         atomicAdd(&pr[2], (unsigned long long)pf.tr); atomicAdd(&pr[3], (unsigned long long)pf.store);
         atomicAdd(&pr[4], (unsigned long long)pf.push); atomicAdd(&pr[5], (unsigned long long)visits);
-        atomicAdd(&pr[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - tk0));
+        atomicAdd(&pr[6], (unsigned long long)((NOFLAT ? 0 : __builtin_amdgcn_s_memtime()) - tk0));
 #endif
     }
 }

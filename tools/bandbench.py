@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--bands", type=int, default=2)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--profile", action="store_true", help="cProfile of rank 0's last repetition")
 args = ap.parse_args()
 tile = fbm(args.size, beta=2.0)
 dem = np.concatenate([tile if k % 2 == 0 else tile[::-1] for k in range(args.bands)])
@@ -22,6 +23,11 @@ def work(comm):
     p.upload_dem(dem[p.row0:p.row0 + p.nrows])
     for rep in range(args.reps):
         t = {}
+        prof = None
+        if args.profile and comm.rank == 0 and rep == args.reps - 1:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         for name, fn in (("fill", p.fill), ("noflat", p.noflat), ("flowdir", p.flowdir), ("accum", p.accum), ("label", p.label), ("watershed", p.watershed)):
             t0 = time.perf_counter()
             fn()
@@ -29,6 +35,10 @@ def work(comm):
         t["total"] = round(sum(t.values()), 1)
         t["exchanges"] = dict(p.exchanges)
         res[(comm.rank, rep)] = t
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof).sort_stats("cumulative").print_stats(28)
     p.close()
 
 ts = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(args.bands)]

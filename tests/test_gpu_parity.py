@@ -299,3 +299,15 @@ def test_whole_chain_in_one_request_matches_oracle(alg, shape):
     opour = oracle.label_max_index(accum, lab, n)
     for f in opour.dtype.names:
         assert np.array_equal(pour[f], opour[f]), f
+
+
+@pytest.mark.parametrize("beta,seed,shape", [(2.0, 101, (1536, 1280)), (3.0, 102, (1300, 1700)), (1.2, 103, (2048, 2048)), (2.5, 104, (997, 1501))])
+def test_fills_match_oracle_on_more_terrain(alg, beta, seed, shape):
+    """More shapes / roughness for the two fill kernels (macro-tile f32 path incl. ragged macro tiles, single-tile f64
+    path): smooth terrain (large lakes, many rounds) and rough terrain (many small pits)."""
+    dem = fbm(shape[0], shape[1], beta=beta, seed=seed)
+    filled = alg.fill.fill_terrain(dem)
+    assert np.array_equal(filled, oracle.fill_terrain(dem))
+    short, diag = alg.fill.minimum_safe_short_and_diag(dem)
+    assert (short, diag) == oracle.minimum_safe_short_and_diag(dem)
+    assert np.array_equal(alg.fill.fill_terrain_no_flats(dem, short, diag), oracle.fill_terrain_no_flats(dem, short, diag))

@@ -386,8 +386,8 @@ struct mhip_ctx {
     std::map<int, std::pair<hipEvent_t, hipEvent_t>> ev;
     std::map<int, bool> ev_valid;
     // second stream + fork/join events of the stage DAG (mhip_ctx_run)
-    hipStream_t stream_b = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr;
+    hipStream_t stream_b = nullptr, stream_c = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr, ev_label = nullptr;
 };
 
 static size_t raster_elem(int which)
@@ -466,11 +466,13 @@ int mhip_ctx_destroy(mhip_ctx *c)
         (void)hipEventDestroy(kv.second.second);
     }
     (void)hipStreamDestroy(c->stream);
-    if (c->stream_b) {
-        (void)hipStreamSynchronize(c->stream_b);
-        (void)hipStreamDestroy(c->stream_b);
+    for (hipStream_t st : {c->stream_b, c->stream_c}) {
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
     }
-    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join})
+    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label})
         if (e) (void)hipEventDestroy(e);
     delete c->run[0];
     delete c->run[1];
@@ -917,17 +919,25 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
 
     // events and the second stream are created here, on the calling thread: the maps are not touched concurrently
     hipEvent_t *ea, *eb;
-    for (int st : {MHIP_STAGE_NOFLAT, MHIP_STAGE_FLOWDIR, MHIP_STAGE_ACCUM, MHIP_STAGE_LABEL, MHIP_STAGE_WATERSHED}) {
+    for (int st : {MHIP_STAGE_NOFLAT, MHIP_STAGE_FLOWDIR, MHIP_STAGE_ACCUM, MHIP_STAGE_LABEL, MHIP_STAGE_WATERSHED, MHIP_STAGE_POURPOINTS}) {
         if (mask & st) {
             MH_TRY(ctx_events(c, st, &ea, &eb));
             c->ev_valid[st];   // creates the key
         }
     }
-    if (!c->stream_b) MH_HIP(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    if (!c->stream_b) {
+        // LABEL only has to finish before the no-flats fill does: lowest priority, so that its workgroups fill the gaps of
+        // the latency-bound fill rounds instead of competing with them; WATERSHED is on the critical path: normal priority
+        int least = 0, greatest = 0;
+        MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        MH_HIP(hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, least));
+        MH_HIP(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    }
     if (!c->ev_fork) {
         MH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_label, hipEventDisableTiming));
     }
     hipStream_t sb = c->stream_b;
     MH_HIP(hipEventRecord(c->ev_fork, s));
@@ -935,21 +945,36 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
 
     std::promise<int> flowdir_ready;   // value: MHIP_OK once ev_flowdir has been recorded on the main stream
     std::future<int> flowdir_fut = flowdir_ready.get_future();
+    std::promise<int> label_ready;     // value: MHIP_OK once the final labels exist and ev_label has been recorded
+    std::future<int> label_fut = label_ready.get_future();
     const bool ws_needs_new_flowdir = (mask & MHIP_STAGE_WATERSHED) && (mask & MHIP_STAGE_FLOWDIR);
     int rc_b = MHIP_OK;
     char err_b[512] = "";
     std::thread tb([&] {
         rc_b = [&]() -> int {
             MH_HIP(hipSetDevice(c->device));
-            if (mask & MHIP_STAGE_LABEL) MH_TRY(stage_label(c, sb));
+            int rc_l = MHIP_OK;
+            if (mask & MHIP_STAGE_LABEL) rc_l = stage_label(c, sb);
+            // both consumers (WATERSHED here, POURPOINTS on the main thread) want the final labels: settle them once
+            if (rc_l == MHIP_OK && (mask & (MHIP_STAGE_WATERSHED | MHIP_STAGE_POURPOINTS)) && c->have[MHIP_R_LABELS]) {
+                rc_l = ctx_ensure_labels_final(c, sb);
+                if (rc_l == MHIP_OK) rc_l = ctx_label_max(c, sb);
+            }
+            if (rc_l == MHIP_OK && hipEventRecord(c->ev_label, sb) != hipSuccess) rc_l = MHIP_EHIP;
+            if (rc_l != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
+            label_ready.set_value(rc_l);
+            MH_TRY(rc_l);
+            hipStream_t sw = sb;
             if (mask & MHIP_STAGE_WATERSHED) {
+                sw = c->stream_c;
+                MH_HIP(hipStreamWaitEvent(sw, c->ev_label, 0));
                 if (ws_needs_new_flowdir) {
                     MH_TRY(flowdir_fut.get());
-                    MH_HIP(hipStreamWaitEvent(sb, c->ev_flowdir, 0));
+                    MH_HIP(hipStreamWaitEvent(sw, c->ev_flowdir, 0));
                 }
-                MH_TRY(stage_watershed(c, sb));
+                MH_TRY(stage_watershed(c, sw));
             }
-            MH_HIP(hipEventRecord(c->ev_join, sb));
+            MH_HIP(hipEventRecord(c->ev_join, sw));
             return MHIP_OK;
         }();
         if (rc_b != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
@@ -964,6 +989,11 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     }();
     flowdir_ready.set_value(rc_a);   // releases the other thread in either case
     if (rc_a == MHIP_OK && (mask & MHIP_STAGE_ACCUM)) rc_a = stage_accum(c, s);
+    // POURPOINTS needs the final labels and the accumulation, not the watersheds: it runs next to them
+    const int rc_l = label_fut.get();
+    if (rc_a == MHIP_OK && rc_l == MHIP_OK && (mask & MHIP_STAGE_POURPOINTS)) {
+        rc_a = hipStreamWaitEvent(s, c->ev_label, 0) == hipSuccess ? stage_pourpoints(c, s) : MHIP_EHIP;
+    }
     tb.join();
     if (rc_a != MHIP_OK) return rc_a;
     if (rc_b != MHIP_OK) {
@@ -971,7 +1001,6 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         return rc_b;
     }
     MH_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
-    if (mask & MHIP_STAGE_POURPOINTS) MH_TRY(stage_pourpoints(c, s));
     return MHIP_OK;
 }
 

@@ -36,7 +36,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 # algorithmic (compulsory) HBM bytes per cell, SURVEY.md 8(d) / BASELINE.md section 4
-ALG_BYTES = {"fill": 8 + 12, "noflat": 12, "flowdir": 9, "accum": 9, "label": 8 + 8, "watershed": 9 + 4, "pourpoints": 12}
+# one request for the whole chain: the bluespot depths (12 B/cell) are computed on the label branch, not in the fill stage
+ALG_BYTES = {"fill": 8, "noflat": 12, "flowdir": 9, "accum": 9, "label": 12 + 8 + 8, "watershed": 9 + 4, "pourpoints": 12}
 #   fill      : fill 8 B (4 R + 4 W) + depths 12 B (4 + 4 R, 4 W)
 #   label     : CCL 8 B (4 R + 4 W) + label_stats 8 B (4 + 4 R)
 #   watershed : 9 B (1 + 4 R, 4 W) + label_count 4 B

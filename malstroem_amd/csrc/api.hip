@@ -751,9 +751,19 @@ static int stage_begin(mhip_ctx *c, int stage, hipStream_t s, hipEvent_t **e1)
     return MHIP_OK;
 }
 
-static int stage_fill(mhip_ctx *c, hipStream_t s)
+static int stage_depths(mhip_ctx *c, hipStream_t s)
 {
-    const int64_t H = c->H, W = c->W, n = H * W;
+    MH_ARG(c->have[MHIP_R_FILLED] && c->have[MHIP_R_DEM], "depths need the filled surface");
+    MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
+    MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(), c->H * c->W, s));
+    c->have[MHIP_R_DEPTHS] = true;
+    return MHIP_OK;
+}
+
+// with_depths == false: the caller computes the bluespot depths on another stream (stage DAG)
+static int stage_fill(mhip_ctx *c, hipStream_t s, bool with_depths = true)
+{
+    const int64_t H = c->H, W = c->W;
     MH_ARG(c->have[MHIP_R_DEM], "FILL needs the DEM");
     MH_TRY(ctx_raster(c, MHIP_R_FILLED));
     MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
@@ -761,23 +771,25 @@ static int stage_fill(mhip_ctx *c, hipStream_t s)
     MH_TRY(stage_begin(c, MHIP_STAGE_FILL, s, &e1));
     FillStats st;
     MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st));
-    MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(), n, s));
+    c->have[MHIP_R_FILLED] = true;
+    c->have[MHIP_R_DEPTHS] = false;
+    if (with_depths) MH_TRY(stage_depths(c, s));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_FILL] = true;
     c->fill_rounds = st.rounds;
     c->fill_st = st;
-    c->have[MHIP_R_FILLED] = c->have[MHIP_R_DEPTHS] = true;
     return MHIP_OK;
 }
 
-static int stage_noflat(mhip_ctx *c, hipStream_t s)
+// shdg_done: minimum_safe_short_and_diag of the current DEM is already in c->sh / c->dg (computed next to the fill)
+static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false)
 {
     const int64_t H = c->H, W = c->W, n = H * W;
     MH_ARG(c->have[MHIP_R_DEM], "NOFLAT needs the DEM");
     MH_TRY(ctx_raster(c, MHIP_R_NOFLAT));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_NOFLAT, s, &e1));
-    MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), n, &c->sh, &c->dg, s));
+    if (!shdg_done) MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), n, &c->sh, &c->dg, s));
     FillStats st;
     if (!c->have[MHIP_R_FILLED]) {  // the plain fill seeds the no-flats iteration (fill_noflat_dev)
         MH_TRY(ctx_raster(c, MHIP_R_FILLED));
@@ -825,11 +837,12 @@ static int stage_accum(mhip_ctx *c, hipStream_t s)
 static int stage_label(mhip_ctx *c, hipStream_t s)
 {
     const int64_t H = c->H, W = c->W, n = H * W;
-    MH_ARG(c->have[MHIP_R_DEPTHS], "LABEL needs bluespot depths");
+    MH_ARG(c->have[MHIP_R_DEPTHS] || c->have[MHIP_R_FILLED], "LABEL needs bluespot depths");
     MH_TRY(ctx_raster(c, MHIP_R_LABELS));
     if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)n));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_LABEL, s, &e1));
+    if (!c->have[MHIP_R_DEPTHS]) MH_TRY(stage_depths(c, s));   // stage DAG: the fill left them to this branch
     MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), H, W,
                         &c->nlabels_raw, s));
     MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
@@ -906,8 +919,8 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     const int side_b = mask & (MHIP_STAGE_LABEL | MHIP_STAGE_WATERSHED);
     const bool overlap = side_a && side_b && !serial_env;
 
-    if (mask & MHIP_STAGE_FILL) MH_TRY(stage_fill(c, s));
     if (!overlap) {
+        if (mask & MHIP_STAGE_FILL) MH_TRY(stage_fill(c, s));
         if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s));
         if (mask & MHIP_STAGE_FLOWDIR) MH_TRY(stage_flowdir(c, s));
         if (mask & MHIP_STAGE_ACCUM) MH_TRY(stage_accum(c, s));
@@ -917,17 +930,17 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         return MHIP_OK;
     }
 
-    // events and the second stream are created here, on the calling thread: the maps are not touched concurrently
+    // events and the side streams are created here, on the calling thread: the maps are not touched concurrently
     hipEvent_t *ea, *eb;
-    for (int st : {MHIP_STAGE_NOFLAT, MHIP_STAGE_FLOWDIR, MHIP_STAGE_ACCUM, MHIP_STAGE_LABEL, MHIP_STAGE_WATERSHED, MHIP_STAGE_POURPOINTS}) {
+    for (int st : {MHIP_STAGE_FILL, MHIP_STAGE_NOFLAT, MHIP_STAGE_FLOWDIR, MHIP_STAGE_ACCUM, MHIP_STAGE_LABEL, MHIP_STAGE_WATERSHED,
+                   MHIP_STAGE_POURPOINTS}) {
         if (mask & st) {
             MH_TRY(ctx_events(c, st, &ea, &eb));
             c->ev_valid[st];   // creates the key
         }
     }
     if (!c->stream_b) {
-        // LABEL only has to finish before the no-flats fill does: lowest priority, so that its workgroups fill the gaps of
-        // the latency-bound fill rounds instead of competing with them; WATERSHED is on the critical path: normal priority
+        // LABEL only has to finish before the no-flats fill does: lowest priority; WATERSHED is on the critical path
         int least = 0, greatest = 0;
         MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         MH_HIP(hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, least));
@@ -940,29 +953,39 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_HIP(hipEventCreateWithFlags(&c->ev_label, hipEventDisableTiming));
     }
     hipStream_t sb = c->stream_b;
-    MH_HIP(hipEventRecord(c->ev_fork, s));
-    MH_HIP(hipStreamWaitEvent(sb, c->ev_fork, 0));
+    const bool do_fill = (mask & MHIP_STAGE_FILL) != 0;
+    MH_ARG(c->have[MHIP_R_DEM] || !(mask & (MHIP_STAGE_FILL | MHIP_STAGE_NOFLAT)), "FILL / NOFLAT need the DEM");
 
-    std::promise<int> flowdir_ready;   // value: MHIP_OK once ev_flowdir has been recorded on the main stream
-    std::future<int> flowdir_fut = flowdir_ready.get_future();
-    std::promise<int> label_ready;     // value: MHIP_OK once the final labels exist and ev_label has been recorded
-    std::future<int> label_fut = label_ready.get_future();
+    // hand-overs between the two host threads (each value is an error code)
+    std::promise<int> fill_done, shdg_done, flowdir_ready, label_ready;
+    std::future<int> fill_fut = fill_done.get_future(), shdg_fut = shdg_done.get_future();
+    std::future<int> flowdir_fut = flowdir_ready.get_future(), label_fut = label_ready.get_future();
     const bool ws_needs_new_flowdir = (mask & MHIP_STAGE_WATERSHED) && (mask & MHIP_STAGE_FLOWDIR);
     int rc_b = MHIP_OK;
     char err_b[512] = "";
+    bool shdg_set = false, label_set = false;   // whatever happens on the side thread, the main thread is never left waiting
     std::thread tb([&] {
         rc_b = [&]() -> int {
             MH_HIP(hipSetDevice(c->device));
-            int rc_l = MHIP_OK;
-            if (mask & MHIP_STAGE_LABEL) rc_l = stage_label(c, sb);
+            // the epsilon of the no-flats fill only needs the DEM: computed while the plain fill runs
+            int rc_e = MHIP_OK;
+            if (mask & MHIP_STAGE_NOFLAT) rc_e = short_diag_dev(c->r[MHIP_R_DEM].as<float>(), c->H * c->W, &c->sh, &c->dg, sb);
+            if (rc_e != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
+            shdg_done.set_value(rc_e);
+            shdg_set = true;
+            int rc_l = rc_e == MHIP_OK ? fill_fut.get() : rc_e;   // ev_fork has been recorded on the main stream
+            if (rc_l == MHIP_OK && hipStreamWaitEvent(sb, c->ev_fork, 0) != hipSuccess) rc_l = MHIP_EHIP;
+            if (rc_l == MHIP_OK && (mask & MHIP_STAGE_LABEL)) rc_l = stage_label(c, sb);   // incl. the bluespot depths
+            else if (rc_l == MHIP_OK && do_fill) rc_l = stage_depths(c, sb);
             // both consumers (WATERSHED here, POURPOINTS on the main thread) want the final labels: settle them once
             if (rc_l == MHIP_OK && (mask & (MHIP_STAGE_WATERSHED | MHIP_STAGE_POURPOINTS)) && c->have[MHIP_R_LABELS]) {
                 rc_l = ctx_ensure_labels_final(c, sb);
                 if (rc_l == MHIP_OK) rc_l = ctx_label_max(c, sb);
             }
             if (rc_l == MHIP_OK && hipEventRecord(c->ev_label, sb) != hipSuccess) rc_l = MHIP_EHIP;
-            if (rc_l != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
+            if (rc_l != MHIP_OK && !err_b[0]) snprintf(err_b, sizeof(err_b), "%s", get_error());
             label_ready.set_value(rc_l);
+            label_set = true;
             MH_TRY(rc_l);
             hipStream_t sw = sb;
             if (mask & MHIP_STAGE_WATERSHED) {
@@ -977,17 +1000,25 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
             MH_HIP(hipEventRecord(c->ev_join, sw));
             return MHIP_OK;
         }();
-        if (rc_b != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
+        if (rc_b != MHIP_OK && !err_b[0]) snprintf(err_b, sizeof(err_b), "%s", get_error());
+        if (!shdg_set) shdg_done.set_value(rc_b);
+        if (!label_set) label_ready.set_value(rc_b);
     });
-    int rc_a = [&]() -> int {
-        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s));
+    int rc_a = MHIP_OK;
+    if (do_fill) rc_a = stage_fill(c, s, /*with_depths=*/false);
+    if (rc_a == MHIP_OK && hipEventRecord(c->ev_fork, s) != hipSuccess) rc_a = MHIP_EHIP;
+    fill_done.set_value(rc_a);            // releases the other thread in either case
+    const int rc_e = shdg_fut.get();
+    if (rc_a == MHIP_OK) rc_a = [&]() -> int {
+        MH_TRY(rc_e);
+        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, /*shdg_done=*/true));
         if (mask & MHIP_STAGE_FLOWDIR) {
             MH_TRY(stage_flowdir(c, s));
             MH_HIP(hipEventRecord(c->ev_flowdir, s));
         }
         return MHIP_OK;
     }();
-    flowdir_ready.set_value(rc_a);   // releases the other thread in either case
+    flowdir_ready.set_value(rc_a);
     if (rc_a == MHIP_OK && (mask & MHIP_STAGE_ACCUM)) rc_a = stage_accum(c, s);
     // POURPOINTS needs the final labels and the accumulation, not the watersheds: it runs next to them
     const int rc_l = label_fut.get();

@@ -30,8 +30,8 @@ namespace {
 constexpr int WN = 64;  // window edge (tile + halo)
 constexpr int TI = 62;  // tile interior edge
 #ifndef MH_MAXCYC
-#define MH_MAXCYC 2
-#endif
+#define MH_MAXCYC 1   // measured on the f64 kernel at 16384^2: 1 -> 18.6 ms, 2 -> 21.4 ms, 3 -> 23.7 ms (a second local
+#endif                // cycle mostly re-verifies; a visit that changed something re-queues its tile instead)
 #ifndef MH_ROW_BARRIER
 #define MH_ROW_BARRIER 1
 #endif
@@ -320,9 +320,7 @@ enum { INIT_NONE = 0, INIT_INF = 1, INIT_SEED = 2 };
 // Development aid (-DMH_PROFILE_VISIT): per-wave time stamps around the phases of a visit, summed in registers and
 // added to stats[128..] when the wave leaves; finish() prints the averages.
 #ifdef MH_PROFILE_VISIT
-// (f32 kernel only: with the stamps the f64 kernel faults on its first worklist round -- not understood, most likely the
-// compiler's handling of the extra SMEM results under ~500 SGPR spills; the shipped kernels contain no s_memtime)
-#define MH_STAMP(var) long long var = 0; if constexpr (!NOFLAT) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); var = __builtin_amdgcn_s_memtime(); }
+#define MH_STAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long var = __builtin_amdgcn_s_memtime()
 struct Prof { long long load, pass, tr, store, push; };   // per-lane (VGPR) accumulators: the kernels have no SGPRs to spare
 #define MH_PROF_ARG , Prof &pf
 #define MH_PROF_PASS , pf
@@ -354,7 +352,9 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
     const int64_t r0 = (int64_t)ti * TI, c0 = (int64_t)tj * TI;  // raster coords of window (0,0)
     const int64_t cc = c0 + lane;
     const bool col_in = cc < Wd;
-    const bool upd = lane >= 1 && lane <= TI;
+    // lane predicates are written with bitwise & : a short-circuit && on per-lane values becomes a divergent branch, and a
+    // divergent region is where this compiler may drop a spill of a full-wave value (tools/lint_exec_spills.py)
+    const bool upd = (lane >= 1) & (lane <= TI);
     const WT INF = Inf<WT>::v();
 
     // ---- stage-in: all 128 row loads are issued back to back (scalar row base + one shared per-lane offset keeps
@@ -375,7 +375,7 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
 #pragma unroll
         for (int r = 0; r < WN; ++r) {
             const int64_t rr = r0 + r;
-            const bool in = col_in && rr < H;
+            const bool in = col_in & (rr < H);
             float dv = dp[lane_c];
             WT wv;
             if constexpr (INIT == INIT_NONE) {
@@ -418,7 +418,7 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
     uint64_t rowok = ~0ull;
     if (a.fixed_top && r0 == 0) rowok &= ~1ull;
     if (a.fixed_bot && H - 1 - r0 < WN) rowok &= ~(1ull << (H - 1 - r0));
-    const bool upd_t = upd && ((rowok >> lane) & 1ull);
+    const bool upd_t = upd & (((rowok >> lane) & 1ull) != 0);
     const uint64_t updmask = has_tile ? __ballot(upd) : 0ull, updmask_t = has_tile ? __ballot(upd_t) : 0ull;
     // rows 0 / 63 are never updated by a pass; a frozen row in between can only be a band's bottom halo row
     const int frozen = (a.fixed_bot && H - 1 - r0 < WN - 1) ? (int)(H - 1 - r0) : -1;
@@ -523,7 +523,7 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
     cycles += ncyc;
     // ---- stage-out: interior cells that are not raster border cells (those never move)
     if (has_tile && (changed || first_round)) {
-        const bool lane_ok = upd && col_in && cc != 0 && cc != Wd - 1;
+        const bool lane_ok = upd & col_in & (cc != 0) & (cc != Wd - 1);
         typedef WT __attribute__((address_space(1))) *gwsp;
         gwsp wst = (gwsp)(W + ((r0 + 1) * Wd + c0));
 #pragma unroll
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
     long long vz = 0;
     asm volatile("" : "+v"(vz));   // opaque per-lane zero
     Prof pf{vz, vz, vz, vz, vz};
-    const long long tk0 = (NOFLAT ? 0 : __builtin_amdgcn_s_memtime()) + vz;
+    const long long tk0 = __builtin_amdgcn_s_memtime() + vz;
 #endif
     if constexpr (MT == 1) {
         // single tiles: every wavefront schedules itself
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
         atomicAdd(&pr[0], (unsigned long long)pf.load); atomicAdd(&pr[1], (unsigned long long)pf.pass);
         atomicAdd(&pr[2], (unsigned long long)pf.tr); atomicAdd(&pr[3], (unsigned long long)pf.store);
         atomicAdd(&pr[4], (unsigned long long)pf.push); atomicAdd(&pr[5], (unsigned long long)visits);
-        atomicAdd(&pr[6], (unsigned long long)((NOFLAT ? 0 : __builtin_amdgcn_s_memtime()) - tk0));
+        atomicAdd(&pr[6], (unsigned long long)(__builtin_amdgcn_s_memtime() - tk0));
 #endif
     }
 }

@@ -1,0 +1,65 @@
+"""CPU: compile every kernel of the library to gfx950 ISA (same flags as the Makefile) and run the spill lint
+(tools/lint_exec_spills.py) on it: a full-wave value moved to an AGPR while EXEC is narrowed and read back after the
+region is the miscompile that crashed two build variants of the f64 fill kernel this round.  No GPU needed."""
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "malstroem_amd" / "csrc"
+sys.path.insert(0, str(ROOT / "tools"))
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only"]
+EXTRA = {"fill.hip": ["-fno-honor-nans"]}
+
+
+def _isa(src, out):
+    r = subprocess.run(["hipcc"] + FLAGS + EXTRA.get(src.name, []) + [str(src), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+@pytest.mark.timeout(900)
+def test_no_full_wave_value_is_spilled_under_narrowed_exec(tmp_path):
+    import lint_exec_spills
+    srcs = sorted(CSRC.glob("*.hip"))
+    assert len(srcs) >= 8
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        outs = list(ex.map(lambda s: _isa(s, tmp_path / (s.stem + ".s")), srcs))
+    nkern, bad = 0, []
+    for o in outs:
+        nkern += sum(1 for _ in lint_exec_spills.kernels(str(o)))
+        bad += lint_exec_spills.lint(str(o))
+    assert nkern >= 40            # the lint really saw the kernels
+    assert not bad, bad
+
+
+def test_lint_catches_the_pattern(tmp_path):
+    """the miscompile in miniature: save under narrowed exec, read back after the region"""
+    import lint_exec_spills
+    asm = """_Zkernel:
+	v_mov_b32_e32 v5, 0
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_2
+	v_accvgpr_write_b32 a7, v5
+.LBB0_2:
+	s_or_b64 exec, exec, s[2:3]
+	v_mov_b32_e32 v5, v9
+	v_accvgpr_read_b32 v5, a7
+	global_load_dword v1, v5, s[4:5]
+	s_endpgm
+_Zbenign:
+	s_and_saveexec_b64 s[2:3], vcc
+	v_accvgpr_write_b32 a7, v5
+	global_store_dword v0, a7, s[6:7]
+	s_or_b64 exec, exec, s[2:3]
+	v_accvgpr_write_b32 a7, v1
+	v_accvgpr_read_b32 v2, a7
+	s_endpgm
+"""
+    p = tmp_path / "t.s"
+    p.write_text(asm)
+    res = lint_exec_spills.lint(str(p))
+    assert len(res) == 1 and res[0][0] == "_Zkernel"

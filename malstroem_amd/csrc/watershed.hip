@@ -66,9 +66,11 @@ __global__ __launch_bounds__(256) void ws_init_kernel(const uint8_t *__restrict_
 // while the path length covered grows by 2**HOPS.  Racing updates are benign: every value a thread can observe in
 // P[] / Q[] is a cell further down the same flow path (or the final terminal).  A cell whose pointer has reached a
 // labelled cell stores it with the DONE bit: later launches then cost one coalesced read for it, no gather.
-constexpr int HOPS = 4;
+constexpr int HOPS = 5;
 constexpr int32_t DONE = (int32_t)0x80000000;
-__global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, int64_t n, unsigned int *changed)
+// `open`: set when some pointer is still on its way after this launch (the host stops as soon as a launch leaves it 0;
+// pointers on a flow cycle stay open for ever: the launch count is capped)
+__global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, int64_t n, unsigned int *open)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -86,10 +88,8 @@ __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, i
             t = pt;         // skip over t (pt may be NONE, or already carry DONE)
             if (t < 0 || t == NONE) break;
         }
-        if (t != t0) {
-            P[i] = t;
-            ch = true;
-        }
+        if (t != t0) P[i] = t;
+        ch = t >= 0 && t != NONE;   // neither at a labelled cell nor out of the raster yet
     }
     if (Q) {
         uint32_t q = Q[i];
@@ -101,12 +101,10 @@ __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, i
             const uint32_t qt = Q[idx];
             q = ((q | qt) & QFLAG) | (qt & QMASK);
         }
-        if (q != q0) {
-            Q[i] = q;
-            ch = true;
-        }
+        if (q != q0) Q[i] = q;
+        ch |= (q & QMASK) != QTERM;
     }
-    if (ch) *changed = 1u;
+    if (ch) *open = 1u;
 }
 
 __global__ __launch_bounds__(256) void ws_assign_kernel(const int32_t *__restrict__ P, const uint32_t *__restrict__ Q,
@@ -180,16 +178,18 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
         q = Q.as<uint32_t>();
     }
     hipLaunchKernelGGL(ws_init_kernel, dim3(grid), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), q, H, W, unassigned);
-    // launches come in pairs with one flag each: the pair is the last one as soon as its SECOND launch changed nothing
-    constexpr int MAX_ROUNDS = 40;   // 40 launches x 4 hops each: paths up to 2**160 cells
-    for (int round = 0; round < MAX_ROUNDS; round += 2) {
+    // two launches (paths up to 2**10 cells), then one at a time; every launch has its own "still open" flag
+    constexpr int MAX_ROUNDS = 32;   // x 5 hops each: paths up to 2**160 cells; flow cycles end here
+    for (int round = 0; round < MAX_ROUNDS;) {
+        const int k = round == 0 ? 2 : 1;
         MH_HIP(hipMemsetAsync(d_changed, 0, 8, s));
-        for (int k = 0; k < 2; ++k)
-            hipLaunchKernelGGL(ws_jump_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, n, d_changed + k);
+        for (int j = 0; j < k; ++j)
+            hipLaunchKernelGGL(ws_jump_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, n, d_changed + j);
         unsigned int h[2] = {0, 0};
         MH_HIP(hipMemcpyAsync(h, d_changed, 8, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
-        if (!h[1]) break;
+        round += k;
+        if (!h[k - 1]) break;
     }
     hipLaunchKernelGGL(ws_assign_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, d_labels, n, unassigned);
     MH_HIP(hipGetLastError());

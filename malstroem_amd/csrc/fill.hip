@@ -637,7 +637,19 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
     } else if constexpr (INIT != INIT_NONE) {
         // first round: every macro tile, statically strided (uniform work)
         for (int t = g; t < nmt; t += (int)gridDim.x) {
-            visit_macro<WT, NOFLAT, INIT, MT>(a, dem, seed, W, t, 0xfu, scr, X, lane, wave, visits, cycles MH_PROF_PASS);
+            unsigned flags = 0xfu;
+            if constexpr (INIT == INIT_INF) {
+                // a window without a raster border cell (nor a band halo row) starts all +inf and cannot move before a
+                // sibling or a neighbour offers something finite: its first cycle is skipped (the window is still stored)
+                flags = 0u;
+                const int mi = t / a.mtc, mj = t - mi * a.mtc;
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t r0 = (int64_t)(2 * mi + (q >> 1)) * TI, c0 = (int64_t)(2 * mj + (q & 1)) * TI;
+                    const bool interior = r0 > 0 && r0 + WN - 1 < a.H - 1 && c0 > 0 && c0 + WN - 1 < a.Wd - 1;
+                    if (!interior) flags |= 1u << q;
+                }
+            }
+            visit_macro<WT, NOFLAT, INIT, MT>(a, dem, seed, W, t, flags, scr, X, lane, wave, visits, cycles MH_PROF_PASS);
             __syncthreads();   // the exchange area is reused by the next visit
         }
     } else {

@@ -7,9 +7,12 @@
 // Device schedule: union-find over linear cell indices where the representative of a set is always its
 // minimum index (hooking larger root under smaller with atomicMin), so after flattening the roots are exactly
 // the components' first raster pixels; an exclusive prefix sum over the root flags gives the scipy rank.
-//   1. init   : parent[i] = i (foreground) / -1 (background)
-//   2. merge  : every foreground cell unites with the already-scanned neighbours that are not implied by
-//               another union (N; else W or NW, and NE)
+//   1. init   : parent[i] = first cell of i's horizontal run of foreground cells inside its 64-cell wavefront chunk
+//               (ballot + count-leading-zeros; runs never cross a raster row), -1 for background: every run is a
+//               finished set before the first atomic
+//   2. merge  : ONE union per pair of vertically adjacent runs: a cell unites with N unless its left neighbour has
+//               already done so (W and NW foreground), with NW only when N and W are background, with NE when N is
+//               background; the first lane of a chunk also unites with W (runs cut by the chunk border)
 //   3. flatten: parent[i] = root(i)
 //   4. rank   : per-block root counts -> single-block scan -> roots get -(rank+1)
 //   5. emit   : labels[i] = rank of root(i), 0 for background
@@ -25,10 +28,21 @@ constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
 template <typename T> __device__ __forceinline__ bool is_fg(T v) { return v != (T)0; }
 
 template <typename T>
-__global__ __launch_bounds__(256) void ccl_init_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t n)
+__global__ __launch_bounds__(256) void ccl_init_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t n, int64_t W)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) parent[i] = is_fg(data[i]) ? (int32_t)i : -1;
+    const int lane = threadIdx.x & 63;
+    const bool fg = i < n && is_fg(data[i]);
+    const bool fg_left = __shfl_up((int)fg, 1) != 0;
+    const bool start = fg && (lane == 0 || !fg_left || (i % W) == 0);
+    const uint64_t brk = __ballot(start);
+    if (i >= n) return;
+    int32_t p = -1;
+    if (fg) {
+        const uint64_t below = brk & ((2ull << lane) - 1ull);   // run starts at or before my lane (mine included)
+        p = (int32_t)(i - (lane - (63 - __builtin_clzll(below))));
+    }
+    parent[i] = p;
 }
 
 __device__ __forceinline__ int32_t find_root(const int32_t *parent, int32_t x)
@@ -64,17 +78,19 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(int32_t *parent, int64_t
     if (i >= H * W) return;
     if (parent[i] < 0) return;
     const int64_t r = i / W, c = i - r * W;
-    const bool hasN = r > 0 && parent[i - W] >= 0;
+    const bool hasW = c > 0 && parent[i - 1] >= 0;
+    if (hasW && (threadIdx.x & 63) == 0) unite(parent, (int32_t)i, (int32_t)(i - 1));   // my run continues the previous chunk's
+    if (r == 0) return;
+    const bool hasN = parent[i - W] >= 0;
+    const bool hasNW = c > 0 && parent[i - W - 1] >= 0;
     if (hasN) {
-        unite(parent, (int32_t)i, (int32_t)(i - W));  // N is adjacent to W, NW and NE: one union covers them
+        // N's run touches mine; the left neighbour has made this union already when W and NW are foreground too
+        if (!(hasW && hasNW)) unite(parent, (int32_t)i, (int32_t)(i - W));
         return;
     }
-    const bool hasW = c > 0 && parent[i - 1] >= 0;
-    const bool hasNW = r > 0 && c > 0 && parent[i - W - 1] >= 0;
-    const bool hasNE = r > 0 && c + 1 < W && parent[i - W + 1] >= 0;
-    if (hasW) unite(parent, (int32_t)i, (int32_t)(i - 1));  // W and NW are vertical neighbours of each other
-    else if (hasNW) unite(parent, (int32_t)i, (int32_t)(i - W - 1));
-    if (hasNE) unite(parent, (int32_t)i, (int32_t)(i - W + 1));
+    const bool hasNE = c + 1 < W && parent[i - W + 1] >= 0;
+    if (hasNW && !hasW) unite(parent, (int32_t)i, (int32_t)(i - W - 1));   // with W foreground, W has N == my NW
+    if (hasNE) unite(parent, (int32_t)i, (int32_t)(i - W + 1));            // a run that starts above my right shoulder
 }
 
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t *parent, int64_t n)
@@ -193,7 +209,7 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
     MH_TRY(counts.alloc(sizeof(uint32_t) * (size_t)nb));
     MH_TRY(total.alloc(sizeof(unsigned long long)));
     int32_t *parent = d_tmp;
-    hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n);
+    hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n, W);
     hipLaunchKernelGGL(ccl_merge_kernel, dim3(g256), dim3(256), 0, s, parent, H, W);
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g256), dim3(256), 0, s, parent, n);
     hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());

@@ -65,6 +65,11 @@ def fbm(n, beta=2.0, seed=42):
     return z.astype(np.float32)
 
 
+KERNEL_OF_STAGE = {"fill": "fill_round_kernel<float, ...> (one launch per round)", "noflat": "fill_round_kernel<double, ...> (one launch per round)",
+                   "flowdir": "d8_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "ccl_* + stats_kernel",
+                   "watershed": "ws_* + count_kernel", "pourpoints": "arg_packed_kernel"}
+
+
 def pmc_traffic(stage, n):
     """HBM bytes of the stage's kernels from the newest committed rocprofv3 PMC table (profiles/*_pmc_hbm_traffic.json,
     made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2; FETCH_SIZE doubled for
@@ -232,7 +237,9 @@ def main():
             "config": {"workload": "%dx%d fBm beta=%g float32 DEM per GPU: fill+depths -> no-flats fill -> D8 -> accumulation -> "
                                    "CCL+label_stats -> watersheds+label_count -> pour points" % (n, n, args.beta),
                        "parallelism": parallelism, "dem_generation_s": round(t_gen, 1), **info},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE.get(dominant, dominant), "stage": dominant,
+                         "launches_per_step": info.get({"fill": "fill_rounds", "noflat": "noflat_rounds"}.get(dominant, ""), 1),
+                         "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": pmc_traffic(dominant, n),
                          "note": "dominant stage by device time; algorithmic bytes of the whole stage / stage time (HIP events)"},
             "d8_roofline": {"bound": "hbm", "kernel": "d8_kernel", "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS,

@@ -161,3 +161,26 @@ def test_keep_labels_mutates_and_masks_like_the_reference(alg):
     mask = alg.label.keep_labels(lab, keep)
     assert keep[0] is False                                                    # label.py:91 side effect
     assert mask.dtype == bool and mask.tolist() == [[False, True, True], [False, False, True]]
+
+
+def test_fills_on_shapes_around_tile_and_macro_tile_multiples():
+    """62-cell tiles, 124-cell macro tiles: shapes right at / next to the multiples (ragged macro tiles with 1, 2 or 3 real
+    tiles, windows that end on the raster border, one-tile rasters), both fills against the oracle."""
+    import oracle
+    import malstroem_amd.algorithms as alg
+    rng = np.random.default_rng(77)
+    dims = [3, 4, 63, 64, 65, 66, 125, 126, 127, 128, 187, 188, 189, 250, 251]
+    shapes = [(h, w) for h in dims for w in (64, 126, 127, 189)] + [(251, 250), (126, 3), (4, 190)]
+    for h, w in shapes:
+        # rough surface with a few deep pits and plateaus: many small lakes and some that span tiles
+        dem = rng.normal(size=(h, w)).cumsum(0).cumsum(1).astype(np.float32)
+        dem -= dem.min()
+        dem *= 50.0 / max(float(dem.max()), 1.0)
+        dem = np.round(dem, 1).astype(np.float32)          # plateaus (ties)
+        if h > 8 and w > 8:
+            dem[h // 2 - 2:h // 2 + 2, 1:w - 1] = -5.0       # a trench across all tile columns
+        filled = alg.fill.fill_terrain(dem)
+        assert np.array_equal(filled, oracle.fill_terrain(dem)), (h, w)
+        short, diag = alg.fill.minimum_safe_short_and_diag(dem)
+        got = alg.fill.fill_terrain_no_flats(dem, short, diag)
+        assert np.array_equal(got, oracle.fill_terrain_no_flats(dem, short, diag)), (h, w)

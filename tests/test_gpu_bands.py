@@ -61,7 +61,8 @@ def test_bands_match_reference_fixture(nbands):
     assert np.array_equal(np.concatenate([o["watersheds"] for o in out]), ws)
 
 
-@pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (4, 1024, 1024), (4, 1000, 130)])
+@pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (4, 1024, 1024), (4, 1000, 130), (3, 380, 130), (2, 252, 190), (5, 640, 70),
+                                        (2, 128, 250), (3, 189, 127)])
 def test_bands_match_oracle(nbands, h, w):
     dem = fbm(h, w, beta=2.0, seed=21)
     out = run_bands(dem, nbands)

@@ -644,6 +644,56 @@ int mhip_ctx_band_apply_neg_lut(mhip_ctx *c, int which, const int32_t *lut, int6
     return MHIP_OK;
 }
 
+/* per-label records over the OWNED rows of a band, indexed by GLOBAL label (after mhip_ctx_band_relabel): the launcher
+ * merges the records of the few labels / watersheds that live in more than one band (distributed.BandPipeline) */
+int mhip_ctx_band_stats(mhip_ctx *c, mhip_stat_record *records)
+{
+    MH_ARG(c && records && c->have[MHIP_R_LABELS] && c->have[MHIP_R_DEPTHS] && c->nlabels >= 0, "ctx_band_stats needs depths and global labels");
+    MH_HIP(hipSetDevice(c->device));
+    const int64_t off = c->W * c->ht, n = c->H_owned * c->W;
+    DevBuf rec;
+    MH_TRY(rec.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1)));
+    MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, n, c->nlabels,
+                           rec.as<mhip_stat_record>(), c->stream, c->W));
+    MH_HIP(hipMemcpyAsync(records, rec.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+int mhip_ctx_band_watershed_counts(mhip_ctx *c, int64_t *counts)
+{
+    MH_ARG(c && counts && c->have[MHIP_R_WATERSHEDS] && c->nlabels >= 0, "ctx_band_watershed_counts needs watersheds");
+    MH_HIP(hipSetDevice(c->device));
+    const int64_t off = c->W * c->ht, n = c->H_owned * c->W;
+    DevBuf cnt;
+    MH_TRY(cnt.alloc(8 * (size_t)(c->nlabels + 1)));
+    MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, cnt.as<int64_t>(), c->stream, c->W));
+    MH_HIP(hipMemcpyAsync(counts, cnt.p, 8 * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    return MHIP_OK;
+}
+
+/* arg-max of the accumulated flow per label over the owned rows; rows are GLOBAL raster rows (-1 when the label has no
+ * cell in this band) */
+int mhip_ctx_band_pourpoints(mhip_ctx *c, mhip_index_record *records)
+{
+    MH_ARG(c && records && c->have[MHIP_R_LABELS] && c->have[MHIP_R_ACCUM] && c->nlabels >= 0, "ctx_band_pourpoints needs labels and accumulated flow");
+    MH_HIP(hipSetDevice(c->device));
+    const int64_t off = c->W * c->ht;
+    DevBuf rec;
+    MH_TRY(rec.alloc(sizeof(mhip_index_record) * (size_t)(c->nlabels + 1)));
+    MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
+                         true, rec.as<mhip_index_record>(), c->stream));
+    std::vector<mhip_index_record> h((size_t)(c->nlabels + 1));
+    MH_HIP(hipMemcpyAsync(h.data(), rec.p, sizeof(mhip_index_record) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    MH_HIP(hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < h.size(); ++k) {
+        records[k] = h[k];
+        if (h[k].row >= 0) records[k].row = h[k].row + c->row0;
+    }
+    return MHIP_OK;
+}
+
 int mhip_ctx_dem_minmax(mhip_ctx *c, float *mn, float *mx, int32_t *has_nan)
 {
     MH_ARG(c && mn && mx && has_nan && c->have[MHIP_R_DEM], "ctx_dem_minmax needs the DEM");

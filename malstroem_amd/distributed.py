@@ -19,7 +19,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from ._lib import R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_ACCUM, STAGE_FLOWDIR
+from ._lib import INDEX_DTYPE, R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_ACCUM, STAGE_FLOWDIR, STAT_DTYPE
 from .pipeline import RASTERS
 
 __all__ = ["band_rows", "Comm", "ThreadComm", "TorchComm", "HipBand", "BandPipeline"]
@@ -356,6 +356,22 @@ class HipBand(object):
         _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))
         return v.value
 
+    # per-label records over the OWNED rows, indexed by global label (nlabels + 1 entries)
+    def band_stats(self, nlabels):
+        rec = np.zeros(nlabels + 1, dtype=STAT_DTYPE)
+        _lib.call("mhip_ctx_band_stats", self._ctx, _lib.ptr(rec))
+        return rec
+
+    def band_watershed_counts(self, nlabels):
+        out = np.zeros(nlabels + 1, dtype=np.int64)
+        _lib.call("mhip_ctx_band_watershed_counts", self._ctx, _lib.ptr(out))
+        return out
+
+    def band_pourpoints(self, nlabels):
+        rec = np.zeros(nlabels + 1, dtype=INDEX_DTYPE)
+        _lib.call("mhip_ctx_band_pourpoints", self._ctx, _lib.ptr(rec))
+        return rec
+
 
 # ---- the protocol ---------------------------------------------------------------------------------------------------
 
@@ -518,6 +534,11 @@ class BandPipeline(object):
             class_label[ids] = labs
         members = mine & ~is_rep
         lut[node_lab[members]] = class_label[cls[members]]
+        # global labels with cells in more than one band (same array on every rank): their records need a merge
+        real = ~phantom
+        pairs = np.unique(np.stack([cls[real], node_rank[real]], axis=1), axis=0) if real.any() else np.zeros((0, 2), np.int64)
+        ranks_per_class = np.bincount(pairs[:, 0], minlength=ncls) if ncls else np.zeros(0, np.int64)
+        self.shared_labels = np.unique(class_label[np.flatnonzero(ranks_per_class > 1)]).astype(np.int64)
         self.nlabels = int(offsets[-1])
         self.label_range = (int(offsets[comm.rank]) + 1, int(offsets[comm.rank + 1]))
         b.relabel(lut.astype(np.int32), self.nlabels)
@@ -552,6 +573,58 @@ class BandPipeline(object):
         if self.has_down:
             lut[W:] = vals[(2 * (comm.rank + 1)) * W:(2 * (comm.rank + 1) + 1) * W]
         b.apply_neg_lut("watersheds", lut.astype(np.int32))
+
+    # ---- per-label records (reference bluespots.py:159-206 on one raster).  Every rank returns the records of the labels
+    # IT numbered (``label_range``, complete after the merge) plus the background record; a label or a watershed that
+    # reaches into other bands is merged from their partial records (a handful of rows per exchange).
+    def _own(self, full):
+        lo, hi = self.label_range
+        return {"first_label": lo, "records": full[lo:hi + 1].copy(), "background": full[0].copy()}
+
+    def stats(self):
+        """label.label_stats(depths, labels): min / max / sum / count per bluespot."""
+        rec = self.band.band_stats(self.nlabels)
+        ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
+        parts = self.comm.allgather(rec[ids])
+        m = parts[0].copy()
+        for p in parts[1:]:
+            m["min"] = np.minimum(m["min"], p["min"])
+            m["max"] = np.maximum(m["max"], p["max"])
+            m["sum"] = m["sum"] + p["sum"]
+            m["count"] = m["count"] + p["count"]
+        rec[ids] = m
+        return self._own(rec)
+
+    def watershed_counts(self):
+        """label.label_count(watersheds): cells per watershed.  A watershed may reach into any band."""
+        cnt = self.band.band_watershed_counts(self.nlabels)
+        lo, hi = self.label_range
+        nz = np.flatnonzero(cnt)
+        foreign = nz[(nz != 0) & ((nz < lo) | (nz > hi))]
+        parts = self.comm.allgather((foreign, cnt[foreign], int(cnt[0])))
+        total0 = 0
+        for r, (ids, vals, c0) in enumerate(parts):
+            total0 += c0
+            if r == self.comm.rank:
+                continue
+            mine = (ids >= lo) & (ids <= hi)
+            np.add.at(cnt, ids[mine], vals[mine])
+        cnt[0] = total0
+        return self._own(cnt)
+
+    def pourpoints(self):
+        """label.label_max_index(accum, labels): value, row, col of the first raster cell with the largest accumulated
+        flow per bluespot (rows are global)."""
+        rec = self.band.band_pourpoints(self.nlabels)
+        ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
+        parts = self.comm.allgather(rec[ids])
+        m = parts[0].copy()
+        for p in parts[1:]:
+            # strict '>' with the first raster position on ties: bands are in raster order, so an earlier band wins ties
+            better = (p["value"] > m["value"]) | ((m["row"] < 0) & (p["row"] >= 0))
+            m[better] = p[better]
+        rec[ids] = m
+        return self._own(rec)
 
     def download(self, name):
         return self.band.download(name)

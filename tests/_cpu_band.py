@@ -222,3 +222,17 @@ class CpuBand(object):
 
     def get_int(self, key):
         return 0
+
+    def _owned(self, name):
+        return self.r[name][self.ht:self.ht + self.nrows]
+
+    def band_stats(self, nlabels):
+        return oracle.label_stats(self._owned("depths"), self._owned("labels"), nlabels)
+
+    def band_watershed_counts(self, nlabels):
+        return np.bincount(self._owned("watersheds").ravel(), minlength=nlabels + 1).astype(np.int64)
+
+    def band_pourpoints(self, nlabels):
+        rec = oracle.label_max_index(self._owned("accum"), self._owned("labels"), nlabels)
+        rec["row"] = np.where(rec["row"] >= 0, rec["row"] + self.row0, rec["row"])
+        return rec

@@ -28,8 +28,38 @@ def reference(dem):
     lab, n = oracle.connected_components(depths)
     ws = lab.copy()
     oracle.watersheds_from_labels(fd, ws, 0)
-    return dict(filled=filled, depths=depths, noflat=fnf, flowdir=fd, accum=oracle.accumulated_flow(fd), labels=lab,
-                nlabels=n, watersheds=ws, short_diag=(short, diag))
+    acc = oracle.accumulated_flow(fd)
+    return dict(filled=filled, depths=depths, noflat=fnf, flowdir=fd, accum=acc, labels=lab,
+                nlabels=n, watersheds=ws, short_diag=(short, diag), stats=oracle.label_stats(depths, lab, n),
+                counts=np.bincount(ws.ravel(), minlength=n + 1), pour=oracle.label_max_index(acc, lab, n))
+
+
+def check_records(outs, ref):
+    """per-rank record slices (BandPipeline.stats / watershed_counts / pourpoints) against the undivided raster"""
+    n = ref["nlabels"]
+    for key, want in (("stats", ref["stats"]), ("counts", ref["counts"]), ("pour", ref["pour"])):
+        parts = [o[key] for o in outs]
+        got = np.concatenate([p["records"] for p in parts])
+        assert [p["first_label"] for p in parts] == list(np.cumsum([1] + [len(p["records"]) for p in parts[:-1]]))
+        assert len(got) == n
+        w = want[1:]
+        if key == "stats":
+            for f in ("min", "max", "count"):
+                assert np.array_equal(got[f], w[f]), (key, f)
+            assert np.allclose(got["sum"], w["sum"], rtol=1e-12, atol=0)
+        elif key == "pour":
+            for f in ("value", "row", "col"):
+                assert np.array_equal(got[f], w[f]), (key, f)
+        else:
+            assert np.array_equal(got, w)
+        for p in parts:   # every rank holds the merged background record
+            bg = p["background"]
+            if key == "counts":
+                assert int(bg) == int(want[0])
+            elif key == "stats":
+                assert bg["count"] == want[0]["count"] and bg["min"] == want[0]["min"] and bg["max"] == want[0]["max"]
+            else:
+                assert tuple(bg) == tuple(want[0])
 
 
 def test_band_rows_partition():
@@ -56,9 +86,11 @@ def test_protocol_threadcomm_cpu_backend(nbands):
         p.accum()
         n = p.label()
         p.watershed()
-        out[comm.rank] = {k: p.download(k) for k in KEYS}
-        out[comm.rank]["short_diag"] = (p.short, p.diag)
-        out[comm.rank]["nlabels"] = n
+        o = {k: p.download(k) for k in KEYS}
+        o["short_diag"] = (p.short, p.diag)
+        o["nlabels"] = n
+        o["stats"], o["counts"], o["pour"] = p.stats(), p.watershed_counts(), p.pourpoints()
+        out[comm.rank] = o
 
     threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
     [t.start() for t in threads]
@@ -68,6 +100,7 @@ def test_protocol_threadcomm_cpu_backend(nbands):
         assert np.array_equal(np.concatenate([o[k] for o in out]), ref[k]), k
     assert out[0]["short_diag"] == ref["short_diag"]
     assert all(o["nlabels"] == ref["nlabels"] for o in out)
+    check_records(out, ref)
 
 
 WORKER = r'''

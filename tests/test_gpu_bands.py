@@ -31,6 +31,7 @@ def run_bands(dem, nbands):
             out[comm.rank]["nlabels"] = n
             out[comm.rank]["short_diag"] = (p.short, p.diag)
             out[comm.rank]["exchanges"] = dict(p.exchanges)
+            out[comm.rank]["stats"], out[comm.rank]["counts"], out[comm.rank]["pour"] = p.stats(), p.watershed_counts(), p.pourpoints()
             p.close()
         except Exception as e:  # pragma: no cover
             err.append(e)
@@ -81,6 +82,25 @@ def test_bands_match_oracle(nbands, h, w):
     ws = lab.copy()
     oracle.watersheds_from_labels(fd, ws, 0)
     assert np.array_equal(np.concatenate([o["watersheds"] for o in out]), ws)
+    # per-label records: every rank returns the labels it numbered, merged across bands
+    acc = np.concatenate([o["accum"] for o in out])
+    dep = oracle.depths(filled, dem)
+    want = {"stats": oracle.label_stats(dep, lab, n), "counts": np.bincount(ws.ravel(), minlength=n + 1),
+            "pour": oracle.label_max_index(acc, lab, n)}
+    for key in ("stats", "counts", "pour"):
+        got = np.concatenate([o[key]["records"] for o in out])
+        assert len(got) == n
+        w_ = want[key][1:]
+        if key == "counts":
+            assert np.array_equal(got, w_)
+            assert all(int(o[key]["background"]) == int(want[key][0]) for o in out)
+        elif key == "stats":
+            for f in ("min", "max", "count"):
+                assert np.array_equal(got[f], w_[f]), f
+            assert np.allclose(got["sum"], w_["sum"], rtol=1e-12, atol=0)
+        else:
+            for f in ("value", "row", "col"):
+                assert np.array_equal(got[f], w_[f]), f
 
 
 def test_device_row_entry_points_match_host_ones():

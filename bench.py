@@ -162,7 +162,7 @@ def main():
             band.upload_dem(dem if rank % 2 == 0 else dem[::-1])
             parallelism = "row bands of one %dx%d DEM over %d GPUs, halo rows %s" % (
                 n * world, n, world, "GPU->GPU over RCCL send/recv" if getattr(comm, "device_rows", False) else "host-staged over gloo")
-            stage_names = ["fill", "noflat", "flowdir", "accum", "label", "watershed"]
+            stage_names = ["fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints"]
         except Exception as e:  # pragma: no cover - only on a multi-GPU node
             band = None
             parallelism = "replicas only (band mode failed: %s)" % (str(e)[:80],)
@@ -175,8 +175,19 @@ def main():
 
     def step(record):
         if band is not None:
+            # the per-label records are computed and merged across bands like in the single-GPU chain; the slice of a
+            # band's own labels stays on the device (nobody downloads records inside the timed loop at N = 1 either)
+            def label_and_stats():
+                band.label()
+                band.stats(fetch_own=False)
+
+            def watershed_and_counts():
+                band.watershed()
+                band.watershed_counts(fetch_own=False)
+
             for name, fn in (("fill", band.fill), ("noflat", band.noflat), ("flowdir", band.flowdir), ("accum", band.accum),
-                             ("label", band.label), ("watershed", band.watershed)):
+                             ("label", label_and_stats), ("watershed", watershed_and_counts),
+                             ("pourpoints", lambda: band.pourpoints(fetch_own=False))):
                 t = time.perf_counter()
                 fn()
                 if record:

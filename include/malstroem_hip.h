@@ -157,12 +157,16 @@ int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int
 /* watersheds on a band: local pointer jumping with pseudo labels on the halo rows, then a boundary LUT */
 int mhip_ctx_band_watershed_local(mhip_ctx *ctx);
 int mhip_ctx_band_apply_neg_lut(mhip_ctx *ctx, int which, const int32_t *lut, int64_t n);
-/* per-label records over the OWNED rows of the band, indexed by GLOBAL label (nlabels_global + 1 entries each): label_stats
- * of the depths, np.bincount of the watersheds, first arg-max of the accumulated flow (rows are global raster rows).  The
- * launcher merges the labels / watersheds that live in more than one band (reference bluespots.py:159-206 on one raster) */
-int mhip_ctx_band_stats(mhip_ctx *ctx, mhip_stat_record *records);
-int mhip_ctx_band_watershed_counts(mhip_ctx *ctx, int64_t *counts);
-int mhip_ctx_band_pourpoints(mhip_ctx *ctx, mhip_index_record *records);
+/* per-label records over the OWNED rows of the band, indexed by GLOBAL label (reference bluespots.py:159-206 on one
+ * raster).  which: 0 = label_stats of the depths (mhip_stat_record), 1 = np.bincount of the watersheds (int64), 2 = first
+ * arg-max of the accumulated flow (mhip_index_record, rows are global raster rows).  _records computes nlabels_global + 1
+ * entries and keeps them on the device; the launcher fetches the slice of the labels this band numbered (_fetch), the few
+ * labels that cross a band boundary (_gather) and the non-zero watershed counts of labels outside [lo, hi] (_foreign_counts:
+ * up to cap pairs, *nfound = how many exist) and merges them across bands */
+int mhip_ctx_band_records(mhip_ctx *ctx, int which);
+int mhip_ctx_band_fetch(mhip_ctx *ctx, int which, int64_t first, int64_t count, void *out);
+int mhip_ctx_band_gather(mhip_ctx *ctx, int which, const int64_t *ids, int64_t nids, void *out);
+int mhip_ctx_band_foreign_counts(mhip_ctx *ctx, int64_t lo, int64_t hi, int64_t cap, int64_t *ids, int64_t *counts, int64_t *nfound);
 int mhip_ctx_upload_dem(mhip_ctx *ctx, const float *dem_band);       /* H_local x W host raster */
 int mhip_ctx_upload(mhip_ctx *ctx, int which, const void *host);     /* any raster (for sub-commands) */
 int mhip_ctx_download(mhip_ctx *ctx, int which, void *host);         /* H_local x W */

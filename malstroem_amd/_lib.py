@@ -40,7 +40,8 @@ SYMBOLS = [
     "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_end",
     "mhip_ctx_zero_raster", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_watershed_local",
-    "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_stats", "mhip_ctx_band_watershed_counts", "mhip_ctx_band_pourpoints",
+    "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_records", "mhip_ctx_band_fetch", "mhip_ctx_band_gather",
+    "mhip_ctx_band_foreign_counts",
 ]
 
 _lib = None

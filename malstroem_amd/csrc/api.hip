@@ -644,52 +644,124 @@ int mhip_ctx_band_apply_neg_lut(mhip_ctx *c, int which, const int32_t *lut, int6
     return MHIP_OK;
 }
 
-/* per-label records over the OWNED rows of a band, indexed by GLOBAL label (after mhip_ctx_band_relabel): the launcher
- * merges the records of the few labels / watersheds that live in more than one band (distributed.BandPipeline) */
-int mhip_ctx_band_stats(mhip_ctx *c, mhip_stat_record *records)
+/* per-label records over the OWNED rows of a band, indexed by GLOBAL label (after mhip_ctx_band_relabel).  They stay on
+ * the device (nlabels_global + 1 entries: too many to ship per band); the launcher fetches the slice of the labels this
+ * band numbered, the few labels that cross a band boundary, and the sparse foreign watershed counts, and merges those
+ * (distributed.BandPipeline).  which: 0 = label_stats of the depths, 1 = bincount of the watersheds, 2 = first arg-max of
+ * the accumulated flow (rows are GLOBAL raster rows, -1 when the label has no cell in this band) */
+namespace {
+__global__ void global_rows_kernel(mhip_index_record *rec, int64_t n, int64_t row0)
 {
-    MH_ARG(c && records && c->have[MHIP_R_LABELS] && c->have[MHIP_R_DEPTHS] && c->nlabels >= 0, "ctx_band_stats needs depths and global labels");
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && rec[i].row >= 0) rec[i].row += row0;
+}
+__global__ void gather_bytes_kernel(const char *src, const int64_t *ids, int64_t nids, int elem, char *dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nids * elem) return;
+    dst[i] = src[ids[i / elem] * elem + i % elem];
+}
+// (id, count) pairs with count > 0 and id outside [lo, hi], id != 0
+__global__ void foreign_counts_kernel(const int64_t *cnt, int64_t n, int64_t lo, int64_t hi, int64_t cap, int64_t *ids, int64_t *vals,
+                                      unsigned long long *nout)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= 0 || i >= n || (i >= lo && i <= hi)) return;
+    const int64_t v = cnt[i];
+    if (v <= 0) return;
+    const unsigned long long k = atomicAdd(nout, 1ull);
+    if ((int64_t)k < cap) {
+        ids[k] = i;
+        vals[k] = v;
+    }
+}
+}  // namespace
+
+static size_t band_record_size(int which) { return which == 0 ? sizeof(mhip_stat_record) : which == 1 ? 8 : sizeof(mhip_index_record); }
+static DevBuf &band_record_buf(mhip_ctx *c, int which) { return which == 0 ? c->stats : which == 1 ? c->ws_counts : c->pour; }
+
+int mhip_ctx_band_records(mhip_ctx *c, int which)
+{
+    MH_ARG(c && which >= 0 && which <= 2 && c->have[MHIP_R_LABELS] && c->nlabels >= 0, "ctx_band_records(ctx, which) needs global labels");
     MH_HIP(hipSetDevice(c->device));
-    const int64_t off = c->W * c->ht, n = c->H_owned * c->W;
-    DevBuf rec;
-    MH_TRY(rec.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1)));
-    MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, n, c->nlabels,
-                           rec.as<mhip_stat_record>(), c->stream, c->W));
-    MH_HIP(hipMemcpyAsync(records, rec.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    const int64_t off = c->W * c->ht, n = c->H_owned * c->W, nrec = c->nlabels + 1;
+    DevBuf &buf = band_record_buf(c, which);
+    MH_TRY(buf.alloc(band_record_size(which) * (size_t)nrec));
+    if (which == 0) {
+        MH_ARG(c->have[MHIP_R_DEPTHS], "label_stats needs the depths");
+        MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, n, c->nlabels,
+                               buf.as<mhip_stat_record>(), c->stream, c->W));
+    } else if (which == 1) {
+        MH_ARG(c->have[MHIP_R_WATERSHEDS], "watershed counts need the watersheds");
+        MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, buf.as<int64_t>(), c->stream, c->W));
+    } else {
+        MH_ARG(c->have[MHIP_R_ACCUM], "pour points need the accumulated flow");
+        MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
+                             true, buf.as<mhip_index_record>(), c->stream));
+        hipLaunchKernelGGL(global_rows_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, c->stream, buf.as<mhip_index_record>(), nrec,
+                           c->row0);
+        MH_HIP(hipGetLastError());
+    }
+    return MHIP_OK;
+}
+
+/* records [first, first + count) of the last mhip_ctx_band_records(which) */
+int mhip_ctx_band_fetch(mhip_ctx *c, int which, int64_t first, int64_t count, void *out)
+{
+    MH_ARG(c && which >= 0 && which <= 2 && band_record_buf(c, which).p && first >= 0 && count >= 0 && first + count <= c->nlabels + 1 &&
+               (out || count == 0), "ctx_band_fetch(ctx, which, first, count, out)");
+    if (count == 0) return MHIP_OK;
+    MH_HIP(hipSetDevice(c->device));
+    const size_t e = band_record_size(which);
+    MH_HIP(hipMemcpyAsync(out, band_record_buf(c, which).as<char>() + e * (size_t)first, e * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     return MHIP_OK;
 }
 
-int mhip_ctx_band_watershed_counts(mhip_ctx *c, int64_t *counts)
+/* records at the given labels (any order) */
+int mhip_ctx_band_gather(mhip_ctx *c, int which, const int64_t *ids, int64_t nids, void *out)
 {
-    MH_ARG(c && counts && c->have[MHIP_R_WATERSHEDS] && c->nlabels >= 0, "ctx_band_watershed_counts needs watersheds");
+    MH_ARG(c && which >= 0 && which <= 2 && band_record_buf(c, which).p && nids >= 0 && ((ids && out) || nids == 0), "ctx_band_gather");
+    if (nids == 0) return MHIP_OK;
+    for (int64_t k = 0; k < nids; ++k) MH_ARG(ids[k] >= 0 && ids[k] <= c->nlabels, "ctx_band_gather: label outside [0, nlabels]");
     MH_HIP(hipSetDevice(c->device));
-    const int64_t off = c->W * c->ht, n = c->H_owned * c->W;
-    DevBuf cnt;
-    MH_TRY(cnt.alloc(8 * (size_t)(c->nlabels + 1)));
-    MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, cnt.as<int64_t>(), c->stream, c->W));
-    MH_HIP(hipMemcpyAsync(counts, cnt.p, 8 * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
+    const int e = (int)band_record_size(which);
+    DevBuf d_ids, d_out;
+    MH_TRY(d_ids.alloc(8 * (size_t)nids));
+    MH_TRY(d_out.alloc((size_t)e * (size_t)nids));
+    MH_HIP(hipMemcpyAsync(d_ids.p, ids, 8 * (size_t)nids, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(gather_bytes_kernel, dim3((unsigned)cdiv(nids * e, 256)), dim3(256), 0, c->stream, band_record_buf(c, which).as<char>(),
+                       d_ids.as<int64_t>(), nids, e, d_out.as<char>());
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(out, d_out.p, (size_t)e * (size_t)nids, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
     return MHIP_OK;
 }
 
-/* arg-max of the accumulated flow per label over the owned rows; rows are GLOBAL raster rows (-1 when the label has no
- * cell in this band) */
-int mhip_ctx_band_pourpoints(mhip_ctx *c, mhip_index_record *records)
+/* watershed counts of labels OUTSIDE [lo, hi] (and != 0) that are non-zero in this band: up to `cap` (id, count) pairs,
+ * *nfound = how many there are (call again with a larger cap if it exceeds cap) */
+int mhip_ctx_band_foreign_counts(mhip_ctx *c, int64_t lo, int64_t hi, int64_t cap, int64_t *ids, int64_t *counts, int64_t *nfound)
 {
-    MH_ARG(c && records && c->have[MHIP_R_LABELS] && c->have[MHIP_R_ACCUM] && c->nlabels >= 0, "ctx_band_pourpoints needs labels and accumulated flow");
+    MH_ARG(c && c->ws_counts.p && cap >= 0 && nfound && ((ids && counts) || cap == 0), "ctx_band_foreign_counts");
     MH_HIP(hipSetDevice(c->device));
-    const int64_t off = c->W * c->ht;
-    DevBuf rec;
-    MH_TRY(rec.alloc(sizeof(mhip_index_record) * (size_t)(c->nlabels + 1)));
-    MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
-                         true, rec.as<mhip_index_record>(), c->stream));
-    std::vector<mhip_index_record> h((size_t)(c->nlabels + 1));
-    MH_HIP(hipMemcpyAsync(h.data(), rec.p, sizeof(mhip_index_record) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    DevBuf d_ids, d_vals, d_n;
+    MH_TRY(d_ids.alloc(8 * (size_t)(cap + 1)));
+    MH_TRY(d_vals.alloc(8 * (size_t)(cap + 1)));
+    MH_TRY(d_n.alloc(8));
+    MH_HIP(hipMemsetAsync(d_n.p, 0, 8, c->stream));
+    const int64_t nrec = c->nlabels + 1;
+    hipLaunchKernelGGL(foreign_counts_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, c->stream, c->ws_counts.as<int64_t>(), nrec, lo, hi,
+                       cap, d_ids.as<int64_t>(), d_vals.as<int64_t>(), d_n.as<unsigned long long>());
+    MH_HIP(hipGetLastError());
+    unsigned long long k = 0;
+    MH_HIP(hipMemcpyAsync(&k, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
     MH_HIP(hipStreamSynchronize(c->stream));
-    for (size_t k = 0; k < h.size(); ++k) {
-        records[k] = h[k];
-        if (h[k].row >= 0) records[k].row = h[k].row + c->row0;
+    *nfound = (int64_t)k;
+    const int64_t take = (int64_t)k < cap ? (int64_t)k : cap;
+    if (take > 0) {
+        MH_HIP(hipMemcpyAsync(ids, d_ids.p, 8 * (size_t)take, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipMemcpyAsync(counts, d_vals.p, 8 * (size_t)take, hipMemcpyDeviceToHost, c->stream));
+        MH_HIP(hipStreamSynchronize(c->stream));
     }
     return MHIP_OK;
 }

@@ -356,21 +356,33 @@ class HipBand(object):
         _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))
         return v.value
 
-    # per-label records over the OWNED rows, indexed by global label (nlabels + 1 entries)
-    def band_stats(self, nlabels):
-        rec = np.zeros(nlabels + 1, dtype=STAT_DTYPE)
-        _lib.call("mhip_ctx_band_stats", self._ctx, _lib.ptr(rec))
-        return rec
+    # per-label records over the OWNED rows, indexed by global label; they stay on the device, the launcher fetches pieces
+    _REC_DTYPE = (STAT_DTYPE, np.dtype(np.int64), INDEX_DTYPE)      # which = 0 stats, 1 watershed counts, 2 pour points
 
-    def band_watershed_counts(self, nlabels):
-        out = np.zeros(nlabels + 1, dtype=np.int64)
-        _lib.call("mhip_ctx_band_watershed_counts", self._ctx, _lib.ptr(out))
+    def records_compute(self, which):
+        _lib.call("mhip_ctx_band_records", self._ctx, int(which))
+
+    def records_fetch(self, which, first, count):
+        out = np.zeros(int(count), dtype=self._REC_DTYPE[which])
+        _lib.call("mhip_ctx_band_fetch", self._ctx, int(which), _lib.i64(first), _lib.i64(count), _lib.ptr(out))
         return out
 
-    def band_pourpoints(self, nlabels):
-        rec = np.zeros(nlabels + 1, dtype=INDEX_DTYPE)
-        _lib.call("mhip_ctx_band_pourpoints", self._ctx, _lib.ptr(rec))
-        return rec
+    def records_gather(self, which, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        out = np.zeros(ids.size, dtype=self._REC_DTYPE[which])
+        _lib.call("mhip_ctx_band_gather", self._ctx, int(which), _lib.ptr(ids), _lib.i64(ids.size), _lib.ptr(out))
+        return out
+
+    def foreign_counts(self, lo, hi):
+        cap = 1 << 16
+        while True:
+            ids, vals, n = np.zeros(cap, np.int64), np.zeros(cap, np.int64), ctypes.c_int64(0)
+            _lib.call("mhip_ctx_band_foreign_counts", self._ctx, _lib.i64(lo), _lib.i64(hi), _lib.i64(cap), _lib.ptr(ids), _lib.ptr(vals),
+                      ctypes.byref(n))
+            if n.value <= cap:
+                order = np.argsort(ids[:n.value])
+                return ids[:n.value][order], vals[:n.value][order]
+            cap = int(n.value)
 
 
 # ---- the protocol ---------------------------------------------------------------------------------------------------
@@ -577,54 +589,60 @@ class BandPipeline(object):
     # ---- per-label records (reference bluespots.py:159-206 on one raster).  Every rank returns the records of the labels
     # IT numbered (``label_range``, complete after the merge) plus the background record; a label or a watershed that
     # reaches into other bands is merged from their partial records (a handful of rows per exchange).
-    def _own(self, full):
-        lo, hi = self.label_range
-        return {"first_label": lo, "records": full[lo:hi + 1].copy(), "background": full[0].copy()}
-
-    def stats(self):
-        """label.label_stats(depths, labels): min / max / sum / count per bluespot."""
-        rec = self.band.band_stats(self.nlabels)
+    def _merged(self, which, merge, fetch_own=True):
+        """own-range slice of record set `which`, with the labels that live in several bands (and the background) merged
+        by `merge(list of per-rank record arrays) -> array`.  fetch_own=False: compute and merge only (the slice of this
+        band's own labels stays on the device, like the records of the single-GPU pipeline until somebody asks for them)"""
+        b, (lo, hi) = self.band, self.label_range
+        b.records_compute(which)
         ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
-        parts = self.comm.allgather(rec[ids])
-        m = parts[0].copy()
-        for p in parts[1:]:
-            m["min"] = np.minimum(m["min"], p["min"])
-            m["max"] = np.maximum(m["max"], p["max"])
-            m["sum"] = m["sum"] + p["sum"]
-            m["count"] = m["count"] + p["count"]
-        rec[ids] = m
-        return self._own(rec)
+        m = merge(self.comm.allgather(b.records_gather(which, ids)))
+        if not fetch_own:
+            return {"first_label": lo, "records": None, "shared_labels": ids, "shared_records": m, "background": m[0].copy()}
+        own = b.records_fetch(which, lo, hi - lo + 1)
+        sel = (ids >= lo) & (ids <= hi)
+        own[ids[sel] - lo] = m[sel]
+        return {"first_label": lo, "records": own, "background": m[0].copy()}
 
-    def watershed_counts(self):
-        """label.label_count(watersheds): cells per watershed.  A watershed may reach into any band."""
-        cnt = self.band.band_watershed_counts(self.nlabels)
-        lo, hi = self.label_range
-        nz = np.flatnonzero(cnt)
-        foreign = nz[(nz != 0) & ((nz < lo) | (nz > hi))]
-        parts = self.comm.allgather((foreign, cnt[foreign], int(cnt[0])))
+    def stats(self, fetch_own=True):
+        """label.label_stats(depths, labels): min / max / sum / count per bluespot."""
+        def merge(parts):
+            m = parts[0].copy()
+            for p in parts[1:]:
+                m["min"] = np.minimum(m["min"], p["min"])
+                m["max"] = np.maximum(m["max"], p["max"])
+                m["sum"] = m["sum"] + p["sum"]
+                m["count"] = m["count"] + p["count"]
+            return m
+        return self._merged(0, merge, fetch_own)
+
+    def watershed_counts(self, fetch_own=True):
+        """label.label_count(watersheds): cells per watershed.  A watershed may reach into any band, so every rank publishes
+        its non-zero counts of labels it did not number (a sparse handful) and adds what the others found of its own."""
+        b, (lo, hi) = self.band, self.label_range
+        b.records_compute(1)
+        own = b.records_fetch(1, lo, hi - lo + 1) if fetch_own else None
+        fid, fval = b.foreign_counts(lo, hi)
+        bg = int(b.records_fetch(1, 0, 1)[0])
         total0 = 0
-        for r, (ids, vals, c0) in enumerate(parts):
+        for r, (ids, vals, c0) in enumerate(self.comm.allgather((fid, fval, bg))):
             total0 += c0
-            if r == self.comm.rank:
-                continue
-            mine = (ids >= lo) & (ids <= hi)
-            np.add.at(cnt, ids[mine], vals[mine])
-        cnt[0] = total0
-        return self._own(cnt)
+            if r != self.comm.rank and own is not None:
+                mine = (ids >= lo) & (ids <= hi)
+                np.add.at(own, ids[mine] - lo, vals[mine])
+        return {"first_label": lo, "records": own, "background": np.int64(total0)}
 
-    def pourpoints(self):
+    def pourpoints(self, fetch_own=True):
         """label.label_max_index(accum, labels): value, row, col of the first raster cell with the largest accumulated
         flow per bluespot (rows are global)."""
-        rec = self.band.band_pourpoints(self.nlabels)
-        ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
-        parts = self.comm.allgather(rec[ids])
-        m = parts[0].copy()
-        for p in parts[1:]:
-            # strict '>' with the first raster position on ties: bands are in raster order, so an earlier band wins ties
-            better = (p["value"] > m["value"]) | ((m["row"] < 0) & (p["row"] >= 0))
-            m[better] = p[better]
-        rec[ids] = m
-        return self._own(rec)
+        def merge(parts):
+            m = parts[0].copy()
+            for p in parts[1:]:
+                # strict '>' with the first raster position on ties: bands are in raster order, so an earlier band wins ties
+                better = (p["value"] > m["value"]) | ((m["row"] < 0) & (p["row"] >= 0))
+                m[better] = p[better]
+            return m
+        return self._merged(2, merge, fetch_own)
 
     def download(self, name):
         return self.band.download(name)

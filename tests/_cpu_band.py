@@ -184,6 +184,7 @@ class CpuBand(object):
 
     def relabel(self, lut, nlabels_global):
         self.r["labels"][...] = np.asarray(lut)[self.r["labels"]]
+        self.nlabels_global = int(nlabels_global)
 
     def watershed_local(self):
         ws = self._raster("watersheds")
@@ -226,13 +227,27 @@ class CpuBand(object):
     def _owned(self, name):
         return self.r[name][self.ht:self.ht + self.nrows]
 
-    def band_stats(self, nlabels):
-        return oracle.label_stats(self._owned("depths"), self._owned("labels"), nlabels)
+    # device-resident record sets of HipBand, here plain arrays: which = 0 stats, 1 watershed counts, 2 pour points
+    def records_compute(self, which):
+        n = self.nlabels_global
+        if which == 0:
+            rec = oracle.label_stats(self._owned("depths"), self._owned("labels"), n)
+        elif which == 1:
+            rec = np.bincount(self._owned("watersheds").ravel(), minlength=n + 1).astype(np.int64)
+        else:
+            rec = oracle.label_max_index(self._owned("accum"), self._owned("labels"), n)
+            rec["row"] = np.where(rec["row"] >= 0, rec["row"] + self.row0, rec["row"])
+        self._rec = getattr(self, "_rec", {})
+        self._rec[which] = rec
 
-    def band_watershed_counts(self, nlabels):
-        return np.bincount(self._owned("watersheds").ravel(), minlength=nlabels + 1).astype(np.int64)
+    def records_fetch(self, which, first, count):
+        return self._rec[which][first:first + count].copy()
 
-    def band_pourpoints(self, nlabels):
-        rec = oracle.label_max_index(self._owned("accum"), self._owned("labels"), nlabels)
-        rec["row"] = np.where(rec["row"] >= 0, rec["row"] + self.row0, rec["row"])
-        return rec
+    def records_gather(self, which, ids):
+        return self._rec[which][np.asarray(ids, dtype=np.int64)].copy()
+
+    def foreign_counts(self, lo, hi):
+        cnt = self._rec[1]
+        ids = np.flatnonzero(cnt)
+        ids = ids[(ids != 0) & ((ids < lo) | (ids > hi))]
+        return ids.astype(np.int64), cnt[ids]

@@ -164,6 +164,8 @@ def main():
                 n * world, n, world, "GPU->GPU over RCCL send/recv" if getattr(comm, "device_rows", False) else "host-staged over gloo")
             stage_names = ["fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints"]
         except Exception as e:  # pragma: no cover - only on a multi-GPU node
+            import traceback
+            traceback.print_exc()
             band = None
             parallelism = "replicas only (band mode failed: %s)" % (str(e)[:80],)
     pipe = None
@@ -175,23 +177,14 @@ def main():
 
     def step(record):
         if band is not None:
-            # the per-label records are computed and merged across bands like in the single-GPU chain; the slice of a
-            # band's own labels stays on the device (nobody downloads records inside the timed loop at N = 1 either)
-            def label_and_stats():
-                band.label()
-                band.stats(fetch_own=False)
-
-            def watershed_and_counts():
-                band.watershed()
-                band.watershed_counts(fetch_own=False)
-
-            for name, fn in (("fill", band.fill), ("noflat", band.noflat), ("flowdir", band.flowdir), ("accum", band.accum),
-                             ("label", label_and_stats), ("watershed", watershed_and_counts),
-                             ("pourpoints", lambda: band.pourpoints(fetch_own=False))):
-                t = time.perf_counter()
-                fn()
-                if record:
-                    stage_ms[name] += (time.perf_counter() - t) * 1e3
+            # the whole chain with the labelling branch on a second host thread / side stream (BandPipeline.run_chain); the
+            # per-label records are computed and merged across bands like in the single-GPU chain, the slice of a band's
+            # own labels stays on the device (nobody downloads records inside the timed loop at N = 1 either)
+            tm = {}
+            band.run_chain(records=True, fetch_own=False, overlap=os.environ.get("MALSTROEM_BAND_OVERLAP", "1") != "0", timings=tm)
+            if record:
+                for name in stage_names:
+                    stage_ms[name] += tm.get(name, 0.0)
         else:
             # one request for the whole chain: the library runs the bluespot branch (label, watershed) on a second
             # stream next to no-flats fill -> D8 -> accumulation ("stage DAG"); all labels are kept

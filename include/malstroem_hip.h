@@ -154,9 +154,19 @@ int mhip_ctx_zero_raster(mhip_ctx *ctx, int which);
 /* labelling on a band: local components -> host merges the boundary equivalences of all bands -> global LUT */
 int mhip_ctx_band_ccl_local(mhip_ctx *ctx, int64_t *nlocal);
 int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int64_t nlabels_global);
+/* the same without a dense table: local label l -> offset + l - #(dropped labels < l); dropped[k] (sorted: the local labels
+ * numbered by another band, or without an owned cell) -> target[k] */
+int mhip_ctx_band_relabel_sparse(mhip_ctx *ctx, int64_t nlocal, int64_t offset, const int32_t *dropped, const int32_t *target,
+                                 int64_t ndropped, int64_t nlabels_global);
 /* watersheds on a band: local pointer jumping with pseudo labels on the halo rows, then a boundary LUT */
 int mhip_ctx_band_watershed_local(mhip_ctx *ctx);
 int mhip_ctx_band_apply_neg_lut(mhip_ctx *ctx, int which, const int32_t *lut, int64_t n);
+/* Two host threads per band (the labelling branch next to no-flats fill -> D8 -> accumulation, like the stage DAG of
+ * mhip_ctx_run): the thread that drives the labelling branch calls _side_begin after the plain fill has been issued and
+ * _side_end when it is done; in between, the band / data-movement entry points IT calls use the context's side stream.
+ * _side_end returns when the side stream has drained, so the caller only has to join the thread. */
+int mhip_ctx_side_begin(mhip_ctx *ctx);
+int mhip_ctx_side_end(mhip_ctx *ctx);
 /* per-label records over the OWNED rows of the band, indexed by GLOBAL label (reference bluespots.py:159-206 on one
  * raster).  which: 0 = label_stats of the depths (mhip_stat_record), 1 = np.bincount of the watersheds (int64), 2 = first
  * arg-max of the accumulated flow (mhip_index_record, rows are global raster rows).  _records computes nlabels_global + 1

@@ -39,13 +39,14 @@ SYMBOLS = [
     "mhip_ctx_band_info", "mhip_ctx_get_edge_row", "mhip_ctx_set_halo_row", "mhip_ctx_get_edge_row_dev",
     "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_end",
-    "mhip_ctx_zero_raster", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_watershed_local",
+    "mhip_ctx_zero_raster", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_watershed_local",
     "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_records", "mhip_ctx_band_fetch", "mhip_ctx_band_gather",
-    "mhip_ctx_band_foreign_counts",
+    "mhip_ctx_band_foreign_counts", "mhip_ctx_side_begin", "mhip_ctx_side_end",
 ]
 
 _lib = None
-_lock = threading.Lock()   # ctypes releases the GIL; the library keeps per-call state, so serialise calls
+# ctypes releases the GIL.  The library is thread safe (thread-local error text, locked buffer pool); a context is driven by
+# one thread at a time, except for the side-stream bracket mhip_ctx_side_begin / _end.
 
 
 def build(force=False):
@@ -99,7 +100,5 @@ def i64(v):
 
 
 def call(name, *args):
-    lib = load()
-    with _lock:
-        rc = getattr(lib, name)(*args)
+    rc = getattr(load(), name)(*args)
     check(rc, name)

@@ -480,14 +480,46 @@ int mhip_ctx_destroy(mhip_ctx *c)
     return MHIP_OK;
 }
 
+// Band launcher with two host threads (distributed.BandPipeline.run_chain): the thread that drives the labelling branch
+// brackets its calls with mhip_ctx_side_begin / _end; in between, the data-movement and band entry points it calls run on
+// the context's side stream, next to the fills the main thread keeps launching on the main stream.
+static thread_local mhip_ctx *t_side_ctx = nullptr;
+static hipStream_t cs(mhip_ctx *c) { return (t_side_ctx == c && c->stream_b) ? c->stream_b : c->stream; }
+
+int mhip_ctx_side_begin(mhip_ctx *c)
+{
+    MH_ARG(c, "ctx");
+    MH_HIP(hipSetDevice(c->device));
+    if (!c->stream_b) MH_HIP(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    if (!c->ev_fork) {
+        MH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_label, hipEventDisableTiming));
+    }
+    MH_HIP(hipEventRecord(c->ev_fork, c->stream));          // everything the main stream has been given so far ...
+    MH_HIP(hipStreamWaitEvent(c->stream_b, c->ev_fork, 0));  // ... is visible to the side stream
+    t_side_ctx = c;
+    return MHIP_OK;
+}
+
+int mhip_ctx_side_end(mhip_ctx *c)
+{
+    MH_ARG(c && t_side_ctx == c, "ctx_side_end without ctx_side_begin on this thread");
+    MH_HIP(hipSetDevice(c->device));
+    MH_HIP(hipStreamSynchronize(c->stream_b));
+    t_side_ctx = nullptr;
+    return MHIP_OK;
+}
+
 int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
 {
     MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_, "ctx_upload(ctx, which, host)");
     MH_HIP(hipSetDevice(c->device));
     MH_TRY(ctx_raster(c, which));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
-    MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * c->ht, host, rowb * (size_t)c->H_owned, hipMemcpyHostToDevice, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * c->ht, host, rowb * (size_t)c->H_owned, hipMemcpyHostToDevice, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     c->have[which] = true;
     if (which == MHIP_R_DEM)  // a new DEM invalidates everything derived from the previous one
         for (int k = 0; k < MHIP_R_COUNT_; ++k)
@@ -504,8 +536,8 @@ int mhip_ctx_download(mhip_ctx *c, int which, void *host)
     MH_ARG(c->have[which], "raster has not been computed or uploaded");
     MH_HIP(hipSetDevice(c->device));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
-    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * c->ht, rowb * (size_t)c->H_owned, hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * c->ht, rowb * (size_t)c->H_owned, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     return MHIP_OK;
 }
 
@@ -529,8 +561,8 @@ int mhip_ctx_get_edge_row(mhip_ctx *c, int which, int side, void *host)
     MH_HIP(hipSetDevice(c->device));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     const int64_t row = side == 0 ? c->ht : side == 1 ? c->ht + c->H_owned - 1 : side == 2 ? 0 : c->H - 1;
-    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     return MHIP_OK;
 }
 
@@ -544,9 +576,9 @@ int mhip_ctx_set_halo_row(mhip_ctx *c, int which, int side, const void *host, in
     const int64_t row = side == 0 ? 0 : c->H - 1;
     DevBuf tmp;
     MH_TRY(tmp.alloc(rowb));
-    MH_HIP(hipMemcpyAsync(tmp.p, host, rowb, hipMemcpyHostToDevice, c->stream));
+    MH_HIP(hipMemcpyAsync(tmp.p, host, rowb, hipMemcpyHostToDevice, cs(c)));
     int ch = 0;
-    MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, tmp.p, (int64_t)rowb, &ch, c->stream));
+    MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, tmp.p, (int64_t)rowb, &ch, cs(c)));
     if (changed) *changed = ch;
     return MHIP_OK;
 }
@@ -560,8 +592,8 @@ int mhip_ctx_get_edge_row_dev(mhip_ctx *c, int which, int side, void *dev_dst)
     MH_HIP(hipSetDevice(c->device));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     const int64_t row = side == 0 ? c->ht : side == 1 ? c->ht + c->H_owned - 1 : side == 2 ? 0 : c->H - 1;
-    MH_HIP(hipMemcpyAsync(dev_dst, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToDevice, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));   // the transport reads the buffer on its own stream
+    MH_HIP(hipMemcpyAsync(dev_dst, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToDevice, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));   // the transport reads the buffer on its own stream
     return MHIP_OK;
 }
 
@@ -574,7 +606,7 @@ int mhip_ctx_set_halo_row_dev(mhip_ctx *c, int which, int side, const void *dev_
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     const int64_t row = side == 0 ? 0 : c->H - 1;
     int ch = 0;
-    MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, dev_src, (int64_t)rowb, &ch, c->stream));
+    MH_TRY(row_update_dev(c->r[which].as<char>() + rowb * row, dev_src, (int64_t)rowb, &ch, cs(c)));
     if (changed) *changed = ch;
     return MHIP_OK;
 }
@@ -584,7 +616,7 @@ int mhip_ctx_zero_raster(mhip_ctx *c, int which)
     MH_ARG(c && which >= 0 && which < MHIP_R_COUNT_, "ctx_zero_raster(ctx, which)");
     MH_HIP(hipSetDevice(c->device));
     MH_TRY(ctx_raster(c, which));
-    MH_HIP(hipMemsetAsync(c->r[which].p, 0, raster_elem(which) * (size_t)(c->H * c->W), c->stream));
+    MH_HIP(hipMemsetAsync(c->r[which].p, 0, raster_elem(which) * (size_t)(c->H * c->W), cs(c)));
     return MHIP_OK;
 }
 
@@ -596,7 +628,7 @@ int mhip_ctx_band_ccl_local(mhip_ctx *c, int64_t *nlocal)
     MH_TRY(ctx_raster(c, MHIP_R_LABELS));
     if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)(c->H * c->W)));
     MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), c->H, c->W,
-                        nlocal, c->stream));
+                        nlocal, cs(c)));
     c->nlabels_raw = *nlocal;
     c->have[MHIP_R_LABELS] = true;
     c->labels_filtered = false;
@@ -610,8 +642,31 @@ int mhip_ctx_band_relabel(mhip_ctx *c, const int32_t *lut, int64_t nlocal, int64
     MH_HIP(hipSetDevice(c->device));
     DevBuf d_lut;
     MH_TRY(d_lut.alloc(4 * (size_t)(nlocal + 1)));
-    MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)(nlocal + 1), hipMemcpyHostToDevice, c->stream));
-    MH_TRY(relabel_lut_dev(c->r[MHIP_R_LABELS].as<int32_t>(), d_lut.as<int32_t>(), nlocal, c->H * c->W, c->stream));
+    MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)(nlocal + 1), hipMemcpyHostToDevice, cs(c)));
+    MH_TRY(relabel_lut_dev(c->r[MHIP_R_LABELS].as<int32_t>(), d_lut.as<int32_t>(), nlocal, c->H * c->W, cs(c)));
+    c->nlabels = c->nlabels_raw = nlabels_global;
+    c->labels_filtered = true;
+    return MHIP_OK;
+}
+
+/* the same without a dense LUT: local label l -> offset + l - #(dropped labels < l); dropped[k] (sorted, the local labels that
+ * are numbered by another band or own no cell here) -> target[k] */
+int mhip_ctx_band_relabel_sparse(mhip_ctx *c, int64_t nlocal, int64_t offset, const int32_t *dropped, const int32_t *target,
+                                 int64_t ndropped, int64_t nlabels_global)
+{
+    MH_ARG(c && nlocal >= 0 && ndropped >= 0 && (ndropped == 0 || (dropped && target)) && c->have[MHIP_R_LABELS] &&
+               offset + nlocal < (int64_t)INT32_MAX, "ctx_band_relabel_sparse");
+    for (int64_t k = 1; k < ndropped; ++k) MH_ARG(dropped[k - 1] < dropped[k], "ctx_band_relabel_sparse: dropped labels must be sorted and unique");
+    MH_HIP(hipSetDevice(c->device));
+    DevBuf d_d, d_t;
+    MH_TRY(d_d.alloc(4 * (size_t)(ndropped + 1)));
+    MH_TRY(d_t.alloc(4 * (size_t)(ndropped + 1)));
+    if (ndropped) {
+        MH_HIP(hipMemcpyAsync(d_d.p, dropped, 4 * (size_t)ndropped, hipMemcpyHostToDevice, cs(c)));
+        MH_HIP(hipMemcpyAsync(d_t.p, target, 4 * (size_t)ndropped, hipMemcpyHostToDevice, cs(c)));
+    }
+    MH_TRY(relabel_sparse_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, nlocal, (int32_t)offset, d_d.as<int32_t>(), d_t.as<int32_t>(),
+                              (int32_t)ndropped, cs(c)));
     c->nlabels = c->nlabels_raw = nlabels_global;
     c->labels_filtered = true;
     return MHIP_OK;
@@ -624,9 +679,9 @@ int mhip_ctx_band_watershed_local(mhip_ctx *c)
     MH_HIP(hipSetDevice(c->device));
     MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
     const size_t n = (size_t)(c->H * c->W);
-    MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * n, hipMemcpyDeviceToDevice, c->stream));
-    MH_TRY(band_pseudo_labels_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, c->ht, c->hb, c->stream));
-    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, 0, c->stream, true));
+    MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * n, hipMemcpyDeviceToDevice, cs(c)));
+    MH_TRY(band_pseudo_labels_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, c->ht, c->hb, cs(c)));
+    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, 0, cs(c), true));
     c->have[MHIP_R_WATERSHEDS] = true;
     return MHIP_OK;
 }
@@ -638,9 +693,9 @@ int mhip_ctx_band_apply_neg_lut(mhip_ctx *c, int which, const int32_t *lut, int6
     MH_HIP(hipSetDevice(c->device));
     DevBuf d_lut;
     MH_TRY(d_lut.alloc(4 * (size_t)n));
-    MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    MH_TRY(negative_lut_dev(c->r[which].as<int32_t>(), c->H * c->W, d_lut.as<int32_t>(), n, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)n, hipMemcpyHostToDevice, cs(c)));
+    MH_TRY(negative_lut_dev(c->r[which].as<int32_t>(), c->H * c->W, d_lut.as<int32_t>(), n, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     return MHIP_OK;
 }
 
@@ -690,15 +745,15 @@ int mhip_ctx_band_records(mhip_ctx *c, int which)
     if (which == 0) {
         MH_ARG(c->have[MHIP_R_DEPTHS], "label_stats needs the depths");
         MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, n, c->nlabels,
-                               buf.as<mhip_stat_record>(), c->stream, c->W));
+                               buf.as<mhip_stat_record>(), cs(c), c->W));
     } else if (which == 1) {
         MH_ARG(c->have[MHIP_R_WATERSHEDS], "watershed counts need the watersheds");
-        MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, buf.as<int64_t>(), c->stream, c->W));
+        MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, buf.as<int64_t>(), cs(c), c->W));
     } else {
         MH_ARG(c->have[MHIP_R_ACCUM], "pour points need the accumulated flow");
         MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
-                             true, buf.as<mhip_index_record>(), c->stream));
-        hipLaunchKernelGGL(global_rows_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, c->stream, buf.as<mhip_index_record>(), nrec,
+                             true, buf.as<mhip_index_record>(), cs(c)));
+        hipLaunchKernelGGL(global_rows_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, cs(c), buf.as<mhip_index_record>(), nrec,
                            c->row0);
         MH_HIP(hipGetLastError());
     }
@@ -713,8 +768,8 @@ int mhip_ctx_band_fetch(mhip_ctx *c, int which, int64_t first, int64_t count, vo
     if (count == 0) return MHIP_OK;
     MH_HIP(hipSetDevice(c->device));
     const size_t e = band_record_size(which);
-    MH_HIP(hipMemcpyAsync(out, band_record_buf(c, which).as<char>() + e * (size_t)first, e * (size_t)count, hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(out, band_record_buf(c, which).as<char>() + e * (size_t)first, e * (size_t)count, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     return MHIP_OK;
 }
 
@@ -729,12 +784,12 @@ int mhip_ctx_band_gather(mhip_ctx *c, int which, const int64_t *ids, int64_t nid
     DevBuf d_ids, d_out;
     MH_TRY(d_ids.alloc(8 * (size_t)nids));
     MH_TRY(d_out.alloc((size_t)e * (size_t)nids));
-    MH_HIP(hipMemcpyAsync(d_ids.p, ids, 8 * (size_t)nids, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(gather_bytes_kernel, dim3((unsigned)cdiv(nids * e, 256)), dim3(256), 0, c->stream, band_record_buf(c, which).as<char>(),
+    MH_HIP(hipMemcpyAsync(d_ids.p, ids, 8 * (size_t)nids, hipMemcpyHostToDevice, cs(c)));
+    hipLaunchKernelGGL(gather_bytes_kernel, dim3((unsigned)cdiv(nids * e, 256)), dim3(256), 0, cs(c), band_record_buf(c, which).as<char>(),
                        d_ids.as<int64_t>(), nids, e, d_out.as<char>());
     MH_HIP(hipGetLastError());
-    MH_HIP(hipMemcpyAsync(out, d_out.p, (size_t)e * (size_t)nids, hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(out, d_out.p, (size_t)e * (size_t)nids, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     return MHIP_OK;
 }
 
@@ -748,20 +803,20 @@ int mhip_ctx_band_foreign_counts(mhip_ctx *c, int64_t lo, int64_t hi, int64_t ca
     MH_TRY(d_ids.alloc(8 * (size_t)(cap + 1)));
     MH_TRY(d_vals.alloc(8 * (size_t)(cap + 1)));
     MH_TRY(d_n.alloc(8));
-    MH_HIP(hipMemsetAsync(d_n.p, 0, 8, c->stream));
+    MH_HIP(hipMemsetAsync(d_n.p, 0, 8, cs(c)));
     const int64_t nrec = c->nlabels + 1;
-    hipLaunchKernelGGL(foreign_counts_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, c->stream, c->ws_counts.as<int64_t>(), nrec, lo, hi,
+    hipLaunchKernelGGL(foreign_counts_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, cs(c), c->ws_counts.as<int64_t>(), nrec, lo, hi,
                        cap, d_ids.as<int64_t>(), d_vals.as<int64_t>(), d_n.as<unsigned long long>());
     MH_HIP(hipGetLastError());
     unsigned long long k = 0;
-    MH_HIP(hipMemcpyAsync(&k, d_n.p, 8, hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(hipMemcpyAsync(&k, d_n.p, 8, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
     *nfound = (int64_t)k;
     const int64_t take = (int64_t)k < cap ? (int64_t)k : cap;
     if (take > 0) {
-        MH_HIP(hipMemcpyAsync(ids, d_ids.p, 8 * (size_t)take, hipMemcpyDeviceToHost, c->stream));
-        MH_HIP(hipMemcpyAsync(counts, d_vals.p, 8 * (size_t)take, hipMemcpyDeviceToHost, c->stream));
-        MH_HIP(hipStreamSynchronize(c->stream));
+        MH_HIP(hipMemcpyAsync(ids, d_ids.p, 8 * (size_t)take, hipMemcpyDeviceToHost, cs(c)));
+        MH_HIP(hipMemcpyAsync(counts, d_vals.p, 8 * (size_t)take, hipMemcpyDeviceToHost, cs(c)));
+        MH_HIP(hipStreamSynchronize(cs(c)));
     }
     return MHIP_OK;
 }
@@ -771,7 +826,7 @@ int mhip_ctx_dem_minmax(mhip_ctx *c, float *mn, float *mx, int32_t *has_nan)
     MH_ARG(c && mn && mx && has_nan && c->have[MHIP_R_DEM], "ctx_dem_minmax needs the DEM");
     MH_HIP(hipSetDevice(c->device));
     int hn = 0;
-    MH_TRY(minmax_dev(c->r[MHIP_R_DEM].as<float>() + c->W * c->ht, c->H_owned * c->W, mn, mx, &hn, c->stream));
+    MH_TRY(minmax_dev(c->r[MHIP_R_DEM].as<float>() + c->W * c->ht, c->H_owned * c->W, mn, mx, &hn, cs(c)));
     *has_nan = hn;
     return MHIP_OK;
 }

@@ -152,6 +152,8 @@ int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_
                 hipStream_t s);
 // label_ops.hip
 int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64_t n, hipStream_t s);
+int relabel_sparse_dev(int32_t *d_labels, int64_t n, int64_t nlocal, int32_t offset, const int32_t *d_dropped, const int32_t *d_target,
+                       int32_t ndropped, hipStream_t s);
 int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask,
                   hipStream_t s);
 // W: raster width if the caller knows it (2-D tiles combine a label's rows before the global atomics), 0 = flat array

@@ -458,6 +458,30 @@ __global__ __launch_bounds__(256) void lut_kernel(int32_t *lab, const int32_t *_
     if (l != 0) lab[i] = lut[l];
 }
 
+// band-local -> global labels without a dense LUT: local label l becomes offset + l - (number of dropped labels below l);
+// a dropped label (sorted `dropped`) becomes its explicit target.  The dropped list is short (labels that touch a band
+// boundary), so the binary search stays in cache.
+__global__ __launch_bounds__(256) void relabel_sparse_kernel(int32_t *lab, int64_t n, int64_t nlocal, int32_t offset,
+                                                            const int32_t *__restrict__ dropped, const int32_t *__restrict__ target,
+                                                            int32_t ndropped, unsigned int *bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = lab[i];
+    if (l < 0 || l > nlocal) {
+        atomicOr(bad, 1u);
+        return;
+    }
+    if (l == 0) return;
+    int32_t lo = 0, hi = ndropped;   // first index with dropped[idx] >= l
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (dropped[mid] < l) lo = mid + 1;
+        else hi = mid;
+    }
+    lab[i] = (lo < ndropped && dropped[lo] == l) ? target[lo] : offset + l - lo;
+}
+
 __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ lab, const uint8_t *__restrict__ keep,
                                                   int64_t nlab, int64_t n, uint8_t *mask, unsigned int *bad)
 {
@@ -587,6 +611,18 @@ int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64
                        bad.as<unsigned int>());
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "relabel_keep");
+}
+
+int relabel_sparse_dev(int32_t *d_labels, int64_t n, int64_t nlocal, int32_t offset, const int32_t *d_dropped, const int32_t *d_target,
+                       int32_t ndropped, hipStream_t s)
+{
+    DevBuf bad;
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    hipLaunchKernelGGL(relabel_sparse_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_labels, n, nlocal, offset, d_dropped, d_target,
+                       ndropped, bad.as<unsigned int>());
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "band_relabel_sparse");
 }
 
 int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask, hipStream_t s)

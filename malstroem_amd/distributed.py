@@ -51,8 +51,16 @@ class Comm(object):
     def allgather(self, obj):
         raise NotImplementedError
 
+    def clone(self):
+        """A second, independent communicator over the same ranks (collective call): the labelling branch of
+        BandPipeline.run_chain talks on it while the main thread keeps using this one."""
+        raise NotImplementedError
+
 
 class SingleComm(Comm):
+    def clone(self):
+        return SingleComm()
+
     def exchange_rows(self, to_up, to_down):
         return None, None
 
@@ -105,6 +113,10 @@ class ThreadComm(Comm):
     def allreduce_max(self, value):
         return max(self.allgather(value))
 
+    def clone(self):
+        w = self.allgather(ThreadComm._World(self.size) if self.rank == 0 else None)[0]   # rank 0's object, shared in-process
+        return ThreadComm(w, self.rank)
+
 
 class TorchComm(Comm):
     """torch.distributed transport on host buffers (gloo).  Plumbing only: no tensor ever reaches a kernel."""
@@ -147,6 +159,9 @@ class TorchComm(Comm):
         out = [None] * self.size
         self._dist.all_gather_object(out, obj, group=self._group)
         return out
+
+    def clone(self):
+        return TorchComm(self._dist.new_group(backend="gloo"))   # host collectives only (RcclComm's rows stay on the original)
 
 
 class RcclComm(TorchComm):
@@ -344,6 +359,13 @@ class HipBand(object):
         lut = np.ascontiguousarray(lut, dtype=np.int32)
         _lib.call("mhip_ctx_band_relabel", self._ctx, _lib.ptr(lut), _lib.i64(lut.size - 1), _lib.i64(nlabels_global))
 
+    def relabel_sparse(self, nlocal, offset, dropped, target, nlabels_global):
+        """local label l -> offset + l - #(dropped < l); dropped[k] (sorted) -> target[k]"""
+        d = np.ascontiguousarray(dropped, dtype=np.int32)
+        t = np.ascontiguousarray(target, dtype=np.int32)
+        _lib.call("mhip_ctx_band_relabel_sparse", self._ctx, _lib.i64(nlocal), _lib.i64(offset), _lib.ptr(d), _lib.ptr(t), _lib.i64(d.size),
+                  _lib.i64(nlabels_global))
+
     def watershed_local(self):
         _lib.call("mhip_ctx_band_watershed_local", self._ctx)
 
@@ -355,6 +377,13 @@ class HipBand(object):
         v = ctypes.c_int64(0)
         _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))
         return v.value
+
+    def side_begin(self):
+        """The calling thread's band calls run on the context's side stream from here on (after everything issued so far)."""
+        _lib.call("mhip_ctx_side_begin", self._ctx)
+
+    def side_end(self):
+        _lib.call("mhip_ctx_side_end", self._ctx)
 
     # per-label records over the OWNED rows, indexed by global label; they stay on the device, the launcher fetches pieces
     _REC_DTYPE = (STAT_DTYPE, np.dtype(np.int64), INDEX_DTYPE)      # which = 0 stats, 1 watershed counts, 2 pour points
@@ -400,6 +429,7 @@ class BandPipeline(object):
         self.has_down = comm.rank < comm.size - 1
         self.exchanges = {"fill": 0, "noflat": 0}
         self.short = self.diag = None
+        self._tls = threading.local()
 
     def close(self):
         self.band.close()
@@ -485,7 +515,7 @@ class BandPipeline(object):
         a LUT.  Returns the global number of labels."""
         import scipy.sparse
         import scipy.sparse.csgraph
-        b, comm, W = self.band, self.comm, self.W
+        b, comm, W = self.band, self._cur_comm(), self.W
         nloc = b.ccl_local()
         rows = dict(nloc=nloc, first=b.get_edge_row("labels", 0), last=b.get_edge_row("labels", 1),
                     top=b.get_edge_row("labels", 2) if self.has_up else None,
@@ -528,24 +558,24 @@ class BandPipeline(object):
         rep_score = np.full(ncls, big, np.int64)
         np.minimum.at(rep_score, cls, score)
         is_rep = score == rep_score[cls]
-        # ---- my LUT: own-numbered labels are all local labels except phantoms and non-representative class members
+        # ---- my numbering: all local labels except the DROPPED ones (phantoms and non-representative class members) keep
+        # their order; kept local label l becomes offset + l - #(dropped labels < l).  Only the (short) dropped list is
+        # ever materialised: the band's labels are rewritten on the device (relabel_sparse).
         mine = node_rank == comm.rank
-        drop = np.zeros(nloc + 1, bool)
-        drop[0] = True
-        drop[node_lab[mine & ~is_rep]] = True
-        keep = ~drop
-        n_own = int(keep.sum())
+        dropped = np.unique(node_lab[mine & ~is_rep]).astype(np.int64)
+        n_own = int(nloc - dropped.size)
         offsets = np.concatenate([[0], np.cumsum(comm.allgather(n_own))])
-        lut = np.zeros(nloc + 1, np.int64)
-        lut[keep] = offsets[comm.rank] + np.arange(1, n_own + 1)
+        off = int(offsets[comm.rank])
+        newlab = lambda l: off + l - np.searchsorted(dropped, l)      # for kept local labels l
         # owners publish the global label of the classes they own; members look it up
         my_reps = mine & is_rep
-        published = comm.allgather((cls[my_reps], lut[node_lab[my_reps]]))
+        published = comm.allgather((cls[my_reps], newlab(node_lab[my_reps])))
         class_label = np.zeros(ncls, np.int64)
         for ids, labs in published:
             class_label[ids] = labs
         members = mine & ~is_rep
-        lut[node_lab[members]] = class_label[cls[members]]
+        target = np.zeros(dropped.size, np.int64)                        # phantoms own no cell here: any value
+        target[np.searchsorted(dropped, node_lab[members])] = class_label[cls[members]]
         # global labels with cells in more than one band (same array on every rank): their records need a merge
         real = ~phantom
         pairs = np.unique(np.stack([cls[real], node_rank[real]], axis=1), axis=0) if real.any() else np.zeros((0, 2), np.int64)
@@ -553,7 +583,7 @@ class BandPipeline(object):
         self.shared_labels = np.unique(class_label[np.flatnonzero(ranks_per_class > 1)]).astype(np.int64)
         self.nlabels = int(offsets[-1])
         self.label_range = (int(offsets[comm.rank]) + 1, int(offsets[comm.rank + 1]))
-        b.relabel(lut.astype(np.int32), self.nlabels)
+        b.relabel_sparse(nloc, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels)
         return self.nlabels
 
     def watershed(self):
@@ -589,6 +619,10 @@ class BandPipeline(object):
     # ---- per-label records (reference bluespots.py:159-206 on one raster).  Every rank returns the records of the labels
     # IT numbered (``label_range``, complete after the merge) plus the background record; a label or a watershed that
     # reaches into other bands is merged from their partial records (a handful of rows per exchange).
+    def _cur_comm(self):
+        """the communicator of the calling thread: the clone inside run_chain's labelling branch, else the main one"""
+        return getattr(self._tls, "comm", None) or self.comm
+
     def _merged(self, which, merge, fetch_own=True):
         """own-range slice of record set `which`, with the labels that live in several bands (and the background) merged
         by `merge(list of per-rank record arrays) -> array`.  fetch_own=False: compute and merge only (the slice of this
@@ -596,7 +630,7 @@ class BandPipeline(object):
         b, (lo, hi) = self.band, self.label_range
         b.records_compute(which)
         ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
-        m = merge(self.comm.allgather(b.records_gather(which, ids)))
+        m = merge(self._cur_comm().allgather(b.records_gather(which, ids)))
         if not fetch_own:
             return {"first_label": lo, "records": None, "shared_labels": ids, "shared_records": m, "background": m[0].copy()}
         own = b.records_fetch(which, lo, hi - lo + 1)
@@ -643,6 +677,73 @@ class BandPipeline(object):
                 m[better] = p[better]
             return m
         return self._merged(2, merge, fetch_own)
+
+    # ---- the whole chain with the stage DAG of mhip_ctx_run: labelling (+ stats) on a second host thread, a second
+    # communicator and the band's side stream, next to no-flats fill -> D8 -> accumulation
+    def run_chain(self, records=True, fetch_own=True, overlap=True, timings=None):
+        """fill, no-flats fill, D8, accumulation, labels, watersheds (+ merged per-label records).  Returns the records dict
+        (None entries when ``records`` is False).  ``timings``: optional dict that receives wall-clock ms per stage."""
+        import time
+        t = {} if timings is None else timings
+
+        def timed(name, fn):
+            t0 = time.perf_counter()
+            r = fn()
+            t[name] = t.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+            return r
+
+        timed("fill", self.fill)
+        out = {"stats": None, "counts": None, "pour": None}
+        if overlap and not hasattr(self, "_comm_b"):
+            self._comm_b = self.comm.clone()
+        err = []
+
+        def label_branch():
+            try:
+                if hasattr(self.band, "side_begin"):
+                    self.band.side_begin()
+                self._tls.comm = self._comm_b
+                timed("label", self.label)
+                if records:
+                    out["stats"] = timed("label", lambda: self.stats(fetch_own))
+            except Exception as e:      # re-raised on the main thread
+                err.append(e)
+            finally:
+                self._tls.comm = None
+                if hasattr(self.band, "side_end"):
+                    try:
+                        self.band.side_end()
+                    except Exception as e:
+                        err.append(e)
+
+        if overlap:
+            # the main thread makes many short library calls (a batch of rounds, a halo swap, a one-float all-reduce ...); with
+            # CPython's default 5 ms switch interval every one of them could wait that long for the GIL while the labelling
+            # thread runs NumPy code
+            import sys
+            old_switch = sys.getswitchinterval()
+            sys.setswitchinterval(1e-4)
+            th = threading.Thread(target=label_branch)
+            th.start()
+        try:
+            timed("noflat", self.noflat)
+            timed("flowdir", self.flowdir)
+            timed("accum", self.accum)
+        finally:
+            if overlap:
+                th.join()
+                sys.setswitchinterval(old_switch)
+        if not overlap:
+            timed("label", self.label)
+            if records:
+                out["stats"] = timed("label", lambda: self.stats(fetch_own))
+        if err:
+            raise err[0]
+        timed("watershed", self.watershed)
+        if records:
+            out["counts"] = timed("watershed", lambda: self.watershed_counts(fetch_own))
+            out["pour"] = timed("pourpoints", lambda: self.pourpoints(fetch_own))
+        return out
 
     def download(self, name):
         return self.band.download(name)

@@ -186,6 +186,13 @@ class CpuBand(object):
         self.r["labels"][...] = np.asarray(lut)[self.r["labels"]]
         self.nlabels_global = int(nlabels_global)
 
+    def relabel_sparse(self, nlocal, offset, dropped, target, nlabels_global):
+        l = np.arange(nlocal + 1, dtype=np.int64)
+        lut = offset + l - np.searchsorted(dropped, l)
+        lut[np.asarray(dropped, dtype=np.int64)] = target
+        lut[0] = 0
+        self.relabel(lut, nlabels_global)
+
     def watershed_local(self):
         ws = self._raster("watersheds")
         ws[...] = self.r["labels"]

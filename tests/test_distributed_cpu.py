@@ -80,16 +80,20 @@ def test_protocol_threadcomm_cpu_backend(nbands):
     def work(comm):
         p = BandPipeline(comm, dem.shape, backend_factory=CpuBand)
         p.upload_dem(dem[p.row0:p.row0 + p.nrows])
-        p.fill()
-        p.noflat()
-        p.flowdir()
-        p.accum()
-        n = p.label()
-        p.watershed()
+        if comm.size == 3:      # stage by stage
+            p.fill()
+            p.noflat()
+            p.flowdir()
+            p.accum()
+            p.label()
+            p.watershed()
+            rec = {"stats": p.stats(), "counts": p.watershed_counts(), "pour": p.pourpoints()}
+        else:                   # the chain with the labelling branch on a second thread / communicator
+            rec = p.run_chain()
         o = {k: p.download(k) for k in KEYS}
         o["short_diag"] = (p.short, p.diag)
-        o["nlabels"] = n
-        o["stats"], o["counts"], o["pour"] = p.stats(), p.watershed_counts(), p.pourpoints()
+        o["nlabels"] = p.nlabels
+        o.update(rec)
         out[comm.rank] = o
 
     threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
@@ -124,7 +128,9 @@ dist.barrier(); dist.destroy_process_group()
 WORKER_DEVROWS = WORKER.replace("from malstroem_amd.distributed import BandPipeline, TorchComm",
                                 "from malstroem_amd.distributed import BandPipeline, RcclComm").replace(
     "p = BandPipeline(TorchComm(), dem.shape, backend_factory=CpuBand)",
-    "comm = RcclComm.create('cpu', backend='gloo')\nassert comm.device_rows\np = BandPipeline(comm, dem.shape, backend_factory=CpuBand)")
+    "comm = RcclComm.create('cpu', backend='gloo')\nassert comm.device_rows\np = BandPipeline(comm, dem.shape, backend_factory=CpuBand)").replace(
+    "p.fill(); p.noflat(); p.flowdir(); p.accum(); n = p.label(); p.watershed()",
+    "p.run_chain(); n = p.nlabels   # labelling branch on a second thread and a cloned (gloo) communicator")
 
 
 @pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_DEVROWS)], ids=["host_rows_2", "device_row_protocol_3"])

@@ -21,17 +21,13 @@ def run_bands(dem, nbands):
         try:
             p = BandPipeline(comm, dem.shape, device=0)
             p.upload_dem(dem[p.row0:p.row0 + p.nrows])
-            p.fill()
-            p.noflat()
-            p.flowdir()
-            p.accum()
-            n = p.label()
-            p.watershed()
+            rec = p.run_chain(overlap=comm.size != 3)      # two host threads per band (3 bands: one after the other)
+            n = p.nlabels
             out[comm.rank] = {k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")}
             out[comm.rank]["nlabels"] = n
             out[comm.rank]["short_diag"] = (p.short, p.diag)
             out[comm.rank]["exchanges"] = dict(p.exchanges)
-            out[comm.rank]["stats"], out[comm.rank]["counts"], out[comm.rank]["pour"] = p.stats(), p.watershed_counts(), p.pourpoints()
+            out[comm.rank].update(rec)
             p.close()
         except Exception as e:  # pragma: no cover
             err.append(e)

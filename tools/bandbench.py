@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=8192)
 ap.add_argument("--bands", type=int, default=2)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--chain", choices=["stages", "serial", "overlap"], default="stages", help="stage by stage, or BandPipeline.run_chain")
 ap.add_argument("--profile", action="store_true", help="cProfile of rank 0's last repetition")
 args = ap.parse_args()
 tile = fbm(args.size, beta=2.0)
@@ -28,11 +29,17 @@ def work(comm):
             import cProfile
             prof = cProfile.Profile()
             prof.enable()
-        for name, fn in (("fill", p.fill), ("noflat", p.noflat), ("flowdir", p.flowdir), ("accum", p.accum), ("label", p.label), ("watershed", p.watershed)):
-            t0 = time.perf_counter()
-            fn()
-            t[name] = round((time.perf_counter() - t0) * 1e3, 1)
-        t["total"] = round(sum(t.values()), 1)
+        t_all = time.perf_counter()
+        if args.chain == "stages":
+            for name, fn in (("fill", p.fill), ("noflat", p.noflat), ("flowdir", p.flowdir), ("accum", p.accum), ("label", p.label), ("watershed", p.watershed)):
+                t0 = time.perf_counter()
+                fn()
+                t[name] = round((time.perf_counter() - t0) * 1e3, 1)
+        else:
+            tm = {}
+            p.run_chain(records=True, fetch_own=False, overlap=args.chain == "overlap", timings=tm)
+            t.update({k: round(v, 1) for k, v in tm.items()})
+        t["total"] = round((time.perf_counter() - t_all) * 1e3, 1)
         t["exchanges"] = dict(p.exchanges)
         res[(comm.rank, rep)] = t
         if prof is not None:

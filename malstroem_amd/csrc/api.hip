@@ -846,6 +846,7 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
     f->out = c->r[which].p;
     f->H = c->H; f->W = c->W;
     f->fixed_top = c->ht; f->fixed_bot = c->hb;
+    f->rounds_per_batch = 16;   // a band pays a halo exchange + an all-reduce per batch: fewer, longer batches
     if (kind) {
         MH_ARG(c->have[MHIP_R_FILLED], "the no-flats fill of a band starts from the converged plain fill");
         f->sh = short_; f->dg = diag;

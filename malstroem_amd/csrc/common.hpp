@@ -121,6 +121,7 @@ struct FillRun {
     const float *seed = nullptr;    // plain-filled surface: no-flats upper-bound start (see fill_noflat_dev)
     double seed_add = 0;
     int fixed_top = 0, fixed_bot = 0;  // local row 0 / H-1 is a halo row owned by the neighbouring band
+    int rounds_per_batch = 8;          // rounds launched between two host checks (a band exchanges its halo rows after each batch)
     struct Impl;
     Impl *impl;
     FillRun();

@@ -715,7 +715,7 @@ template <typename WT> __global__ void copy_dem_kernel(const float *dem, WT *out
 }
 
 constexpr int MAX_ROUNDS = 1 << 15;
-constexpr int BATCH = 8;
+constexpr int MAX_BATCH = 32;   // rounds per host check: FillRun::rounds_per_batch (even, <= MAX_BATCH)
 
 // marks every macro tile of macro row `ti` active for the round that is launched next (band mode: a halo row changed)
 __global__ void activate_tile_row_kernel(int ti, int ntc, int shard_cap, int *list, unsigned int *mark, unsigned int *count)
@@ -835,13 +835,14 @@ int FillRun::batch(hipStream_t s, bool *active)
     Impl &m = *impl;
     *active = false;
     if (m.trivial) return MHIP_OK;
+    const int BATCH = rounds_per_batch < 2 ? 2 : (rounds_per_batch > MAX_BATCH ? MAX_BATCH : rounds_per_batch & ~1);
     if (m.round + BATCH >= MAX_ROUNDS) {
         set_error("fill did not converge within %d rounds", MAX_ROUNDS);
         return MHIP_ENOTCONV;
     }
-    unsigned int h_cnt[BATCH * NSHARD];
+    unsigned int h_cnt[MAX_BATCH * NSHARD];
     for (int b = 0; b < BATCH; ++b) MH_TRY(fill_launch_any(*this, m.round + b, INIT_NONE, s));
-    MH_HIP(hipMemcpyAsync(h_cnt, m.count + (size_t)(m.round + 1) * NSHARD, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(h_cnt, m.count + (size_t)(m.round + 1) * NSHARD, sizeof(unsigned int) * BATCH * NSHARD, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     int used = BATCH;
     bool still = true;

@@ -237,6 +237,15 @@ class RcclComm(TorchComm):
                 out[side] = take_recv(side, rcv.data_ptr())
         return out[0], out[1]
 
+    def allreduce_max(self, value):
+        """the per-batch "is anybody still active" flag: on the device group too (one small RCCL all-reduce instead of a
+        gloo round over TCP); the host threads' object collectives stay on gloo"""
+        if self.device.type != "cuda":
+            return super(RcclComm, self).allreduce_max(value)
+        t = self._torch.tensor([float(value)], dtype=self._torch.float64, device=self.device)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._pg)
+        return float(t.item())
+
     def self_test(self):
         torch = self._torch
         n = 4096

@@ -1122,8 +1122,8 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         int least = 0, greatest = 0;
         MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         MH_HIP(hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, least));
-        MH_HIP(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
     }
+    if (!c->stream_c) MH_HIP(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
     if (!c->ev_fork) {
         MH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));

@@ -234,7 +234,7 @@ def main():
         dominant = max(stage_names, key=lambda s: stage_ms[s])
         d8 = stages["flowdir"]
         out = {
-            "metric": "Mcells/s fill->D8->accum->label(+watershed) on %d^2 f32 fBm DEM" % n,
+            "metric": "Mcells/s fill->D8->accum->label on %d^2 f32 DEM" % n,   # BASELINE.json; the step also runs watersheds + pour points
             "value": round(value, 2), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 fill / f64 no-flats+D8+accum / u8 flowdir / i32 labels", "data": "synthetic",

@@ -598,7 +598,7 @@ class BandPipeline(object):
     def watershed(self):
         """flow.watersheds_from_labels over all bands: local pointer jumping with pseudo labels on the halo rows, then the
         boundary system (2 rows per band) is solved identically on every rank and applied as a LUT."""
-        b, comm, W = self.band, self.comm, self.W
+        b, comm, W = self.band, self._cur_comm(), self.W
         b.watershed_local()
         rows = comm.allgather((b.get_edge_row("watersheds", 0), b.get_edge_row("watersheds", 1)))
         R = comm.size
@@ -668,7 +668,7 @@ class BandPipeline(object):
         fid, fval = b.foreign_counts(lo, hi)
         bg = int(b.records_fetch(1, 0, 1)[0])
         total0 = 0
-        for r, (ids, vals, c0) in enumerate(self.comm.allgather((fid, fval, bg))):
+        for r, (ids, vals, c0) in enumerate(self._cur_comm().allgather((fid, fval, bg))):
             total0 += c0
             if r != self.comm.rank and own is not None:
                 mine = (ids >= lo) & (ids <= hi)
@@ -725,32 +725,65 @@ class BandPipeline(object):
                     except Exception as e:
                         err.append(e)
 
-        if overlap:
-            # the main thread makes many short library calls (a batch of rounds, a halo swap, a one-float all-reduce ...); with
-            # CPython's default 5 ms switch interval every one of them could wait that long for the GIL while the labelling
-            # thread runs NumPy code
-            import sys
-            old_switch = sys.getswitchinterval()
-            sys.setswitchinterval(1e-4)
-            th = threading.Thread(target=label_branch)
-            th.start()
-        try:
+        def ws_branch():
+            try:
+                if hasattr(self.band, "side_begin"):
+                    self.band.side_begin()
+                self._tls.comm = self._comm_b
+                timed("watershed", self.watershed)
+                if records:
+                    out["counts"] = timed("watershed", lambda: self.watershed_counts(fetch_own))
+            except Exception as e:
+                err.append(e)
+            finally:
+                self._tls.comm = None
+                if hasattr(self.band, "side_end"):
+                    try:
+                        self.band.side_end()
+                    except Exception as e:
+                        err.append(e)
+
+        if not overlap:
             timed("noflat", self.noflat)
             timed("flowdir", self.flowdir)
             timed("accum", self.accum)
-        finally:
-            if overlap:
-                th.join()
-                sys.setswitchinterval(old_switch)
-        if not overlap:
             timed("label", self.label)
             if records:
                 out["stats"] = timed("label", lambda: self.stats(fetch_own))
-        if err:
-            raise err[0]
-        timed("watershed", self.watershed)
+            timed("watershed", self.watershed)
+            if records:
+                out["counts"] = timed("watershed", lambda: self.watershed_counts(fetch_own))
+                out["pour"] = timed("pourpoints", lambda: self.pourpoints(fetch_own))
+            return out
+
+        # the main thread makes many short library calls (a batch of rounds, a halo swap, a one-float all-reduce ...); with
+        # CPython's default 5 ms switch interval every one of them could wait that long for the GIL while the side thread
+        # runs NumPy code
+        import sys
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(1e-4)
+        th = threading.Thread(target=label_branch)
+        th.start()
+        try:
+            try:
+                timed("noflat", self.noflat)
+                timed("flowdir", self.flowdir)
+            finally:
+                th.join()
+            if err:
+                raise err[0]
+            # like the single-GPU DAG: watersheds (need labels + flow directions) next to the accumulation
+            th = threading.Thread(target=ws_branch)
+            th.start()
+            try:
+                timed("accum", self.accum)
+            finally:
+                th.join()
+            if err:
+                raise err[0]
+        finally:
+            sys.setswitchinterval(old_switch)
         if records:
-            out["counts"] = timed("watershed", lambda: self.watershed_counts(fetch_own))
             out["pour"] = timed("pourpoints", lambda: self.pourpoints(fetch_own))
         return out
 

@@ -85,6 +85,11 @@ int mhip_keep_mask(const int32_t *labels, const uint8_t *keep, int64_t nlab, int
 int mhip_label_stats_f32(const float *data, const int32_t *labels, int64_t n, int64_t nlab,
                          mhip_stat_record *records);
 
+/* the same on float64 data: the reference's generic path (label.py:43-75) for rasters that are not float32
+ * (integer rasters are converted to float64 by the caller, as the reference's float64 record fields do). */
+int mhip_label_stats_f64(const double *data, const int32_t *labels, int64_t n, int64_t nlab,
+                         mhip_stat_record *records);
+
 /* label.label_min_index / label.label_max_index  reference _label.pyx:99-128, label.py:135-166:
  * per label extreme value and its FIRST raster-order position (strict compare). nlab+1 records. */
 int mhip_label_argmin_f64(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab,

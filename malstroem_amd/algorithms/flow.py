@@ -133,3 +133,40 @@ def trace_downstream(flowdir, cell):
         yield cell
         delta = direction_to_delta(flowdir[cell[0], cell[1]])
         cell = (cell[0] + delta[0], cell[1] + delta[1]) if delta else None
+
+
+def trace_accumulated_flow(flowdir, accum, cell):
+    """Walk downstream from ``cell`` writing ``1 + sum(accum of the upstream neighbours)`` into ``accum`` and stop at
+    the first cell that still has an unresolved (``<= 0``) upstream neighbour, or off the raster (flow.py:304-341).
+
+    Per-cell host helper kept for API parity (the reference does not rebind it either at whole-stage granularity);
+    the raster-wide ``accumulated_flow`` is the HIP kernel.
+    """
+    cell = (int(cell[0]), int(cell[1]))
+    while cell_in_raster(flowdir.shape, cell):
+        total = 0
+        for up in upstream_cells(flowdir, cell):
+            value = accum[up[0], up[1]]
+            if value <= 0:
+                return
+            total += value
+        accum[cell[0], cell[1]] = total + 1
+        delta = direction_to_delta(flowdir[cell[0], cell[1]])
+        if delta is None:   # a cell without direction ends the walk (the reference fails on it, flow.py:340-341)
+            return
+        cell = (cell[0] + delta[0], cell[1] + delta[1])
+
+
+def assign_watersheds_upstream(flowdir, labelled, cell, unassigned):
+    """Give every ``unassigned`` cell upstream of ``cell`` the first label met on its way down, in place
+    (flow.py:367-395): depth-first over the upstream tree, carrying the label of the cell just downstream.
+
+    Per-cell host helper kept for API parity; ``watersheds_from_labels`` (all edge cells at once) is the HIP kernel.
+    """
+    stack = [(int(cell[0]), int(cell[1]), unassigned)]
+    while stack:
+        r, c, below = stack.pop()
+        lbl = labelled[r, c]
+        if lbl == unassigned:
+            labelled[r, c] = lbl = below
+        stack.extend((u[0], u[1], lbl) for u in upstream_cells(flowdir, (r, c)))

@@ -16,6 +16,7 @@ __all__ = ["available", "enable", "disable", "enabled"]
 available = _lib.LIB_PATH.exists() and _lib.device_count() > 0
 enabled = False
 _orig = []   # (module object, attribute name, original function)
+_targets = []   # packages patched by enable(target=...) since the last disable()
 
 # (module name, attribute) -> HIP implementation
 _PATCH = {
@@ -42,20 +43,27 @@ def enable(target=None):
         warnings.warn("malstroem_amd HIP backend not available (library not built or no MI355X visible)",
                       RuntimeWarning)
         return
-    if target is not None and not _orig:
+    if target is not None and not any(t is target for t in _targets):
+        # idempotent per target like speedups.enable (speedups/__init__.py:44-45); a second, different target is
+        # patched as well (both are restored by disable())
+        missing = [(mod, attr) for (mod, attr) in _PATCH if not hasattr(getattr(target, mod, None), attr)]
+        if missing:
+            raise AttributeError("enable(target): %r lacks %s" % (target, ", ".join("%s.%s" % m for m in missing)))
         for (mod, attr), fn in _PATCH.items():
             m = getattr(target, mod)
             _orig.append((m, attr, getattr(m, attr)))
             setattr(m, attr, fn)
+        _targets.append(target)
     enabled = True
 
 
 def disable():
     """Undo ``enable(target)`` (restores the reference functions) and mark the backend disabled."""
     global enabled
-    for m, attr, fn in _orig:
+    for m, attr, fn in reversed(_orig):
         setattr(m, attr, fn)
     del _orig[:]
+    del _targets[:]
     enabled = False
 
 

@@ -52,16 +52,19 @@ def connected_components(data):
 def label_stats(data, labelled, nlabels=None):
     """Per-label min, max, sum, count (label 0 included) as a record array (label.py:43-75)."""
     data = np.asarray(data)
+    fn = "mhip_label_stats_f32"
     if data.dtype != np.float32:
-        raise ValueError("label_stats runs on float32 data (the reference fast path, _label.pyx:68); got '%s'"
-                         % data.dtype)
+        # the reference's generic path (label.py:43-75) accumulates any raster into float64 record fields
+        if data.dtype.kind not in "fiub":
+            raise ValueError("numeric raster expected, got '%s'" % data.dtype)
+        data, fn = data.astype(np.float64), "mhip_label_stats_f64"
     data = np.ascontiguousarray(data)
     lab = _labels(labelled)
     if lab.shape != data.shape:
         raise ValueError("shape mismatch")
     nlabels = _nlabels(lab, nlabels)
     rec = np.zeros(nlabels + 1, dtype=STAT_DTYPE)
-    _lib.call("mhip_label_stats_f32", _lib.ptr(data), _lib.ptr(lab), _lib.i64(lab.size), _lib.i64(nlabels), _lib.ptr(rec))
+    _lib.call(fn, _lib.ptr(data), _lib.ptr(lab), _lib.i64(lab.size), _lib.i64(nlabels), _lib.ptr(rec))
     return rec
 
 

@@ -302,6 +302,19 @@ int mhip_label_stats_f32(const float *data, const int32_t *labels, int64_t n, in
     return download(records, d_r, sizeof(mhip_stat_record) * (size_t)(nlab + 1), s);
 }
 
+int mhip_label_stats_f64(const double *data, const int32_t *labels, int64_t n, int64_t nlab, mhip_stat_record *records)
+{
+    MH_ARG(data && labels && records && n >= 1 && nlab >= 0, "label_stats_f64(data, labels, n>=1, nlab>=0, records)");
+    MH_TRY(require_device());
+    hipStream_t s = 0;
+    DevBuf d_d, d_l, d_r;
+    MH_TRY(upload(d_d, data, (size_t)n * 8, s));
+    MH_TRY(upload(d_l, labels, (size_t)n * 4, s));
+    MH_TRY(d_r.alloc(sizeof(mhip_stat_record) * (size_t)(nlab + 1)));
+    MH_TRY(label_stats64_dev(d_d.as<double>(), d_l.as<int32_t>(), n, nlab, d_r.as<mhip_stat_record>(), s));
+    return download(records, d_r, sizeof(mhip_stat_record) * (size_t)(nlab + 1), s);
+}
+
 static int label_arg_host(const double *data, const int32_t *labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
                           mhip_index_record *records)
 {

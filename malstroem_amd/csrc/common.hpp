@@ -160,6 +160,7 @@ int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, 
 // W: raster width if the caller knows it (2-D tiles combine a label's rows before the global atomics), 0 = flat array
 int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
                     hipStream_t s, int64_t W = 0);
+int label_stats64_dev(const double *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s);
 int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
                   mhip_index_record *d_rec, hipStream_t s);
 int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s, int64_t W = 0);

@@ -223,6 +223,61 @@ __global__ __launch_bounds__(256) void stats_finish_kernel(StatAcc a, int64_t nr
     rec[i] = r;
 }
 
+// ---- label_stats on float64 data (the reference's generic path, label.py:43-75; not on the hot path) -------------
+// One thread per cell; equal-label runs are combined inside a wavefront and the run heads go to the global atomics.
+struct StatAcc64 {
+    uint64_t *minkey, *maxkey;  // f64 ordered keys
+    double *sum;
+    unsigned long long *count;
+};
+__global__ __launch_bounds__(256) void stats64_init_kernel(StatAcc64 a, int64_t nrec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    a.minkey[i] = f64_key(__builtin_inf());
+    a.maxkey[i] = f64_key(-__builtin_inf());
+    a.sum[i] = 0.0;
+    a.count[i] = 0ull;
+}
+__global__ __launch_bounds__(256) void stats64_kernel(const double *__restrict__ data, const int32_t *__restrict__ lab, int64_t n,
+                                                      int64_t nlab, StatAcc64 a, unsigned int *bad)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    int32_t l = valid ? lab[i] : -1;
+    const double v = valid ? data[i] : 0.0;
+    if (valid && (l < 0 || l > nlab)) {
+        atomicOr(bad, 1u);
+        l = -1;
+    }
+    const bool ok = l >= 0;
+    const bool isnan = v != v;   // never wins `val < min` / `val > max`; it does poison the sum (label.py:68-73)
+    double vmin = isnan ? __builtin_inf() : v, vmax = isnan ? -__builtin_inf() : v;
+    const int len = run_length_from(l, lane, ok);
+    const bool head = is_run_head(l, lane, ok);
+    vmin = seg_reduce(vmin, len, [](double x, double y) { return fmin(x, y); });
+    vmax = seg_reduce(vmax, len, [](double x, double y) { return fmax(x, y); });
+    const double sm = seg_reduce(v, len, [](double x, double y) { return x + y; });
+    if (head && ok) {
+        atomicMin((unsigned long long *)&a.minkey[l], (unsigned long long)f64_key(vmin));
+        atomicMax((unsigned long long *)&a.maxkey[l], (unsigned long long)f64_key(vmax));
+        atomicAdd(&a.sum[l], sm);
+        atomicAdd(&a.count[l], (unsigned long long)len);
+    }
+}
+__global__ __launch_bounds__(256) void stats64_finish_kernel(StatAcc64 a, int64_t nrec, mhip_stat_record *rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    mhip_stat_record r;
+    r.min = key_f64(a.minkey[i]);
+    r.max = key_f64(a.maxkey[i]);
+    r.sum = a.sum[i];
+    r.count = (int64_t)a.count[i];
+    rec[i] = r;
+}
+
 // ---- label_min_index / label_max_index ----------------------------------------------------------
 // pass 1: per label extreme of the monotone f64 key (-0.0 folded onto +0.0 so that float equality == key equality)
 // pass 2: smallest linear index whose value equals the extreme
@@ -535,6 +590,24 @@ int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int
     const TileGeom g = tile_geom(n, W);
     hipLaunchKernelGGL(stats_kernel, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
     hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
+    MH_HIP(hipGetLastError());
+    return check_bad(bad, s, "label_stats");
+}
+
+int label_stats64_dev(const double *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s)
+{
+    const int64_t nrec = nlab + 1;
+    DevBuf mn, mx, sm, ct, bad;
+    MH_TRY(mn.alloc(8 * (size_t)nrec));
+    MH_TRY(mx.alloc(8 * (size_t)nrec));
+    MH_TRY(sm.alloc(8 * (size_t)nrec));
+    MH_TRY(ct.alloc(8 * (size_t)nrec));
+    MH_TRY(bad.alloc(4));
+    MH_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    StatAcc64 a{mn.as<uint64_t>(), mx.as<uint64_t>(), sm.as<double>(), ct.as<unsigned long long>()};
+    hipLaunchKernelGGL(stats64_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
+    hipLaunchKernelGGL(stats64_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_data, d_labels, n, nlab, a, bad.as<unsigned int>());
+    hipLaunchKernelGGL(stats64_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "label_stats");
 }

@@ -33,3 +33,59 @@ def fbm(h, w=None, beta=2.0, seed=42):
     z = np.fft.irfft2(amp * phase, s=(h, w))
     z = (z - z.min()) / (z.max() - z.min()) * 100
     return z.astype(np.float32)
+
+
+def reference_vectors():
+    """The reference's own vector fixtures (pourpoints / nodes / streams .json), decoded by extract_reference_vectors.py."""
+    import gzip
+    import json
+    with gzip.open(GOLDEN / "reference_vectors.json.gz", "rt") as fh:
+        return json.load(fh)
+
+
+def d8_mul_vs_div_case():
+    """3x3 surface on which the two reference D8 variants disagree at the centre cell.
+
+    The U neighbour drops by fl(dd * 1/2**0.5), the UR neighbour by dd = 484.544921875: the Cython path
+    (_flow.pyx:93-94,140 multiplies the diagonal drop by 1/2**0.5) finds the two drops EQUAL, so U (code 0) keeps the
+    strict `>` comparison; the Python twin (flow.py:79 divides by sqrt(2)) rounds the diagonal one ulp higher and takes
+    UR (code 1).  The build follows the Cython variant.
+    """
+    dd = 484.544921875
+    inv = 1.0 / 2 ** 0.5
+    assert dd / (2 ** 0.5) > dd * inv
+    z = np.zeros((3, 3), dtype=np.float64)
+    z[0, 1] = -(dd * inv)
+    z[0, 2] = -dd
+    return z, 0, 1   # surface, code(cython), code(python)
+
+
+def assemble_reference_pourpoints(cell_area, pp, stats, wcounts):
+    """Field-by-field restatement of the pour point record of reference bluespots.py:75-82 (test-side copy for the oracle)."""
+    out = []
+    for ix in range(len(pp)):
+        out.append(dict(bspot_id=ix, cell_row=int(pp["row"][ix]), cell_col=int(pp["col"][ix]),
+                        bspot_dmax=float(stats["max"][ix]), bspot_area=float(stats["count"][ix] * cell_area),
+                        bspot_vol=float(stats["sum"][ix] * cell_area), wshed_area=float(wcounts[ix] * cell_area)))
+    return out
+
+
+def assert_label_sums(got_sum, ref_sum, data, labels):
+    """label_stats `sum` parity: the reference adds float64(values) sequentially in raster order.
+    Wherever that sequential sum equals the exactly rounded sum (math.fsum) no partial sum ever rounded, every summation
+    order gives the same bits, and the device must match EXACTLY; only for the remaining labels (none on the fixtures:
+    depths are multiples of a float32 ulp) the comparison falls back to 1e-12 relative."""
+    import math
+    d = np.asarray(data, dtype=np.float64).ravel()
+    lab = np.asarray(labels).ravel()
+    order = np.argsort(lab, kind="stable")
+    bounds = np.searchsorted(lab[order], np.arange(len(ref_sum) + 1))
+    inexact = 0
+    for l in range(len(ref_sum)):
+        exact = math.fsum(d[order[bounds[l]:bounds[l + 1]]])
+        if exact == ref_sum[l]:
+            assert got_sum[l] == ref_sum[l], (l, got_sum[l], ref_sum[l])
+        else:
+            inexact += 1
+            assert abs(got_sum[l] - ref_sum[l]) <= 1e-12 * abs(ref_sum[l]), (l, got_sum[l], ref_sum[l])
+    return inexact

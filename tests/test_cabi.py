@@ -77,3 +77,59 @@ def test_host_helpers_match_reference_semantics():
     f2 = np.full((3, 3), 8, dtype=np.uint8)
     flow.set_edges_flow_outward(f2)
     assert f2.tolist() == [[7, 0, 1], [6, 8, 2], [5, 4, 3]]
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE + "/malstroem/algorithms"), reason="reference checkout not on this box")
+def test_enable_patches_the_real_reference_package(monkeypatch):
+    """hip.enable(target=malstroem.algorithms) on the reference's own (pure-Python) package: the 13 whole-stage functions
+    are rebound like speedups.enable() rebinds its 8 (speedups/__init__.py:37-77), with identical call signatures, and
+    disable() restores them.  Runs without a GPU (nothing is called); `available` is forced for the duration."""
+    import inspect
+    import sys
+    import types
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)       # never write into the read-only reference tree
+    monkeypatch.syspath_prepend(REFERENCE)
+    import malstroem.algorithms as ref_alg
+    from malstroem.algorithms import fill as rfill, flow as rflow, label as rlabel  # noqa: F401
+    import malstroem_amd.algorithms as alg
+    hip = alg.hip
+    originals = {(m, a): getattr(getattr(ref_alg, m), a) for (m, a) in hip._PATCH}
+    assert len(originals) == 13
+    was_enabled = hip.enabled
+    monkeypatch.setattr(hip, "available", True)
+    hip.disable()
+    other = types.SimpleNamespace(fill=types.SimpleNamespace(**{a: None for (m, a) in hip._PATCH if m == "fill"}),
+                                  flow=types.SimpleNamespace(**{a: None for (m, a) in hip._PATCH if m == "flow"}),
+                                  label=types.SimpleNamespace(**{a: None for (m, a) in hip._PATCH if m == "label"}))
+    try:
+        hip.enable(target=ref_alg)
+        for (m, a), fn in hip._PATCH.items():
+            bound = getattr(getattr(ref_alg, m), a)
+            assert bound is fn and bound is not originals[(m, a)], (m, a)
+            ours = list(inspect.signature(fn).parameters.values())
+            theirs = list(inspect.signature(originals[(m, a)]).parameters.values())
+            # same names, order, kinds and defaults; ours may only ADD trailing keyword arguments with defaults
+            assert [(p.name, p.kind, p.default) for p in ours[:len(theirs)]] == [(p.name, p.kind, p.default) for p in theirs], (m, a)
+            assert all(p.default is not inspect.Parameter.empty for p in ours[len(theirs):]), (m, a)
+        # functions the reference keeps un-patched stay its own, and exist in the mirror with the same signatures
+        for name in ("trace_accumulated_flow", "assign_watersheds_upstream", "upstream_cells", "trace_downstream"):
+            assert getattr(ref_alg.flow, name).__module__ == "malstroem.algorithms.flow"
+            assert (list(inspect.signature(getattr(alg.flow, name)).parameters) ==
+                    list(inspect.signature(getattr(ref_alg.flow, name)).parameters)), name
+        hip.enable(target=ref_alg)                       # idempotent (speedups/__init__.py:44-45)
+        assert len(hip._orig) == 13
+        hip.enable(target=other)                         # a second target is patched too, not silently ignored
+        assert other.fill.fill_terrain is alg.fill.fill_terrain and len(hip._orig) == 26
+        with pytest.raises(AttributeError):
+            hip.enable(target=types.SimpleNamespace(fill=None, flow=None, label=None))
+    finally:
+        hip.disable()
+    for (m, a), fn in originals.items():
+        assert getattr(getattr(ref_alg, m), a) is fn, (m, a)
+    assert other.fill.fill_terrain is None
+    monkeypatch.undo()
+    if was_enabled:
+        hip.enable()

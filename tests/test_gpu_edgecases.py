@@ -1,6 +1,8 @@
 """GPU: edge cases and randomised inputs beyond the D8-of-a-no-flats-surface pipeline, always against the oracle
 (or scipy for the labelling): flow cycles, interior sinks, inward pointing edges, tiny / ragged rasters, masks with
 every kind of adjacency, explicit nlabels, error behaviour."""
+import math
+
 import numpy as np
 import pytest
 import scipy.ndimage
@@ -113,6 +115,22 @@ def test_fill_with_nan_cells_matches_the_reference_comparisons(alg):
     assert np.array_equal(got, want, equal_nan=True)
 
 
+def test_fill_with_nan_on_the_raster_border(alg):
+    """Border cells are copied from the DEM (fill.py:102-109): a NaN border cell stays NaN and never wins a min
+    (`a <= NaN` is false, _fill.pyx:22), the interior behind it fills as if it were a wall."""
+    rng = np.random.default_rng(16)
+    for shape in ((40, 45), (70, 130)):
+        dem = (rng.random(shape) * 5).astype(np.float32)
+        dem[0, 3] = dem[0, 0] = dem[-1, 7:12] = dem[5:9, 0] = dem[17, -1] = dem[-1, -1] = np.nan
+        dem[1, 3] = dem[6, 1] = 0.0                      # pits right behind NaN border cells
+        got, want = alg.fill.fill_terrain(dem), oracle.fill_terrain(dem)
+        assert np.isnan(got[0, 3]) and np.isnan(got[-1, -1]) and np.isnan(got[6, 0])
+        assert np.array_equal(got, want, equal_nan=True)
+        short, diag = oracle.minimum_safe_short_and_diag(np.nan_to_num(dem))
+        got, want = alg.fill.fill_terrain_no_flats(dem, short, diag), oracle.fill_terrain_no_flats(dem, short, diag)
+        assert np.array_equal(got, want, equal_nan=True)
+
+
 @pytest.mark.parametrize("seed", range(5))
 def test_connected_components_random_masks_equal_scipy(alg, seed):
     rng = np.random.default_rng(300 + seed)
@@ -184,3 +202,23 @@ def test_fills_on_shapes_around_tile_and_macro_tile_multiples():
         short, diag = alg.fill.minimum_safe_short_and_diag(dem)
         got = alg.fill.fill_terrain_no_flats(dem, short, diag)
         assert np.array_equal(got, oracle.fill_terrain_no_flats(dem, short, diag)), (h, w)
+
+
+def test_label_stats_on_non_float32_rasters(alg):
+    """The reference's generic path (label.py:43-75) takes any raster; float64 / integer data run the float64 kernel."""
+    rng = np.random.default_rng(21)
+    lab = rng.integers(0, 40, size=(90, 131)).astype(np.int32)
+    lab[10:40, 20:90] = 0
+    for data in (rng.standard_normal(lab.shape), rng.integers(-50, 50, size=lab.shape), rng.integers(0, 255, size=lab.shape).astype(np.uint8),
+                 (rng.random(lab.shape) * 1e-3).astype(np.float16)):
+        got = alg.label.label_stats(data, lab)
+        d64 = data.astype(np.float64)
+        for l in range(40):
+            sel = d64[lab == l]
+            assert got["count"][l] == sel.size and got["min"][l] == sel.min() and got["max"][l] == sel.max()
+            assert abs(got["sum"][l] - math.fsum(sel)) <= 1e-12 * max(1.0, np.abs(sel).sum())
+    data = rng.standard_normal(lab.shape)
+    data[3, 3] = np.nan
+    got, want = alg.label.label_stats(data, lab, 45), oracle.label_stats(data.astype(np.float32), lab, 45)
+    assert len(got) == 46 and np.isnan(got["sum"][lab[3, 3]]) and got["count"][45] == 0 and got["min"][45] == np.inf
+    assert np.array_equal(got["count"], want["count"])

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import PYREF_CASES, fbm, fixtures, pyref
+from _cases import (PYREF_CASES, assemble_reference_pourpoints, assert_label_sums, d8_mul_vs_div_case, fbm, fixtures,
+                    pyref, reference_vectors)
 
 pytestmark = pytest.mark.gpu
 
@@ -111,6 +112,88 @@ def test_label_index_reference(alg, fx):
         assert np.array_equal(mi[f], rmi[f]) and np.array_equal(ma[f], rma[f]), f
 
 
+def test_flowdir_follows_the_cython_variant_where_the_two_differ(alg):
+    """_flow.pyx:93-94,140 multiplies the diagonal drop by 1/2**0.5, flow.py:79 divides by sqrt(2): on this surface the
+    two give different codes at the centre cell; the kernel must give the Cython one."""
+    z, code_cython, code_python = d8_mul_vs_div_case()
+    assert oracle.terrain_flowdirection(z, variant="python")[1, 1] == code_python != code_cython
+    for pad in (0, 5, 70):     # the cell inside a 3x3 raster, and inside rasters wider than one lane strip
+        zz = np.zeros((3 + 2 * pad, 3 + 2 * pad))
+        zz[pad:pad + 3, pad:pad + 3] = z
+        fd = alg.flow.terrain_flowdirection(zz)
+        assert fd[pad + 1, pad + 1] == code_cython
+        assert np.array_equal(fd, oracle.terrain_flowdirection(zz, variant="cython"))
+
+
+def test_pourpoints_reproduce_the_reference_vector_fixture(alg, fx):
+    """reference tests/data/pourpoints.json: 105 records = label_min_index(no-flats surface) + label_stats(depths) +
+    label_count(watersheds) (bluespots.py:49-88, 195-206, the branch WITHOUT accumulated flow).  Three ways: the stage
+    functions, the device pipeline's POURPOINTS stage on its arg-min branch, and BluespotTool given input_dem only."""
+    from malstroem_amd.bluespots import BluespotTool, assemble_pourpoints
+    from malstroem_amd.pipeline import HydroPipeline
+    ref = reference_vectors()["pourpoints"]
+    gt = [float(v) for v in fx["geotransform"]]
+    lab = fx["labelled"]
+
+    def check(features):
+        assert len(features) == len(ref) == 105
+        for f, r in zip(features, ref):
+            p = f["properties"] if "properties" in f else f
+            for k in ("bspot_id", "cell_row", "cell_col", "bspot_dmax", "bspot_area", "bspot_vol", "wshed_area"):
+                assert p[k] == r["properties"][k], (p["bspot_id"], k)
+            if "geometry" in f:
+                assert np.allclose(f["geometry"]["coordinates"], r["coordinates"], rtol=0, atol=1e-6)
+
+    # (1) stage functions
+    pp = alg.label.label_min_index(fx["filled_no_flats"], lab)
+    st = alg.label.label_stats(fx["depths"], lab)
+    ws = lab.copy()
+    alg.flow.watersheds_from_labels(fx["flowdir_noflats"], ws, 0)
+    check(assemble_pourpoints(gt, pp, st, alg.label.label_count(ws)))
+    check(assemble_reference_pourpoints(abs(gt[1]) * abs(gt[5]), pp, st, alg.label.label_count(ws)))
+
+    # (2) device pipeline: labels uploaded, no accumulated flow -> POURPOINTS takes arg-min of the no-flats surface
+    with HydroPipeline(lab.shape) as pipe:
+        pipe.upload("dem", fx["dtm"])
+        pipe.upload("depths", fx["depths"])
+        pipe.upload("flowdir", fx["flowdir_noflats"])
+        pipe.run("noflat")
+        pipe.upload("labels", lab)
+        pipe.run("watershed", "pourpoints")
+        pix, counts = pipe.pourpoints(), pipe.watershed_counts()
+        assert np.array_equal(pipe.download("watersheds"), fx["wsheds"])
+    check(assemble_pourpoints(gt, pix, st, counts))
+
+    # (3) BluespotTool, input_dem given, no input_accum; the filter that made labelled.tif is not recorded, so it is
+    #     rebuilt from the fixture itself: keep the raw bluespots that survive in labelled.tif
+    raw, nraw = oracle.connected_components(fx["depths"])
+    kept = np.unique(raw[lab > 0])
+    rst = oracle.label_stats(fx["depths"], raw)
+    keys = {(rst["min"][l], rst["max"][l], rst["sum"][l], int(rst["count"][l])) for l in kept}
+
+    class Reader(object):
+        def __init__(self, a):
+            self.a, self.transform = a, gt
+
+        def read(self):
+            return self.a
+
+    class Writer(object):
+        def write(self, a):
+            self.a = a
+
+        def write_geojson_features(self, fc):
+            self.fc = fc
+
+    labeled, pour, wsheds = Writer(), Writer(), Writer()
+    BluespotTool(input_depths=Reader(fx["depths"]), input_flowdir=Reader(fx["flowdir_noflats"]),
+                 input_bluespot_filter_function=lambda s: (s["min"], s["max"], s["sum"], int(s["count"])) in keys,
+                 input_dem=Reader(fx["dtm"]), output_labeled_raster=labeled, output_pourpoints=pour,
+                 output_watersheds_raster=wsheds).process()
+    assert np.array_equal(labeled.a, lab) and np.array_equal(wsheds.a, fx["wsheds"])
+    check(pour.fc["features"])
+
+
 # ---- pure-Python reference goldens ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("name", PYREF_CASES)
@@ -175,7 +258,7 @@ def test_chain_equals_oracle(alg, name, h, w, beta, seed):
     st, ost = alg.label.label_stats(depths, raw), oracle.label_stats(depths, raw)
     for f in ("min", "max", "count"):
         assert np.array_equal(st[f], ost[f]), f
-    assert np.allclose(st["sum"], ost["sum"], rtol=1e-12, atol=0)
+    assert_label_sums(st["sum"], ost["sum"], depths, raw)   # exact wherever the reference's own sum is (fsum guard)
     keep = (ost["count"] >= 5) & (ost["max"] > 0.05)
     lab, nl = alg.label.connected_components(alg.label.keep_labels(raw, list(keep)))
     olab, onl = oracle.connected_components(oracle.keep_labels(oraw, list(keep)))
@@ -294,7 +377,7 @@ def test_whole_chain_in_one_request_matches_oracle(alg, shape):
     ost = oracle.label_stats(dep, lab, n)
     for f in ("min", "max", "count"):
         assert np.array_equal(stats[f], ost[f]), f
-    assert np.allclose(stats["sum"], ost["sum"], rtol=1e-12, atol=0)
+    assert_label_sums(stats["sum"], ost["sum"], dep, lab)
     assert np.array_equal(counts, oracle.label_count(ws))   # every label owns at least its own cells: max(ws) == n
     opour = oracle.label_max_index(accum, lab, n)
     for f in opour.dtype.names:

@@ -8,7 +8,10 @@ import pytest
 import scipy.ndimage
 
 import oracle
-from _cases import PYREF_CASES, fixtures, pyref
+import math
+
+from _cases import (PYREF_CASES, assemble_reference_pourpoints, d8_mul_vs_div_case, fixtures, pyref,
+                    reference_vectors)
 
 
 @pytest.fixture(scope="module")
@@ -97,6 +100,41 @@ def test_label_stats_known_answers(fx):
     sel = fx["depths"][lab == big]
     assert st[big]["min"] == sel.min() and st[big]["max"] == sel.max() and st[big]["count"] == sel.size
     np.testing.assert_almost_equal(st[big]["sum"], sel.astype(np.float64).sum())
+
+
+def test_pourpoints_match_reference_vector_fixture(fx):
+    """reference tests/data/pourpoints.json (tests/data/fixtures.py:13-15): all 105 pour point records are
+    label_min_index(no-flats, labelled) + label_stats(depths, labelled) + label_count(wsheds) (bluespots.py:49-88,195-206)."""
+    ref = reference_vectors()["pourpoints"]
+    lab = fx["labelled"]
+    gt = fx["geotransform"]
+    cell_area = abs(gt[1]) * abs(gt[5])
+    pp = oracle.label_min_index(fx["filled_no_flats"], lab)
+    st = oracle.label_stats(fx["depths"], lab)
+    wc = oracle.label_count(fx["wsheds"])
+    mine = assemble_reference_pourpoints(cell_area, pp, st, wc)
+    assert len(mine) == len(ref) == 105
+    for m, r in zip(mine, ref):
+        for k, v in m.items():
+            assert r["properties"][k] == v, (m["bspot_id"], k)
+
+
+def test_label_stats_sum_is_exact_on_the_fixtures(fx):
+    """SURVEY 8a row S guard: the reference's sequential float64 sum equals the exactly rounded sum (math.fsum) for
+    every label, so ANY summation order (the device's float64 atomics) reproduces the reference bits on these inputs."""
+    st = oracle.label_stats(fx["depths"], fx["labelled"])
+    d, lab = fx["depths"].astype(np.float64).ravel(), fx["labelled"].ravel()
+    order = np.argsort(lab, kind="stable")
+    bounds = np.searchsorted(lab[order], np.arange(len(st) + 1))
+    for l in range(len(st)):
+        assert st["sum"][l] == math.fsum(d[order[bounds[l]:bounds[l + 1]]]), l
+
+
+def test_d8_follows_the_cython_variant_where_the_two_differ():
+    z, code_cython, code_python = d8_mul_vs_div_case()
+    assert oracle.terrain_flowdirection(z, variant="cython")[1, 1] == code_cython
+    assert oracle.terrain_flowdirection(z, variant="python")[1, 1] == code_python
+    assert code_cython != code_python
 
 
 # ---- (2) pure-Python reference outputs ----------------------------------------------------

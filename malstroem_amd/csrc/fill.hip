@@ -21,6 +21,7 @@
 // the update is lane-masked (no-flats).  Raster border cells have W == dem from the start and therefore
 // never move; cells outside the raster are +inf and never win a min.
 #include "common.hpp"
+#include <mutex>
 #include <vector>
 
 namespace mh {
@@ -754,12 +755,20 @@ static int fill_launch(FillRun &f, int round, int init, hipStream_t s)
     auto k_none = fill_round_kernel<WT, NOFLAT, INIT_NONE, MT>;
     auto k_inf = fill_round_kernel<WT, NOFLAT, INIT_INF, MT>;
     auto k_seed = fill_round_kernel<WT, NOFLAT, NOFLAT ? INIT_SEED : INIT_INF, MT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        MH_HIP(hipFuncSetAttribute((const void *)k_none, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MH_HIP(hipFuncSetAttribute((const void *)k_inf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MH_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+    // > 64 KB of dynamic LDS is an opt-in PER DEVICE: one flag per device (and per instantiation of this function), set
+    // under a lock -- band contexts on several GPUs launch from several host threads
+    {
+        static std::mutex mu;
+        static bool attr_done[64] = {};
+        int dev = 0;
+        MH_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            MH_HIP(hipFuncSetAttribute((const void *)k_none, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MH_HIP(hipFuncSetAttribute((const void *)k_inf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MH_HIP(hipFuncSetAttribute((const void *)k_seed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
     }
     RoundArgs a;
     a.H = f.H; a.Wd = f.W; a.ntr = m.ntr; a.ntc = m.ntc; a.mtr = m.mtr; a.mtc = m.mtc; a.shard_cap = m.shard_cap;

@@ -12,7 +12,14 @@ Per kernel, in program order: a stack of the SGPR pairs holding a saved EXEC (`s
 `s_mov_b64 sX, exec` push; `s_or_b64 exec, exec, sX` / `s_mov_b64 exec, sX` pop down to sX).  A v_accvgpr_write aN
 issued while the stack is non-empty is reported when, after its region has been left, aN is READ before it is written
 again -- unless the write stores back what was just read from the same aN.  Linear scan (ignores the CFG): a heuristic,
-good enough to catch the pattern above; run by tests/test_build_lint.py on every kernel of the library."""
+good enough to catch the pattern above; run by tests/test_build_lint.py on every kernel of the library.
+
+The same hazard through SCRATCH (a "Folded Spill" scratch_store under narrowed EXEC, reloaded after the region): a store
+under narrowed EXEC is harmless when the slot already holds a value of every lane (an earlier store under full EXEC: that
+is how a per-lane PHI of a spilled value looks, e.g. the 100-byte private segment of fill_round_kernel<float,false,1>
+at commit 2c30b20); it is reported when NO full-EXEC store precedes it and the slot is reloaded after the region.
+`private_segments(path)` lists every kernel's .private_segment_fixed_size so the tests can also require "no scratch at
+all" of the shipped fill kernels."""
 import re
 import sys
 
@@ -22,6 +29,14 @@ REST = re.compile(r"(?:s_or_b64 exec, exec, |s_mov_b64 exec, )(s\[\d+:\d+\])")
 WR = re.compile(r"v_accvgpr_write_b32 (a\d+), (v\d+)")
 RD = re.compile(r"v_accvgpr_read_b32 (v\d+), (a\d+)")
 USE = re.compile(r"\ba\[?(\d+)(?::(\d+))?\]?")
+SST = re.compile(r"scratch_store_dword(x\d)? off, v\[?\d+(?::\d+)?\]?, off(?: offset:(\d+))?")
+SLD = re.compile(r"scratch_load_dword(x\d)? v\[?\d+(?::\d+)?\]?, off, off(?: offset:(\d+))?")
+
+
+def _slots(m):
+    n = int(m.group(1)[1:]) if m.group(1) else 1
+    off = int(m.group(2) or 0)
+    return [off + 4 * k for k in range(n)]
 
 
 def kernels(path):
@@ -60,6 +75,24 @@ def lint_kernel(body):
                 continue   # stores back what it just read from the same AGPR
             writes.append((i, ln, m.group(1), len(stack), s))
     bad = []
+    # scratch spill slots: stores under narrowed EXEC into a slot no full-EXEC store has filled, reloaded after the region
+    full, partial = set(), {}
+    for i, (ln, s) in enumerate(body):
+        m = SST.match(s)
+        if m:
+            for slot in _slots(m):
+                if depth_at[i] == 0:
+                    full.add(slot)
+                    partial.pop(slot, None)
+                elif slot not in full and slot not in partial:
+                    partial[slot] = (ln, depth_at[i], s)
+            continue
+        m = SLD.match(s)
+        if m:
+            for slot in _slots(m):
+                if slot in partial and depth_at[i] < partial[slot][1]:
+                    pl, pd, ps = partial.pop(slot)
+                    bad.append((pl, pd, ps, ln, s))
     for i, ln, areg, depth, s in writes:
         n = int(areg[1:])
         left = False
@@ -94,6 +127,23 @@ def lint(path, only=None):
             continue
         for ln, depth, s, ln2, t in lint_kernel(body):
             out.append((name, ln, depth, s, ln2, t))
+    return out
+
+
+def private_segments(path):
+    """{kernel name: .private_segment_fixed_size} from the kernel descriptors' metadata."""
+    out, size = {}, None
+    for line in open(path):
+        m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+        if m:
+            size = int(m.group(1))
+        m = re.match(r"\s+(?:- )?\.name:\s+(\S+)", line)
+        if m and size is not None:
+            pass
+        m2 = re.match(r"\s+\.symbol:\s+(\S+)\.kd", line)
+        if m2 and size is not None:
+            out[m2.group(1)] = size
+            size = None
     return out
 
 

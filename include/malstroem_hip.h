@@ -128,23 +128,33 @@ enum mhip_raster {
 
 /* Single-GPU context for an H x W raster on `device`. */
 int mhip_ctx_create(mhip_ctx **out, int64_t H, int64_t W, int device);
-/* Multi-GPU context: this rank owns rows [row0, row0+H_local) of a H_global x W raster; bands are
- * contiguous in rank order.  nccl_unique_id is the 128-byte ncclUniqueId created by rank 0
- * (mhip_comm_unique_id) and distributed by the host launcher. */
+/* Multi-GPU context: this rank owns rows [row0, row0+H_local) of a H_global x W raster; bands are contiguous in rank
+ * order, one rank (process) per GPU.
+ * RCCL transport: rank 0 calls mhip_comm_unique_id (ncclGetUniqueId, 128 bytes), the launcher hands the bytes to every
+ * rank (any channel: a file, a socket, torch.distributed ...), and every rank passes them to mhip_ctx_create_band, which
+ * joins the communicator (ncclCommInitRank: a COLLECTIVE call over all nranks bands).  With nccl_unique_id == NULL the
+ * context has no communicator and the launcher moves the edge rows itself (mhip_ctx_get_edge_row / _set_halo_row). */
 int mhip_comm_unique_id(void *id128);
 int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t row0, int64_t H_local,
                          int device, int rank, int nranks, const void *nccl_unique_id);
+int mhip_ctx_has_comm(mhip_ctx *ctx);        /* 1 if the context owns an RCCL communicator */
+/* Neighbour exchange over RCCL (ncclGroupStart / ncclSend + ncclRecv per neighbour / ncclGroupEnd on the context's stream,
+ * straight out of the raster's edge rows; band neighbours are xGMI peers): the rows that arrive are compared with and
+ * stored into the halo rows on the device; changed[0] / changed[1] = the top / bottom halo row changed. */
+int mhip_ctx_exchange_halo(mhip_ctx *ctx, int which, int32_t *changed);
+/* max over all bands of one value (ncclAllReduce): ends the fill / accumulation loops ("is anybody still active") */
+int mhip_ctx_allreduce_max(mhip_ctx *ctx, double value, double *out);
 int mhip_ctx_destroy(mhip_ctx *ctx);
 /* ---- row-band protocol.  A band context holds its owned rows plus one halo row per neighbour (a copy of
- * the neighbouring band's edge row).  The host launcher moves edge rows between neighbours (through host
- * buffers + torch.distributed/gloo, or device buffers + RCCL send/recv: the *_dev variants below) and drives
- * the fills to a GLOBAL fixed point: begin -> { batch; exchange edge rows; halo_changed } until no band is active. */
+ * the neighbouring band's edge row).  Edge rows move between neighbours over RCCL (mhip_ctx_exchange_halo above) or,
+ * for a context without a communicator, through the launcher (host buffers, or device buffers: the *_dev variants
+ * below); either way the launcher drives the fills to a GLOBAL fixed point: begin -> { batch; exchange edge rows; halo_changed } until no band is active. */
 int mhip_ctx_band_info(mhip_ctx *ctx, int64_t *row_off, int64_t *rows_local, int32_t *halo_top, int32_t *halo_bottom);
 int mhip_ctx_get_edge_row(mhip_ctx *ctx, int which, int side, void *host);   /* side 0: first owned row, 1: last owned row,
                                                                                 2: top halo row, 3: bottom halo row */
 int mhip_ctx_set_halo_row(mhip_ctx *ctx, int which, int side, const void *host, int32_t *changed); /* 0: top halo, 1: bottom */
-/* the same with DEVICE buffers of the caller (W * element size bytes on the context's GPU): the launcher hands them to
- * RCCL send/recv (torch.distributed "nccl" backend) so halo rows travel GPU -> GPU over xGMI without a host copy */
+/* the same with DEVICE buffers of the caller (W * element size bytes on the context's GPU), for a launcher that brings
+ * its own device-to-device transport */
 int mhip_ctx_get_edge_row_dev(mhip_ctx *ctx, int which, int side, void *dev_dst);
 int mhip_ctx_set_halo_row_dev(mhip_ctx *ctx, int which, int side, const void *dev_src, int32_t *changed);
 int mhip_ctx_dem_minmax(mhip_ctx *ctx, float *mn, float *mx, int32_t *has_nan);   /* owned rows only */

@@ -398,6 +398,8 @@ struct mhip_ctx {
     FillStats fill_st, noflat_st;
     std::map<int, std::pair<hipEvent_t, hipEvent_t>> ev;
     std::map<int, bool> ev_valid;
+    void *comm = nullptr;   // RCCL communicator over all bands (comm.hip); nullptr: the launcher moves the rows
+    DevBuf comm_stage, comm_word, comm_flags;
     // second stream + fork/join events of the stage DAG (mhip_ctx_run)
     hipStream_t stream_b = nullptr, stream_c = nullptr;
     hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr, ev_label = nullptr;
@@ -435,20 +437,22 @@ static int ctx_events(mhip_ctx *c, int stage, hipEvent_t **a, hipEvent_t **b)
 
 int mhip_comm_unique_id(void *id128)
 {
-    (void)id128;
-    set_error("the RCCL transport is not built into this library yet: bands exchange their halo rows through the host "
-              "launcher (mhip_ctx_get_edge_row / mhip_ctx_set_halo_row)");
-    return MHIP_ECOMM;
+    MH_ARG(id128, "comm_unique_id(id128)");
+    MH_TRY(require_device());
+    return comm_unique_id(id128);
 }
 
 int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t row0, int64_t H_local, int device, int rank,
                          int nranks, const void *nccl_unique_id)
 {
     MH_ARG(out && H_global >= 1 && W >= 1 && H_local >= 1 && row0 >= 0 && row0 + H_local <= H_global, "ctx_create_band geometry");
-    (void)nccl_unique_id;
+    MH_ARG(rank >= 0 && nranks >= 1 && rank < nranks, "ctx_create_band(rank, nranks)");
     MH_TRY(require_device());
     MH_HIP(hipSetDevice(device));
+    void *comm = nullptr;
+    if (nccl_unique_id) MH_TRY(comm_create(&comm, nccl_unique_id, rank, nranks));   // collective over all bands
     mhip_ctx *c = new mhip_ctx();
+    c->comm = comm;
     c->ht = row0 > 0 ? 1 : 0;
     c->hb = row0 + H_local < H_global ? 1 : 0;
     c->H_owned = H_local;
@@ -456,6 +460,7 @@ int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t ro
     c->W = W; c->H_global = H_global; c->row0 = row0;
     c->device = device; c->rank = rank; c->nranks = nranks;
     if (hipStreamCreate(&c->stream) != hipSuccess) {
+        comm_destroy(c->comm);
         delete c;
         set_error("hipStreamCreate failed");
         return MHIP_EHIP;
@@ -489,6 +494,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
         if (e) (void)hipEventDestroy(e);
     delete c->run[0];
     delete c->run[1];
+    comm_destroy(c->comm);
     delete c;
     return MHIP_OK;
 }
@@ -623,6 +629,55 @@ int mhip_ctx_set_halo_row_dev(mhip_ctx *c, int which, int side, const void *dev_
     if (changed) *changed = ch;
     return MHIP_OK;
 }
+
+/* RCCL transport (band contexts created with an ncclUniqueId): neighbours trade the edge rows of raster `which` GPU -> GPU
+ * on the context's stream; the received rows are compared with / stored into the halo rows; changed[0 / 1] = top / bottom
+ * halo row changed.  One host synchronisation (the two flags). */
+int mhip_ctx_exchange_halo(mhip_ctx *c, int which, int32_t *changed)
+{
+    MH_ARG(c && changed && which >= 0 && which < MHIP_R_COUNT_, "ctx_exchange_halo(ctx, which, changed[2])");
+    MH_ARG(c->comm || c->nranks == 1, "this band context has no RCCL communicator (created without an ncclUniqueId)");
+    changed[0] = changed[1] = 0;
+    if (!c->ht && !c->hb) return MHIP_OK;
+    MH_ARG(c->r[which].p, "raster has not been computed or uploaded");
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = cs(c);
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    MH_TRY(c->comm_stage.alloc(2 * rowb));
+    MH_TRY(c->comm_flags.alloc(8));
+    MH_HIP(hipMemsetAsync(c->comm_flags.p, 0, 8, s));
+    char *base = c->r[which].as<char>();
+    MH_TRY(comm_exchange_rows(c->comm, c->rank, c->nranks, base + rowb * c->ht, base + rowb * (c->ht + c->H_owned - 1), c->comm_stage.p, rowb, s));
+    if (c->ht) MH_TRY(row_update_async(base, c->comm_stage.p, (int64_t)rowb, c->comm_flags.as<int>(), s));
+    if (c->hb) MH_TRY(row_update_async(base + rowb * (c->H - 1), c->comm_stage.as<char>() + rowb, (int64_t)rowb, c->comm_flags.as<int>() + 1, s));
+    int h[2] = {0, 0};
+    MH_HIP(hipMemcpyAsync(h, c->comm_flags.p, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    changed[0] = h[0];
+    changed[1] = h[1];
+    return MHIP_OK;
+}
+
+/* max of `value` over all bands (ends the fill / accumulation loops: "is anybody still active") */
+int mhip_ctx_allreduce_max(mhip_ctx *c, double value, double *out)
+{
+    MH_ARG(c && out, "ctx_allreduce_max(ctx, value, out)");
+    if (c->nranks == 1 && !c->comm) {
+        *out = value;
+        return MHIP_OK;
+    }
+    MH_ARG(c->comm, "this band context has no RCCL communicator (created without an ncclUniqueId)");
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = cs(c);
+    MH_TRY(c->comm_word.alloc(8));
+    MH_HIP(hipMemcpyAsync(c->comm_word.p, &value, 8, hipMemcpyHostToDevice, s));
+    MH_TRY(comm_allreduce_max(c->comm, c->comm_word.as<double>(), s));
+    MH_HIP(hipMemcpyAsync(out, c->comm_word.p, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
+}
+
+int mhip_ctx_has_comm(mhip_ctx *c) { return (c && c->comm) ? 1 : 0; }
 
 int mhip_ctx_zero_raster(mhip_ctx *c, int which)
 {

@@ -144,6 +144,14 @@ int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_ou
            int64_t Hg = 0);
 int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
+int row_update_async(void *d_dst, const void *d_src, int64_t nbytes, int *d_changed, hipStream_t s);
+// comm.hip (RCCL, opened at run time)
+int comm_unique_id(void *id128);
+int comm_create(void **comm, const void *id128, int rank, int nranks);
+void comm_destroy(void *comm);
+int comm_exchange_rows(void *comm, int rank, int nranks, const void *first_row, const void *last_row, void *stage, size_t rowbytes,
+                       hipStream_t s);
+int comm_allreduce_max(void *comm, double *d_value, hipStream_t s);
 // accum.hip
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0);
 // ccl.hip   (d_tmp: H*W int32 scratch)

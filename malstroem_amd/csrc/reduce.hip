@@ -94,6 +94,15 @@ int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed,
     return MHIP_OK;
 }
 
+// the same without the read-back: *d_changed (device word, cleared by the caller) is set when any byte differed
+int row_update_async(void *d_dst, const void *d_src, int64_t nbytes, int *d_changed, hipStream_t s)
+{
+    hipLaunchKernelGGL(row_update_kernel, dim3((unsigned)cdiv(nbytes, 256)), dim3(256), 0, s, (uint8_t *)d_dst, (const uint8_t *)d_src,
+                       nbytes, d_changed);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
 // fill.py:235-250: maxval = f64(max(|amax|,|amin|)); short = (nextafter(maxval, inf) - maxval) * 1024; diag = short * 2**0.5
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s)
 {

@@ -7,13 +7,21 @@ ends the loop -- the result is bit-identical to the single-raster fill because t
 schedule independent (csrc/fill.hip).  D8 needs one halo row of the no-flats surface and hands its own edge
 rows to the neighbours afterwards (accumulation / watersheds walk across bands on them).
 
-Transport: ``Comm`` moves a few rows (W * 4..8 bytes each) per exchange.  ``TorchComm`` uses
-``torch.distributed`` (plumbing only; gloo on host buffers today -- the product path stays torch-free);
-``ThreadComm`` connects several bands inside one process (tests on a single GPU).  The compute backend is
-``HipBand`` (the C-ABI band context); tests may substitute a CPU stand-in to exercise the protocol over gloo.
+Transport.  The DATA path -- neighbour exchange of edge rows and the one-word "anybody still active" reduction -- runs
+over RCCL inside the library (``mhip_ctx_exchange_halo`` / ``mhip_ctx_allreduce_max``: ncclSend/ncclRecv between band
+neighbours over xGMI on the band's own stream, no host hop).  The CONTROL path -- handing the 128-byte ncclUniqueId to
+every rank and the few small Python-object collectives of the label / watershed boundary systems -- goes through a
+``Comm`` the launcher supplies: ``SocketComm`` (stdlib TCP, rank 0 as hub: nothing but Python is needed),
+``ThreadComm`` (several bands inside one process: tests on a single GPU), or any object with the same four methods
+(``tools/launch_comm.TorchComm`` wraps torch.distributed/gloo for launchers that already live in that world; this
+package itself never imports it).  Without RCCL (one GPU shared by several bands, CPU stand-in backends in the
+tests) the rows travel through the ``Comm`` as host buffers.  The compute backend is ``HipBand`` (the C-ABI band context).
 """
 import ctypes
+import pickle
 import queue
+import socket
+import struct
 import threading
 
 import numpy as np
@@ -22,7 +30,7 @@ from . import _lib
 from ._lib import INDEX_DTYPE, R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_ACCUM, STAGE_FLOWDIR, STAT_DTYPE
 from .pipeline import RASTERS
 
-__all__ = ["band_rows", "Comm", "ThreadComm", "TorchComm", "HipBand", "BandPipeline"]
+__all__ = ["band_rows", "Comm", "SingleComm", "ThreadComm", "SocketComm", "HipBand", "BandPipeline"]
 
 
 def band_rows(H, size, rank):
@@ -118,158 +126,117 @@ class ThreadComm(Comm):
         return ThreadComm(w, self.rank)
 
 
-class TorchComm(Comm):
-    """torch.distributed transport on host buffers (gloo).  Plumbing only: no tensor ever reaches a kernel."""
+class SocketComm(Comm):
+    """Control-plane transport over plain TCP sockets (stdlib only): rank 0 listens on (addr, port), every other rank
+    connects once; a collective is "send my pickled object to rank 0, receive the list of everybody's".  Messages are a
+    few rows at most (the boundary systems of the label / watershed protocols, the 128-byte ncclUniqueId), so the star
+    topology is not a bottleneck; the rows of the fills travel over RCCL, not through here.
 
-    def __init__(self, group=None):
-        import torch
-        import torch.distributed as dist
-        self._torch, self._dist, self._group = torch, dist, group
-        self.rank = dist.get_rank(group)
-        self.size = dist.get_world_size(group)
+    ``SocketComm.from_env()`` reads RANK / WORLD_SIZE / MASTER_ADDR / MALSTROEM_COMM_PORT (default MASTER_PORT + 17)."""
 
-    def exchange_rows(self, to_up, to_down):
-        torch, dist = self._torch, self._dist
-        ops, recv_up, recv_down, keep = [], None, None, []
-        if self.rank > 0:
-            t = torch.from_numpy(np.ascontiguousarray(to_up).view(np.uint8).reshape(-1).copy())
-            recv_up = torch.empty_like(t)
-            keep.append(t)
-            ops += [dist.P2POp(dist.isend, t, self.rank - 1, self._group), dist.P2POp(dist.irecv, recv_up, self.rank - 1, self._group)]
-        if self.rank < self.size - 1:
-            t = torch.from_numpy(np.ascontiguousarray(to_down).view(np.uint8).reshape(-1).copy())
-            recv_down = torch.empty_like(t)
-            keep.append(t)
-            ops += [dist.P2POp(dist.isend, t, self.rank + 1, self._group), dist.P2POp(dist.irecv, recv_down, self.rank + 1, self._group)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        like_up = to_up if to_up is not None else to_down
-        like_down = to_down if to_down is not None else to_up
-        from_up = None if recv_up is None else recv_up.numpy().view(like_up.dtype).reshape(like_up.shape)
-        from_down = None if recv_down is None else recv_down.numpy().view(like_down.dtype).reshape(like_down.shape)
-        return from_up, from_down
-
-    def allreduce_max(self, value):
-        t = self._torch.tensor([float(value)], dtype=self._torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
-        return float(t[0])
-
-    def allgather(self, obj):
-        out = [None] * self.size
-        self._dist.all_gather_object(out, obj, group=self._group)
-        return out
-
-    def clone(self):
-        return TorchComm(self._dist.new_group(backend="gloo"))   # host collectives only (RcclComm's rows stay on the original)
-
-
-class RcclComm(TorchComm):
-    """Halo rows travel GPU -> GPU over RCCL (``torch.distributed`` backend "nccl" IS RCCL on ROCm; band neighbours are
-    xGMI peers): the band copies its edge rows into small device tensors, one ``batch_isend_irecv`` per exchange moves
-    them, the band reads its halo rows back from device tensors -- no host staging.  The Python-object collectives of the
-    labelling / watershed protocols (a few rows per band) and the one-float all-reduce stay on the host group (gloo).
-
-    ``RcclComm.create(device)`` builds the extra process group and runs a self test (every rank sends a pattern to its
-    neighbours and checks what it receives); any failure on any rank makes ALL ranks fall back to ``TorchComm``."""
-
-    device_rows = True
-
-    def __init__(self, device, group=None, timeout_s=120, backend="nccl"):
-        """``backend="gloo"`` with ``device="cpu"`` runs the same protocol on host tensors (CPU tests of this class)."""
-        super(RcclComm, self).__init__(group)
-        import datetime
-        torch, dist = self._torch, self._dist
-        if backend == "nccl":
-            if not torch.cuda.is_available():
-                # torch bundles its own HIP runtime: it must be imported BEFORE libmalstroem_hip is loaded, then both share it
-                raise RuntimeError("torch sees no GPU (import torch before the first malstroem_amd call in this process)")
-            torch.cuda.set_device(int(device))
-            self.device = torch.device("cuda", int(device))
+    def __init__(self, rank, size, addr="127.0.0.1", port=29517, timeout_s=300.0, _socks=None):
+        self.rank, self.size, self._addr, self._port, self._timeout = int(rank), int(size), addr, int(port), float(timeout_s)
+        self._lock = threading.Lock()
+        self._nclones = 0
+        if _socks is not None:
+            self._peers, self._hub = _socks
+            return
+        self._peers, self._hub = {}, None
+        if self.size == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, self._port))
+            srv.listen(self.size)
+            srv.settimeout(self._timeout)
+            try:
+                while len(self._peers) < self.size - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(self._timeout)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    r = struct.unpack("<i", self._recv_exact(conn, 4))[0]
+                    self._peers[r] = conn
+            finally:
+                srv.close()
         else:
-            self.device = torch.device("cpu")
-        self._pg = dist.new_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
-        self._bufs = {}
+            import time
+            deadline = time.time() + self._timeout
+            while True:
+                try:
+                    self._hub = socket.create_connection((addr, self._port), timeout=self._timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            self._hub.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._hub.sendall(struct.pack("<i", self.rank))
 
     @classmethod
-    def create(cls, device, group=None, backend="nccl"):
-        """-> RcclComm, or a plain TorchComm when RCCL is unusable here (decided collectively)."""
-        host = TorchComm(group)
-        ok, comm, why = 1.0, None, ""
-        try:
-            comm = cls(device, group, backend=backend)
-            comm.self_test()
-        except Exception as e:  # any rank's failure is everybody's fallback
-            ok, why = 0.0, "%s: %s" % (type(e).__name__, e)
-        if host.allreduce_max(1.0 - ok) > 0.0:
-            if why and host.rank == 0:
-                import warnings
-                warnings.warn("RCCL halo transport unavailable (%s): using host-staged gloo" % why[:200], RuntimeWarning)
-            return host
-        return comm
+    def from_env(cls, env=None):
+        import os
+        env = os.environ if env is None else env
+        port = int(env.get("MALSTROEM_COMM_PORT", int(env.get("MASTER_PORT", "29500")) + 17))
+        return cls(int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1")), env.get("MASTER_ADDR", "127.0.0.1"), port)
 
-    def _pair(self, nbytes, key):
-        b = self._bufs.get((key, nbytes))
-        if b is None:
-            torch = self._torch
-            b = (torch.empty(nbytes, dtype=torch.uint8, device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
-            self._bufs[(key, nbytes)] = b
-        return b
+    @staticmethod
+    def _recv_exact(sock, n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("SocketComm: peer closed the connection")
+            buf += chunk
+        return bytes(buf)
 
-    def exchange_device_rows(self, nbytes, fill_send, take_recv):
-        """``fill_send(side, ptr)`` writes my edge row for neighbour ``side`` (0 up, 1 down) to device address ``ptr``;
-        ``take_recv(side, ptr)`` consumes the row that arrived from that neighbour.  Returns take_recv's results."""
-        torch, dist = self._torch, self._dist
-        ops, sides = [], []
-        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
-            if 0 <= peer < self.size:
-                snd, rcv = self._pair(nbytes, side)
-                fill_send(side, snd.data_ptr())      # synchronous on the band's stream: the row is in `snd` on return
-                ops += [dist.P2POp(dist.isend, snd, peer, self._pg), dist.P2POp(dist.irecv, rcv, peer, self._pg)]
-                sides.append((side, rcv))
-        out = {0: False, 1: False}
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if self.device.type == "cuda":
-                torch.cuda.synchronize(self.device)  # RCCL ran on torch's stream; the band reads on its own
-            for side, rcv in sides:
-                out[side] = take_recv(side, rcv.data_ptr())
-        return out[0], out[1]
+    @classmethod
+    def _send_msg(cls, sock, payload):
+        sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+    @classmethod
+    def _recv_msg(cls, sock):
+        n = struct.unpack("<q", cls._recv_exact(sock, 8))[0]
+        return cls._recv_exact(sock, n)
+
+    def allgather(self, obj):
+        if self.size == 1:
+            return [obj]
+        with self._lock:
+            if self.rank == 0:
+                parts = [None] * self.size
+                parts[0] = obj
+                for r, conn in self._peers.items():
+                    parts[r] = pickle.loads(self._recv_msg(conn))
+                blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+                for conn in self._peers.values():
+                    self._send_msg(conn, blob)
+                return parts
+            self._send_msg(self._hub, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
+            return pickle.loads(self._recv_msg(self._hub))
 
     def allreduce_max(self, value):
-        """the per-batch "is anybody still active" flag: on the device group too (one small RCCL all-reduce instead of a
-        gloo round over TCP); the host threads' object collectives stay on gloo"""
-        if self.device.type != "cuda":
-            return super(RcclComm, self).allreduce_max(value)
-        t = self._torch.tensor([float(value)], dtype=self._torch.float64, device=self.device)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._pg)
-        return float(t.item())
+        return max(self.allgather(float(value)))
 
-    def self_test(self):
-        torch = self._torch
-        n = 4096
-        got = {}
+    def exchange_rows(self, to_up, to_down):
+        """host-staged neighbour exchange (bands without RCCL): everybody's edge rows pass through the hub"""
+        rows = self.allgather((to_up, to_down))
+        from_up = rows[self.rank - 1][1] if self.rank > 0 else None
+        from_down = rows[self.rank + 1][0] if self.rank < self.size - 1 else None
+        return from_up, from_down
 
-        def fill(side, ptr):
-            snd, _ = self._pair(n, side)
-            snd.fill_((self.rank * 2 + side) % 251)
+    def clone(self):
+        """a second, independent set of connections on the next port (collective call)"""
+        self._nclones += 1
+        return SocketComm(self.rank, self.size, self._addr, self._port + self._nclones, self._timeout)
 
-        def take(side, ptr):
-            _, rcv = self._pair(n, side)
-            got[side] = int(rcv[0].item()), bool((rcv == rcv[0]).all().item())
-            return True
-
-        self.exchange_device_rows(n, fill, take)
-        for side, peer in ((0, self.rank - 1), (1, self.rank + 1)):
-            if 0 <= peer < self.size:
-                want = (peer * 2 + (1 - side)) % 251    # the neighbour's row for MY direction
-                if got.get(side) != (want, True):
-                    raise RuntimeError("RCCL self test: rank %d side %d received %r, expected %d" % (self.rank, side, got.get(side), want))
-        t = torch.ones(1, device=self.device)
-        self._dist.all_reduce(t, group=self._pg)
-        if int(t.item()) != self.size:
-            raise RuntimeError("RCCL self test: all_reduce returned %r" % (t.item(),))
+    def close(self):
+        for c in list(self._peers.values()) + ([self._hub] if self._hub else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._peers, self._hub = {}, None
 
 
 # ---- compute backend: one band context on one GPU -----------------------------------------------------------------
@@ -277,11 +244,37 @@ class RcclComm(TorchComm):
 class HipBand(object):
     """ctypes face of a band ``mhip_ctx`` (include/malstroem_hip.h, row-band protocol)."""
 
-    def __init__(self, H_global, W, row0, nrows, device=0, rank=0, size=1):
+    def __init__(self, H_global, W, row0, nrows, device=0, rank=0, size=1, unique_id=None):
+        """``unique_id``: the 128 bytes of rank 0's ``HipBand.new_unique_id()``; with it the context joins the RCCL
+        communicator of all ``size`` bands (a collective call) and moves its halo rows itself."""
         self.W, self.nrows = int(W), int(nrows)
         self._ctx = ctypes.c_void_p()
+        uid = None
+        if unique_id is not None:
+            if len(unique_id) != 128:
+                raise ValueError("ncclUniqueId must be 128 bytes")
+            uid = ctypes.create_string_buffer(bytes(unique_id), 128)
         _lib.call("mhip_ctx_create_band", ctypes.byref(self._ctx), _lib.i64(H_global), _lib.i64(W), _lib.i64(row0),
-                  _lib.i64(nrows), int(device), int(rank), int(size), None)
+                  _lib.i64(nrows), int(device), int(rank), int(size), uid)
+        self.has_comm = bool(_lib.load().mhip_ctx_has_comm(self._ctx))
+
+    @staticmethod
+    def new_unique_id():
+        """ncclGetUniqueId through the library (rank 0 calls it, the launcher's ``Comm`` distributes the bytes)."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.call("mhip_comm_unique_id", buf)
+        return bytes(buf.raw)
+
+    def exchange_halo(self, name):
+        """RCCL neighbour exchange of raster ``name``'s edge rows -> (top halo changed, bottom halo changed)."""
+        changed = (ctypes.c_int32 * 2)(0, 0)
+        _lib.call("mhip_ctx_exchange_halo", self._ctx, RASTERS[name], changed)
+        return bool(changed[0]), bool(changed[1])
+
+    def allreduce_max(self, value):
+        out = ctypes.c_double(0.0)
+        _lib.call("mhip_ctx_allreduce_max", self._ctx, ctypes.c_double(float(value)), ctypes.byref(out))
+        return out.value
 
     def close(self):
         if self._ctx:
@@ -428,12 +421,36 @@ class HipBand(object):
 class BandPipeline(object):
     """One rank's share of a row-banded DEM.  Every rank calls the same methods in the same order (SPMD)."""
 
-    def __init__(self, comm, shape, device=0, backend_factory=None):
+    def __init__(self, comm, shape, device=0, backend_factory=None, rccl=None):
+        """``rccl``: True = the bands join an RCCL communicator inside the library and move their halo rows GPU -> GPU
+        (one rank per GPU required), False = rows travel through ``comm`` as host buffers, None = RCCL whenever there is
+        more than one rank and the backend is the HIP one.  Creation is voted on: if any rank fails, every rank raises."""
         self.comm = comm
         self.H, self.W = int(shape[0]), int(shape[1])
         self.row0, self.nrows = band_rows(self.H, comm.size, comm.rank)
         factory = backend_factory or HipBand
-        self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size)
+        if rccl is None:
+            rccl = comm.size > 1 and factory is HipBand
+        self.band, err = None, None
+        try:
+            uid = None
+            if rccl and comm.size > 1:
+                try:
+                    mine = getattr(factory, "new_unique_id", HipBand.new_unique_id)() if comm.rank == 0 else None
+                except Exception as e:
+                    mine, err = None, e
+                uid = comm.allgather(mine)[0]          # every rank takes part, whatever happened on rank 0
+                if uid is None:
+                    raise err or RuntimeError("rank 0 could not create an ncclUniqueId")
+            kw = dict(unique_id=uid) if uid is not None else {}
+            self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size, **kw)
+        except Exception as e:
+            err = err or e
+        if comm.allreduce_max(1.0 if err is not None else 0.0) > 0.0:
+            if self.band is not None:
+                self.band.close()
+            raise err if err is not None else RuntimeError("band setup failed on another rank")
+        self.rccl = bool(getattr(self.band, "has_comm", False))
         self.has_up = comm.rank > 0
         self.has_down = comm.rank < comm.size - 1
         self.exchanges = {"fill": 0, "noflat": 0}
@@ -444,12 +461,23 @@ class BandPipeline(object):
         self.band.close()
 
     # ---- helpers
+    def _allreduce_max(self, value):
+        """data-path reduction of the iteration loops: RCCL when the band owns a communicator"""
+        return self.band.allreduce_max(value) if self.rccl else self.comm.allreduce_max(value)
+
+    def _vote(self, busy, err=None):
+        """all-reduce of "still busy" that also carries failures: a rank that caught an exception votes 2 and every
+        rank leaves the loop with an error instead of waiting for the failed one in the next collective"""
+        m = self._allreduce_max(2.0 if err is not None else (1.0 if busy else 0.0))
+        if m >= 2.0:
+            raise err if err is not None else RuntimeError("another band failed in this stage")
+        return m > 0.0
+
     def _swap_edges(self, name):
         """Neighbours trade edge rows of raster ``name``; returns which of my halo rows changed (top, bottom)."""
         b = self.band
-        if getattr(self.comm, "device_rows", False) and hasattr(b, "get_edge_row_dev"):
-            return self.comm.exchange_device_rows(b.row_bytes(name), lambda side, ptr: b.get_edge_row_dev(name, side, ptr),
-                                                  lambda side, ptr: b.set_halo_row_dev(name, side, ptr))
+        if self.rccl:
+            return b.exchange_halo(name)
         to_up = b.get_edge_row(name, 0) if self.has_up else None
         to_down = b.get_edge_row(name, 1) if self.has_down else None
         from_up, from_down = self.comm.exchange_rows(to_up, to_down)
@@ -464,18 +492,30 @@ class BandPipeline(object):
 
     def _fill(self, kind, name, short=0.0, diag=0.0):
         b = self.band
-        active = b.fill_begin(kind, short, diag)
+        err, active = None, False
+        try:
+            active = b.fill_begin(kind, short, diag)
+        except Exception as e:
+            err = e
         while True:
-            ch_top, ch_bot = self._swap_edges(name)
-            if ch_top:
-                b.fill_halo_changed(kind, 0)
-            if ch_bot:
-                b.fill_halo_changed(kind, 1)
-            self.exchanges["noflat" if kind else "fill"] += 1
-            busy = active or ch_top or ch_bot
-            if not self.comm.allreduce_max(1.0 if busy else 0.0):
+            busy = False
+            if err is None:
+                try:
+                    ch_top, ch_bot = self._swap_edges(name)
+                    if ch_top:
+                        b.fill_halo_changed(kind, 0)
+                    if ch_bot:
+                        b.fill_halo_changed(kind, 1)
+                    self.exchanges["noflat" if kind else "fill"] += 1
+                    busy = active or ch_top or ch_bot
+                except Exception as e:
+                    err = e
+            if not self._vote(busy, err):
                 break
-            active = b.fill_batch(kind) if busy else False
+            try:
+                active = b.fill_batch(kind) if busy else False
+            except Exception as e:
+                err = e
         b.fill_end(kind)
 
     def fill(self):
@@ -510,10 +550,14 @@ class BandPipeline(object):
         b.zero_raster("accum")
         self.exchanges["accum"] = 0
         while True:
-            b.run_accum()
-            ch_top, ch_bot = self._swap_edges("accum")
-            self.exchanges["accum"] += 1
-            if not self.comm.allreduce_max(1.0 if (ch_top or ch_bot) else 0.0):
+            err, ch_top, ch_bot = None, False, False
+            try:
+                b.run_accum()
+                ch_top, ch_bot = self._swap_edges("accum")
+                self.exchanges["accum"] += 1
+            except Exception as e:
+                err = e
+            if not self._vote(ch_top or ch_bot, err):
                 break
 
     def label(self):
@@ -762,25 +806,26 @@ class BandPipeline(object):
         import sys
         old_switch = sys.getswitchinterval()
         sys.setswitchinterval(1e-4)
-        th = threading.Thread(target=label_branch)
-        th.start()
-        try:
-            try:
-                timed("noflat", self.noflat)
-                timed("flowdir", self.flowdir)
-            finally:
-                th.join()
-            if err:
-                raise err[0]
-            # like the single-GPU DAG: watersheds (need labels + flow directions) next to the accumulation
-            th = threading.Thread(target=ws_branch)
+        def together(main_steps, side):
+            """main_steps on this thread next to `side` on a second one; failures on either thread of ANY rank are voted
+            on (host communicator) after the join, so that all ranks raise together instead of one rank leaving the others
+            inside their next collective"""
+            th = threading.Thread(target=side)
             th.start()
             try:
-                timed("accum", self.accum)
+                for name, fn in main_steps:
+                    timed(name, fn)
+            except Exception as e:
+                err.append(e)
             finally:
                 th.join()
-            if err:
-                raise err[0]
+            if self.comm.allreduce_max(1.0 if err else 0.0) > 0.0:
+                raise err[0] if err else RuntimeError("another band failed in this phase of the chain")
+
+        try:
+            together([("noflat", self.noflat), ("flowdir", self.flowdir)], label_branch)
+            # like the single-GPU DAG: watersheds (need labels + flow directions) next to the accumulation
+            together([("accum", self.accum)], ws_branch)
         finally:
             sys.setswitchinterval(old_switch)
         if records:

@@ -7,8 +7,19 @@ import oracle
 
 
 class CpuBand(object):
-    def __init__(self, H_global, W, row0, nrows, device=0, rank=0, size=1):
+    def __init__(self, H_global, W, row0, nrows, device=0, rank=0, size=1, unique_id=None):
         self.Hg, self.W, self.row0, self.nrows = H_global, W, row0, nrows
+        self.rank, self.size = rank, size
+        # stand-in for the library's RCCL communicator: the "unique id" carries a TCP port and every band joins a
+        # SocketComm on it (a collective call, like ncclCommInitRank), so BandPipeline's in-library transport path
+        # (band.exchange_halo / band.allreduce_max) runs on CPU boxes too
+        self.has_comm = False
+        self._comm = None
+        if unique_id is not None and size > 1:
+            import struct
+            from malstroem_amd.distributed import SocketComm
+            self._comm = SocketComm(rank, size, "127.0.0.1", struct.unpack("<i", unique_id[:4])[0], timeout_s=120)
+            self.has_comm = True
         self.ht = 1 if row0 > 0 else 0
         self.hb = 1 if row0 + nrows < H_global else 0
         self.H = nrows + self.ht + self.hb
@@ -16,7 +27,24 @@ class CpuBand(object):
         self.kind_state = {}
 
     def close(self):
-        pass
+        if self._comm is not None:
+            self._comm.close()
+
+    @staticmethod
+    def new_unique_id():
+        import os
+        import struct
+        port = int(os.environ.get("CPUBAND_COMM_PORT", "0")) or (31000 + os.getpid() % 2000)
+        return struct.pack("<i", port) + bytes(124)
+
+    def exchange_halo(self, name):
+        has_up, has_down = self.rank > 0, self.rank < self.size - 1
+        from_up, from_down = self._comm.exchange_rows(self.get_edge_row(name, 0) if has_up else None,
+                                                      self.get_edge_row(name, 1) if has_down else None)
+        return (self.set_halo_row(name, 0, from_up) if has_up else False, self.set_halo_row(name, 1, from_down) if has_down else False)
+
+    def allreduce_max(self, value):
+        return self._comm.allreduce_max(value) if self._comm is not None else value
 
     def _dtype(self, name):
         return {"dem": np.float32, "filled": np.float32, "depths": np.float32, "noflat": np.float64, "flowdir": np.uint8,

@@ -110,10 +110,12 @@ def test_protocol_threadcomm_cpu_backend(nbands):
 WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
 import numpy as np, torch.distributed as dist
 from _cases import fbm
 from _cpu_band import CpuBand
-from malstroem_amd.distributed import BandPipeline, TorchComm
+from launch_comm import TorchComm
+from malstroem_amd.distributed import BandPipeline
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 dem = fbm(90, 70, beta=2.0, seed=4)
 p = BandPipeline(TorchComm(), dem.shape, backend_factory=CpuBand)
@@ -125,24 +127,39 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-WORKER_DEVROWS = WORKER.replace("from malstroem_amd.distributed import BandPipeline, TorchComm",
-                                "from malstroem_amd.distributed import BandPipeline, RcclComm").replace(
-    "p = BandPipeline(TorchComm(), dem.shape, backend_factory=CpuBand)",
-    "comm = RcclComm.create('cpu', backend='gloo')\nassert comm.device_rows\np = BandPipeline(comm, dem.shape, backend_factory=CpuBand)").replace(
-    "p.fill(); p.noflat(); p.flowdir(); p.accum(); n = p.label(); p.watershed()",
-    "p.run_chain(); n = p.nlabels   # labelling branch on a second thread and a cloned (gloo) communicator")
+# the package's own stdlib transport for the control path + the in-library transport path for the rows (the CPU stand-in
+# joins a socket "communicator" where HipBand joins RCCL), whole chain with the labelling branch on a second thread
+WORKER_SOCKET = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+import numpy as np
+from _cases import fbm
+from _cpu_band import CpuBand
+from malstroem_amd.distributed import BandPipeline, SocketComm
+assert "torch" not in sys.modules
+comm = SocketComm.from_env()
+dem = fbm(90, 70, beta=2.0, seed=4)
+p = BandPipeline(comm, dem.shape, backend_factory=CpuBand, rccl=True)
+assert p.rccl and p.band.has_comm
+p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+p.run_chain(); n = p.nlabels
+np.savez(os.path.join(os.environ["OUT"], "rank%d.npz" % comm.rank), row0=p.row0, nlabels=n,
+         **{k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")})
+comm.allgather(None); p.close(); comm.close()
+assert "torch" not in sys.modules, "the product package pulled torch in"
+'''
 
 
-@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_DEVROWS)], ids=["host_rows_2", "device_row_protocol_3"])
+@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET)], ids=["host_rows_2", "socket_and_in_library_transport_3"])
 def test_protocol_gloo_processes(world, worker, tmp_path):
-    """Band protocol over real processes.  The second case drives the device-row transport class (RcclComm: per-neighbour
-    device buffers, one batch_isend_irecv per exchange, self test) with host tensors over gloo -- on a GPU node the same
-    code runs with backend "nccl" on cuda tensors."""
+    """Band protocol over real processes: (1) world size 2 over torch.distributed/gloo (tools/launch_comm.TorchComm), rows
+    staged through the host communicator; (2) world size 3 over the package's stdlib SocketComm with the rows on the band's
+    own communicator (BandPipeline's RCCL code path, socket stand-in) and the whole chain incl. the threaded label branch."""
     port = 29500 + (os.getpid() % 2000)
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   REPO=str(ROOT), OUT=str(tmp_path))
+                   REPO=str(ROOT), OUT=str(tmp_path), CPUBAND_COMM_PORT=str(port + 40))
         procs.append(subprocess.Popen([sys.executable, "-c", worker], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0

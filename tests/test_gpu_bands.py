@@ -129,42 +129,44 @@ def test_device_row_entry_points_match_host_ones():
         bot.close()
 
 
-RCCL_WORKER = r'''
-import os, sys
-sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
-import numpy as np, torch.distributed as dist
-from _cases import fbm
-from malstroem_amd.distributed import BandPipeline, RcclComm
-dist.init_process_group("gloo", rank=0, world_size=1)
-comm = RcclComm.create(0)                      # backend "nccl" == RCCL: group creation, cuda buffers, self test
-assert getattr(comm, "device_rows", False), "RCCL transport fell back to gloo on a GPU box"
-dem = fbm(200, 150, beta=2.0, seed=9)
-p = BandPipeline(comm, dem.shape, device=0)
-p.upload_dem(dem)
-p.fill(); p.noflat(); p.flowdir(); p.accum(); n = p.label(); p.watershed()
-np.savez(os.environ["OUT"], nlabels=n, **{k: p.download(k) for k in ("filled", "noflat", "flowdir", "accum", "labels", "watersheds")})
-p.close(); dist.destroy_process_group()
-'''
+def test_rccl_inside_the_library_single_rank():
+    """The library's own RCCL transport (comm.hip: librccl opened at run time, ncclGetUniqueId, ncclCommInitRank, the
+    all-reduce that ends the fill loops, ncclCommDestroy) on the only world size a one-GPU box offers; the band chain runs
+    through BandPipeline's RCCL code path.  Neighbour traffic (ncclSend / ncclRecv between two GPUs) first runs on the
+    driver's multi-GPU node; its protocol is covered by tests/test_distributed_cpu.py on the socket stand-in."""
+    from malstroem_amd.distributed import BandPipeline, HipBand, SingleComm
+    uid = HipBand.new_unique_id()
+    assert len(uid) == 128 and any(uid)
+    band = HipBand(64, 48, 0, 64, device=0, rank=0, size=1, unique_id=uid)
+    try:
+        assert band.has_comm
+        assert band.allreduce_max(3.5) == 3.5 and band.allreduce_max(-2.0) == -2.0
+        band.upload("dem", fbm(64, 48, seed=3))
+        assert band.exchange_halo("dem") == (False, False)      # no neighbours: nothing moves
+    finally:
+        band.close()
 
+    class OneRankRccl(SingleComm):
+        size = 1
 
-def test_rccl_transport_single_rank(tmp_path):
-    """The RCCL transport class on a real GPU with the only world size one box offers (1): process-group creation on the
-    "nccl" backend, device buffers, the self test and the band chain through it.  (Neighbour traffic itself is covered by
-    tests/test_distributed_cpu.py::test_protocol_gloo_processes[device_row_protocol_3] and the test above.)"""
-    import os, subprocess, sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parents[1]
-    out = tmp_path / "rccl.npz"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), REPO=str(root), OUT=str(out))
-    r = subprocess.run([sys.executable, "-c", RCCL_WORKER], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = np.load(out)
     dem = fbm(200, 150, beta=2.0, seed=9)
+    p = BandPipeline(OneRankRccl(), dem.shape, device=0, rccl=False)
+    p.band.close()
+    p.band = HipBand(200, 150, 0, 200, device=0, rank=0, size=1, unique_id=HipBand.new_unique_id())
+    p.rccl = True
+    try:
+        p.upload_dem(dem)
+        out = p.run_chain()
+        got = {k: p.download(k) for k in ("filled", "noflat", "flowdir", "accum", "labels", "watersheds")}
+        n = p.nlabels
+    finally:
+        p.close()
     filled = oracle.fill_terrain(dem)
     short, diag = oracle.minimum_safe_short_and_diag(dem)
     fnf = oracle.fill_terrain_no_flats(dem, short, diag)
     fd = oracle.terrain_flowdirection(fnf)
     assert np.array_equal(got["filled"], filled) and np.array_equal(got["noflat"], fnf) and np.array_equal(got["flowdir"], fd)
     assert np.array_equal(got["accum"], oracle.accumulated_flow(fd))
-    lab, n = oracle.connected_components(oracle.depths(filled, dem))
-    assert int(got["nlabels"]) == n and np.array_equal(got["labels"], lab)
+    lab, nref = oracle.connected_components(oracle.depths(filled, dem))
+    assert n == nref and np.array_equal(got["labels"], lab)
+    assert out["pour"] is not None

@@ -1,48 +1,58 @@
 #!/usr/bin/env python3
 """bench.py -- whole-job throughput of the raster hydrology hot path on MI355X.
 
-Metric (BASELINE.json): Mcells/s for fill -> D8 -> accumulation -> bluespot label (-> watershed, pour
-points) on a 16384^2 float32 fBm DEM, inputs resident in HBM when the timed region starts, plus the
-achieved fraction of the HBM roofline per stage (D8 stencil = the metric's second headline).
-
-A "step" is one pass of the whole chain over the DEM:
+Metric (BASELINE.json): Mcells/s for fill -> D8 -> accumulation -> bluespot label (-> watershed, pour points) with the
+inputs resident in HBM when the timed region starts, plus the achieved fraction of the HBM roofline per stage (the D8
+stencil is the metric's second headline).  A "step" is one pass of the whole chain over the DEM:
     fill (+depths) -> minimum_safe_short_and_diag + no-flats fill -> D8 -> accumulation ->
     connected components + label_stats -> (keep all) -> watersheds + label_count -> pour points (argmax accum)
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 16384] [--beta 2.0]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size S] [--beta 2.0] [--bands B] [--config 2|3]
 
-N > 1 is launched by torch.distributed.run (one process per GPU).  torch is used ONLY for rank plumbing
-(gloo: barrier, max-over-ranks of the timing, moving a few halo rows); the product itself is torch-free.
-N > 1 is WEAK scaling of ONE DEM: the global raster is (N * size) x size, row-banded over the GPUs
-(malstroem_amd.distributed.BandPipeline: halo-row exchange for the two fills, D8, accumulation, labelling with
-cross-band equivalences, watersheds).  Each band is the same fBm tile, mirrored on odd ranks so that the global
-surface is continuous across band boundaries.  The per-label record reductions (label_stats, label_count,
-pour points) are not band-merged yet and are left out of the N > 1 step (they are ~7 % of the N = 1 step).
-Should the band path fail on a box, the run falls back to one independent DEM per GPU and says so.
+Workloads (BASELINE.json `configs`):
+  N = 1 (default)    configs[2]: one 16384^2 fBm DEM on one GPU, one device context -- the configuration the metric is quoted on.
+  N > 1 (default)    configs[3]: ONE 65536^2 DEM row-banded over the N GPUs: STRONG scaling (total work fixed).  A band context
+                     addresses < 2**31 cells (int32 cell indices), so the raster is cut into B = max(N, 4) bands; with N < 4 a
+                     process drives B / N bands on its GPU as threads (N = 1 or 2: the 1- and 2-GPU points of the curve; pass
+                     --size 65536 to get the N = 1 point).  One band per GPU (N >= 4): halo rows travel GPU -> GPU over RCCL
+                     inside the library; several bands per GPU: through the host communicator.
+  --config 2         configs[1]: 4096^2, fill + no-flats + D8 only (stencil roofline bring-up), one GPU.
+The 65536^2 DEM is a two-octave variant of the SURVEY 8(d) recipe (an FFT of that size does not fit a rank's share of host
+memory): 0.5 x the periodic 16384^2 spectral fBm tile (seed 42, tiled 4 x 4) + 0.5 x a 1024^2 spectral fBm (seed 43)
+bilinearly upsampled x 64, every rank building only its own rows.
 
-Only the `cpu_baseline` leg touches oracle/ (the single-thread C restatement of the reference path),
-on a bounded sample, on rank 0 at N = 1.
+N > 1 is launched by torch.distributed.run (one process per GPU).  torch is used ONLY by this launcher for rank plumbing
+(gloo: barrier, max over ranks of the timing, the control-plane collectives of the band protocol and handing the
+ncclUniqueId to the ranks); the product package is torch-free.  If the band path fails on any rank the run exits non-zero:
+there is no fall-back to independent replicas.
+
+Only the `cpu_baseline` leg touches oracle/ (the single-thread C restatement of the reference path), on a bounded sample,
+on rank 0 at N = 1.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
+import traceback
 from pathlib import Path
 
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
 
 # algorithmic (compulsory) HBM bytes per cell, SURVEY.md 8(d) / BASELINE.md section 4
 # one request for the whole chain: the bluespot depths (12 B/cell) are computed on the label branch, not in the fill stage
 ALG_BYTES = {"fill": 8, "noflat": 12, "flowdir": 9, "accum": 9, "label": 12 + 8 + 8, "watershed": 9 + 4, "pourpoints": 12}
-#   fill      : fill 8 B (4 R + 4 W) + depths 12 B (4 + 4 R, 4 W)
-#   label     : CCL 8 B (4 R + 4 W) + label_stats 8 B (4 + 4 R)
+#   fill      : fill 8 B (4 R + 4 W)
+#   label     : depths 12 B (4 + 4 R, 4 W) + CCL 8 B (4 R + 4 W) + label_stats 8 B (4 + 4 R)
 #   watershed : 9 B (1 + 4 R, 4 W) + label_count 4 B
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the device-copy ceiling is measured below
 STAGES = ["fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints"]
+BAND_CELL_LIMIT = 2 ** 30   # cells per band context the bench aims for (hard limit of a context: 2**31 - 2)
 
 
 def fbm(n, beta=2.0, seed=42):
@@ -65,31 +75,83 @@ def fbm(n, beta=2.0, seed=42):
     return z.astype(np.float32)
 
 
-KERNEL_OF_STAGE = {"fill": "fill_round_kernel<float, ...> (one launch per round)", "noflat": "fill_round_kernel<double, ...> (one launch per round)",
-                   "flowdir": "d8_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "ccl_* + stats_kernel",
+class DemSource(object):
+    """Rows [row0, row0 + nrows) of the benchmark DEM of edge `size`, identical bits on every rank."""
+    TILE, COARSE = 16384, 1024
+
+    def __init__(self, size, beta):
+        self.size, self.beta = int(size), float(beta)
+        self.two_octave = self.size > self.TILE
+        if self.two_octave:
+            assert self.size % self.TILE == 0 and self.size % self.COARSE == 0, "large DEMs are multiples of 16384"
+            self.tile = fbm(self.TILE, beta=beta, seed=42)
+            self.coarse = fbm(self.COARSE, beta=beta, seed=43).astype(np.float64)
+            self.recipe = ("two-octave fBm beta=%g: 0.5 x periodic %d^2 spectral tile (seed 42) tiled %dx%d + 0.5 x %d^2 spectral "
+                           "fBm (seed 43) bilinearly upsampled x%d" % (beta, self.TILE, self.size // self.TILE, self.size // self.TILE,
+                                                                      self.COARSE, self.size // self.COARSE))
+        else:
+            self.full = fbm(self.size, beta=beta, seed=42)
+            self.recipe = "spectral fBm beta=%g seed 42 (SURVEY 8d recipe)" % beta
+
+    def rows(self, row0, nrows):
+        if not self.two_octave:
+            return np.ascontiguousarray(self.full[row0:row0 + nrows])
+        n, f, nc = self.size, self.size // self.COARSE, self.COARSE
+        out = np.empty((nrows, n), dtype=np.float32)
+        cx = np.arange(n, dtype=np.float64) / f
+        c0 = np.floor(cx).astype(np.int64) % nc
+        c1, ct = (c0 + 1) % nc, (cx - np.floor(cx))[None, :]
+        reps = n // self.TILE
+        for a in range(0, nrows, 1024):
+            r = np.arange(row0 + a, min(row0 + nrows, row0 + a + 1024), dtype=np.int64)
+            rx = r.astype(np.float64) / f
+            r0 = np.floor(rx).astype(np.int64) % nc
+            r1, rt = (r0 + 1) % nc, (rx - np.floor(rx))[:, None]
+            lr = (1.0 - rt) * self.coarse[r0] + rt * self.coarse[r1]                 # rows interpolated: len(r) x 1024
+            low = (1.0 - ct) * lr[:, c0] + ct * lr[:, c1]                             # columns interpolated: len(r) x n
+            det = np.tile(self.tile[r % self.TILE], (1, reps))
+            out[a:a + len(r)] = (0.5 * low + 0.5 * det.astype(np.float64)).astype(np.float32)
+        return out
+
+
+KERNEL_OF_STAGE = {"fill": "fill stage kernels (see stages.fill)", "noflat": "fill_round_kernel<double, ...> (one launch per round)",
+                   "flowdir": "d8_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "depths + ccl_* + stats_kernel",
                    "watershed": "ws_* + count_kernel", "pourpoints": "arg_packed_kernel"}
+# FETCH_SIZE under-counts wide coalesced streaming reads by 2 on gfx950 (MI355X_MICROARCH.md, HBM section): the correction
+# applies per kernel, by its load width (16 B per lane), not to the tile loads (4 / 8 B per lane) of the fills
+FETCH_X2 = ("d8_kernel", "depths_kernel", "minmax_kernel", "pf_apply_kernel", "noflat_seed_kernel")
+STAGE_KERNELS = {"flowdir": ("d8_kernel",), "fill": ("fill_round_kernel<float", "pf_"), "noflat": ("fill_round_kernel<double", "noflat_"),
+                 "accum": ("accum_",), "label": ("ccl_", "stats_", "depths_kernel"), "watershed": ("ws_", "count_kernel"),
+                 "pourpoints": ("arg_",)}
 
 
 def pmc_traffic(stage, n):
-    """HBM bytes of the stage's kernels from the newest committed rocprofv3 PMC table (profiles/*_pmc_hbm_traffic.json,
-    made by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2; FETCH_SIZE doubled for
-    the 16-byte-per-lane streaming reads of d8 / depths as MI355X_MICROARCH.md prescribes, left as reported for the
-    4-byte tile loads of the fills)."""
+    """HBM bytes of the stage's kernels from the newest committed rocprofv3 PMC table (profiles/*_pmc_hbm_traffic.json, made
+    by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2)."""
     tables = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
-    if n != 16384 or not tables:
+    if n != 16384 or not tables or stage not in STAGE_KERNELS:
         return None
     path = tables[-1]
-    kernels = {"flowdir": (("d8_kernel",), 2.0), "fill": (("fill_round_kernel<float",), 1.0),
-               "noflat": (("fill_round_kernel<double",), 1.0), "accum": (("accum_",), 1.0), "label": (("ccl_", "stats_"), 1.0),
-               "watershed": (("ws_", "count_kernel"), 1.0), "pourpoints": (("arg_",), 1.0)}
-    if stage not in kernels:
-        return None
-    prefixes, fcorr = kernels[stage]
     tot = 0.0
     for row in json.loads(path.read_text()):
-        if row["kernel"].startswith(prefixes):
+        if row["kernel"].startswith(STAGE_KERNELS[stage]):
+            fcorr = 2.0 if row["kernel"].startswith(FETCH_X2) else 1.0
             tot += (row["fetch_size_kb"] * fcorr + row["write_size_kb"]) * 1024.0
+    if tot == 0.0:
+        return None
     return {"hbm_bytes_per_stage": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "source": "profiles/" + path.name}
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 0
 
 
 def cpu_baseline(dem, sample):
@@ -110,8 +172,45 @@ def cpu_baseline(dem, sample):
     oracle.label_count(ws)
     oracle.label_max_index(acc, lab, n)
     dt = time.perf_counter() - t0
+    model, ncores = host_cpu()
     return {"value": round(crop.size / dt / 1e6, 3), "unit": "Mcells/s", "cores": 1, "kind": "port",
-            "sample": "%dx%d crop of the benchmark DEM, full chain, %.1f s" % (sample, sample, dt)}
+            "host_cpu": model, "host_cores": ncores,
+            "sample": "%dx%d crop of the benchmark DEM, full chain, %.1f s, 1 thread (the reference path is single-threaded)" % (sample, sample, dt)}
+
+
+class BandWorker(threading.Thread):
+    """One band of the row-banded DEM: owns a BandPipeline, runs one chain per step on request."""
+
+    def __init__(self, comm, shape, device, rccl, dem_rows_fn, gate):
+        super(BandWorker, self).__init__(daemon=True)
+        self.comm, self.shape, self.device, self.rccl, self.dem_rows_fn, self.gate = comm, shape, device, rccl, dem_rows_fn, gate
+        self.error, self.pipe, self.timings, self.stop = None, None, {}, False
+
+    def run(self):
+        from malstroem_amd.distributed import BandPipeline
+        try:
+            self.pipe = BandPipeline(self.comm, self.shape, device=self.device, rccl=self.rccl)
+            self.pipe.upload_dem(self.dem_rows_fn(self.pipe.row0, self.pipe.nrows))
+        except Exception as e:
+            traceback.print_exc()
+            self.error = e
+        self.gate.wait()                      # setup done (or failed) on every band of this process
+        while True:
+            self.gate.wait()                  # start of a step (or stop)
+            if self.stop:
+                break
+            if self.error is None:
+                try:
+                    tm = {}
+                    self.pipe.run_chain(records=True, fetch_own=False, overlap=os.environ.get("MALSTROEM_BAND_OVERLAP", "1") != "0", timings=tm)
+                    for k, v in tm.items():
+                        self.timings[k] = self.timings.get(k, 0.0) + v
+                except Exception as e:
+                    traceback.print_exc()
+                    self.error = e
+            self.gate.wait()                  # end of the step
+        if self.pipe is not None:
+            self.pipe.close()
 
 
 def main():
@@ -119,8 +218,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--size", type=int, default=0, help="DEM edge; default 16384 on one GPU, 65536 on several")
     ap.add_argument("--beta", type=float, default=2.0)
+    ap.add_argument("--bands", type=int, default=0, help="row bands in total (default: as many as the int32 cell domain needs, >= N)")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="2: 4096^2, fill + D8 only (BASELINE configs[1])")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -130,8 +231,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
-        import torch.distributed as dist  # plumbing only: barrier + max over ranks (gloo, CPU tensors)
-        import torch
+        import torch.distributed as dist  # launcher plumbing only (gloo, CPU tensors)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
@@ -139,56 +239,78 @@ def main():
     from malstroem_amd.pipeline import HydroPipeline
     if _lib.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libmalstroem_hip has no CPU fallback")
-
-    n = args.size
-    t_gen = time.perf_counter()
-    dem = fbm(n, beta=args.beta, seed=42)   # every rank builds the same tile (bands mirror it on odd ranks)
-    t_gen = time.perf_counter() - t_gen
-
     ndev = _lib.device_count()
     device = local_rank % ndev
-    parallelism = "1 GPU"
-    stage_names = STAGES
-    band = None
-    if world > 1:
-        try:
-            from malstroem_amd.distributed import BandPipeline, RcclComm, TorchComm
-            # halo rows GPU -> GPU over RCCL when it passes its self test on every rank, else host-staged gloo
-            transport = os.environ.get("MALSTROEM_BAND_TRANSPORT", "auto")
-            if world > ndev:
-                transport = "gloo"   # ranks share a GPU (rehearsal on a small box): RCCL wants one device per rank
-            comm = TorchComm() if transport == "gloo" else RcclComm.create(device)
-            band = BandPipeline(comm, (n * world, n), device=device)
-            band.upload_dem(dem if rank % 2 == 0 else dem[::-1])
-            parallelism = "row bands of one %dx%d DEM over %d GPUs, halo rows %s" % (
-                n * world, n, world, "GPU->GPU over RCCL send/recv" if getattr(comm, "device_rows", False) else "host-staged over gloo")
-            stage_names = ["fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints"]
-        except Exception as e:  # pragma: no cover - only on a multi-GPU node
-            import traceback
-            traceback.print_exc()
-            band = None
-            parallelism = "replicas only (band mode failed: %s)" % (str(e)[:80],)
-    pipe = None
-    if band is None:
-        pipe = HydroPipeline(dem.shape, device=device)
-        pipe.upload("dem", dem)
+
+    config2 = args.config == 2
+    n = args.size or (4096 if config2 else (16384 if world == 1 else 65536))
+    cells = float(n) * n
+    nbands = args.bands or max(world, -(-int(cells) // BAND_CELL_LIMIT))
+    nbands = -(-nbands // world) * world
+    band_mode = (world > 1 or nbands > 1) and not config2
+    stage_names = ["fill", "noflat", "flowdir"] if config2 else STAGES
+
+    t_gen = time.perf_counter()
+    src = DemSource(n, args.beta)
+    t_gen = time.perf_counter() - t_gen
 
     stage_ms = {s: 0.0 for s in stage_names}
+    pipe, workers, gate = None, [], None
+    parallelism = "1 GPU, one device context"
+    if band_mode:
+        from launch_comm import TorchComm
+        from malstroem_amd.distributed import HybridComm, SingleComm
+        k = nbands // world
+        proc_comm = TorchComm() if world > 1 else SingleComm()
+        rccl = k == 1 and world > 1 and world <= ndev and os.environ.get("MALSTROEM_BAND_TRANSPORT", "rccl") != "host"
+        comms = [proc_comm] if k == 1 else HybridComm.world(proc_comm, k)
+        gate = threading.Barrier(k + 1)
+        workers = [BandWorker(c, (n, n), device, rccl, src.rows, gate) for c in comms]
+        for w in workers:
+            w.start()
+        gate.wait()
+        parallelism = "%d row bands of one %dx%d DEM over %d GPU(s), %d band(s) per GPU; halo rows %s" % (
+            nbands, n, n, world, k, "GPU->GPU over RCCL inside the library (ncclSend/ncclRecv)" if rccl else "through the host communicator")
+    else:
+        pipe = HydroPipeline((n, n), device=device)
+        pipe.upload("dem", src.rows(0, n))
+
+    def failed():
+        bad = 1.0 if any(w.error is not None for w in workers) else 0.0
+        if dist is not None:
+            import torch
+            t = torch.tensor([bad], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bad = float(t[0])
+        return bad > 0.0
+
+    def shutdown(code):
+        for w in workers:
+            w.stop = True
+        if workers:
+            gate.wait()
+            for w in workers:
+                w.join(60)
+        if pipe is not None:
+            pipe.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(code)
+
+    if failed():
+        if rank == 0:
+            print("bench.py: band setup failed on at least one rank (no replica fall-back); see the tracebacks above", file=sys.stderr)
+        shutdown(3)
 
     def step(record):
-        if band is not None:
-            # the whole chain with the labelling branch on a second host thread / side stream (BandPipeline.run_chain); the
-            # per-label records are computed and merged across bands like in the single-GPU chain, the slice of a band's
-            # own labels stays on the device (nobody downloads records inside the timed loop at N = 1 either)
-            tm = {}
-            band.run_chain(records=True, fetch_own=False, overlap=os.environ.get("MALSTROEM_BAND_OVERLAP", "1") != "0", timings=tm)
-            if record:
-                for name in stage_names:
-                    stage_ms[name] += tm.get(name, 0.0)
+        if band_mode:
+            gate.wait()     # go
+            gate.wait()     # all bands of this process are through
         else:
             # one request for the whole chain: the library runs the bluespot branch (label, watershed) on a second
             # stream next to no-flats fill -> D8 -> accumulation ("stage DAG"); all labels are kept
-            pipe.run("fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints")
+            pipe.run(*stage_names)
             pipe.sync()
             if record:
                 for s in stage_names:
@@ -202,6 +324,8 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    for w in workers:
+        w.timings = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -213,53 +337,67 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+    if failed():
+        if rank == 0:
+            print("bench.py: the band chain failed on at least one rank; no metric is reported", file=sys.stderr)
+        shutdown(4)
 
-    cells = float(n) * n
     ms_per_step = elapsed * 1e3 / args.steps
-    value = cells * world * args.steps / elapsed / 1e6
-    for s in stage_names:
-        stage_ms[s] /= args.steps
-
-    if band is not None:
-        info = {"nlabels": band.nlabels, "halo_exchanges": dict(band.exchanges)}
+    value = cells * args.steps / elapsed / 1e6           # ONE DEM whatever N is: whole-job cells per second
+    if band_mode:
+        for s in stage_names:
+            stage_ms[s] = max(w.timings.get(s, 0.0) for w in workers) / args.steps   # host wall clock per stage, slowest band of this rank
+        info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands}
     else:
-        info = {k: pipe.get_int(k) for k in ("fill_rounds", "noflat_rounds", "nlabels", "fill_tiles", "fill_visits", "fill_cycles",
-                                            "noflat_visits", "noflat_cycles")}
+        for s in stage_names:
+            stage_ms[s] /= args.steps
+        keys = ("fill_rounds", "noflat_rounds", "fill_tiles", "fill_visits", "fill_cycles", "noflat_visits", "noflat_cycles") + (() if config2 else ("nlabels",))
+        info = {k: pipe.get_int(k) for k in keys}
+        for k in ("fill_algorithm", "fill_launches"):
+            try:
+                info[k] = pipe.get_int(k)
+            except Exception:
+                pass
     if rank == 0:
         stages = {}
         for s in stage_names:
             gbs = ALG_BYTES[s] * cells / (stage_ms[s] * 1e-3) / 1e9 if stage_ms[s] > 0 else 0.0
             stages[s] = {"ms": round(stage_ms[s], 3), "alg_bytes_per_cell": ALG_BYTES[s], "achieved_GBs": round(gbs, 1),
-                         "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                         "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * world), 4)}
         dominant = max(stage_names, key=lambda s: stage_ms[s])
         d8 = stages["flowdir"]
+        copy_gbs = None
+        try:
+            copy_gbs = round(pipe.copy_bandwidth(), 1) if pipe is not None else None
+        except Exception:
+            copy_gbs = None
+        chain = "fill -> no-flats fill -> D8" if config2 else ("fill+depths -> no-flats fill -> D8 -> accumulation -> CCL+label_stats -> "
+                                                               "watersheds+label_count -> pour points")
+        launches_key = {"fill": "fill_launches" if "fill_launches" in info else "fill_rounds", "noflat": "noflat_rounds"}.get(dominant, "")
         out = {
-            "metric": "Mcells/s fill->D8->accum->label on %d^2 f32 DEM" % n,   # BASELINE.json; the step also runs watersheds + pour points
+            "metric": ("Mcells/s fill->D8 on %d^2 f32 DEM" if config2 else "Mcells/s fill->D8->accum->label on %d^2 f32 DEM") % n,
             "value": round(value, 2), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if band_mode else "weak",
+            "vs_baseline": None,
             "dtype": "f32 fill / f64 no-flats+D8+accum / u8 flowdir / i32 labels", "data": "synthetic",
-            "config": {"workload": "%dx%d fBm beta=%g float32 DEM per GPU: fill+depths -> no-flats fill -> D8 -> accumulation -> "
-                                   "CCL+label_stats -> watersheds+label_count -> pour points" % (n, n, args.beta),
+            "config": {"workload": "%dx%d float32 DEM (%s): %s" % (n, n, src.recipe, chain),
                        "parallelism": parallelism, "dem_generation_s": round(t_gen, 1), **info},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE.get(dominant, dominant), "stage": dominant,
-                         "launches_per_step": info.get({"fill": "fill_rounds", "noflat": "noflat_rounds"}.get(dominant, ""), 1),
-                         "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": pmc_traffic(dominant, n),
-                         "note": "dominant stage by device time; algorithmic bytes of the whole stage / stage time (HIP events)"},
-            "d8_roofline": {"bound": "hbm", "kernel": "d8_kernel", "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "traffic": pmc_traffic("flowdir", n)},
+                         "launches_per_step": info.get(launches_key, 1),
+                         "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": pmc_traffic(dominant, n) if not band_mode else None,
+                         "measured_copy_peak_GBs": copy_gbs,
+                         "note": "dominant stage by %s; algorithmic bytes of the whole stage / stage time" % (
+                             "host wall clock of the slowest band (rank 0)" if band_mode else "device time (HIP events on the stage's stream)")},
+            "d8_roofline": {"bound": "hbm", "kernel": "d8_kernel", "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
+                            "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "frac_of_measured_copy_peak": round(d8["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
+                            "traffic": pmc_traffic("flowdir", n) if not band_mode else None},
             "stages": stages,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dem, min(args.cpu_sample, n))
+        if world == 1 and not band_mode and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(src.full, min(args.cpu_sample, n))
         print(json.dumps(out), flush=True)
-    if pipe is not None:
-        pipe.close()
-    if band is not None:
-        band.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    shutdown(0)
 
 
 if __name__ == "__main__":

@@ -44,6 +44,10 @@ const char *mhip_version(void);
 int mhip_device_count(void);                 /* number of HIP devices, 0 if none / runtime missing */
 int mhip_set_device(int device);             /* device used by the calling thread's later calls */
 
+/* measurement aid: rate of a 16-byte-per-lane device-to-device copy of `bytes` (read + written bytes per second, GB/s),
+ * i.e. the achievable share of the HBM spec peak on this device; reported next to the roofline fractions by bench.py */
+int mhip_copy_bandwidth(int64_t bytes, int32_t reps, double *gbs);
+
 /* ---- whole-stage entry points on HOST rasters (upload -> kernels -> download) ----------------- */
 
 /* fill.fill_terrain(dtm)  reference fill.py:112-171 (+ sweep _fill.pyx:28-70).

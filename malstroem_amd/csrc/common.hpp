@@ -144,6 +144,7 @@ int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_ou
            int64_t Hg = 0);
 int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
+int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s);
 int row_update_async(void *d_dst, const void *d_src, int64_t nbytes, int *d_changed, hipStream_t s);
 // comm.hip (RCCL, opened at run time)
 int comm_unique_id(void *id128);

@@ -103,6 +103,39 @@ int row_update_async(void *d_dst, const void *d_src, int64_t nbytes, int *d_chan
     return MHIP_OK;
 }
 
+// ---- device-to-device copy rate (context for the roofline numbers: the achievable share of the 8 TB/s spec peak) ----
+namespace {
+__global__ __launch_bounds__(256) void copy16_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
+int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s)
+{
+    DevBuf a, b;
+    MH_TRY(a.alloc(bytes));
+    MH_TRY(b.alloc(bytes));
+    MH_HIP(hipMemsetAsync(a.p, 1, bytes, s));
+    const int64_t n = (int64_t)(bytes / 16);
+    hipEvent_t e0, e1;
+    MH_HIP(hipEventCreate(&e0));
+    MH_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(copy16_kernel, dim3(256 * 16), dim3(256), 0, s, a.as<float4>(), b.as<float4>(), n);   // warm-up
+    MH_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 16), dim3(256), 0, s, a.as<float4>(), b.as<float4>(), n);
+    MH_HIP(hipEventRecord(e1, s));
+    MH_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    MH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbs = ms > 0 ? 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
+    return MHIP_OK;
+}
+
 // fill.py:235-250: maxval = f64(max(|amax|,|amin|)); short = (nextafter(maxval, inf) - maxval) * 1024; diag = short * 2**0.5
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s)
 {

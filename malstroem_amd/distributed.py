@@ -30,7 +30,7 @@ from . import _lib
 from ._lib import INDEX_DTYPE, R_DEM, R_FILLED, R_FLOWDIR, R_NOFLAT, RASTER_DTYPE, STAGE_ACCUM, STAGE_FLOWDIR, STAT_DTYPE
 from .pipeline import RASTERS
 
-__all__ = ["band_rows", "Comm", "SingleComm", "ThreadComm", "SocketComm", "HipBand", "BandPipeline"]
+__all__ = ["band_rows", "Comm", "SingleComm", "ThreadComm", "SocketComm", "HybridComm", "HipBand", "BandPipeline"]
 
 
 def band_rows(H, size, rank):
@@ -237,6 +237,65 @@ class SocketComm(Comm):
             except OSError:
                 pass
         self._peers, self._hub = {}, None
+
+
+class HybridComm(Comm):
+    """``k`` bands per process (threads) times ``P`` processes = ``P * k`` virtual ranks, band order = (process, thread).
+
+    A GPU addresses at most 2**31 - 2 cells per band context (int32 cell indices keep the union-find / pointer-jumping
+    rasters at 4 bytes per cell), so a raster beyond that runs as several bands on ONE GPU as well: the 1- and 2-GPU
+    points of a 65536 x 65536 strong-scaling curve are 4 and 2 bands per process.  Several bands share a GPU here, so
+    there is no RCCL communicator (one rank per device); rows and objects travel through the process-level ``Comm``
+    (all-gathered: the few boundary rows of every band), which is fine for what this mode is for.
+
+    ``HybridComm.world(proc_comm, k)`` -> the ``k`` endpoints of this process, one per band thread."""
+
+    class _World(object):
+        def __init__(self, proc, k):
+            self.proc, self.k = proc, k
+            self.barrier = threading.Barrier(k)
+            self.slots = [None] * k
+            self.result = None
+
+    @classmethod
+    def world(cls, proc_comm, k):
+        w = cls._World(proc_comm, int(k))
+        return [cls(w, t) for t in range(int(k))]
+
+    def __init__(self, world, t):
+        self._w, self._t = world, t
+        self.rank = world.proc.rank * world.k + t
+        self.size = world.proc.size * world.k
+
+    def allgather(self, obj):
+        w = self._w
+        w.slots[self._t] = obj
+        w.barrier.wait(timeout=1800)
+        if self._t == 0:
+            w.result = [o for part in w.proc.allgather(list(w.slots)) for o in part]
+        w.barrier.wait(timeout=1800)
+        out = w.result
+        w.barrier.wait(timeout=1800)
+        return out
+
+    def allreduce_max(self, value):
+        return max(self.allgather(float(value)))
+
+    def exchange_rows(self, to_up, to_down):
+        rows = self.allgather((to_up, to_down))
+        from_up = rows[self.rank - 1][1] if self.rank > 0 else None
+        from_down = rows[self.rank + 1][0] if self.rank < self.size - 1 else None
+        return from_up, from_down
+
+    def clone(self):
+        w = self._w
+        w.barrier.wait(timeout=1800)
+        if self._t == 0:
+            w.result = HybridComm._World(w.proc.clone(), w.k)
+        w.barrier.wait(timeout=1800)
+        nw = w.result
+        w.barrier.wait(timeout=1800)
+        return HybridComm(nw, self._t)
 
 
 # ---- compute backend: one band context on one GPU -----------------------------------------------------------------

@@ -79,6 +79,13 @@ class HydroPipeline(object):
         _lib.call("mhip_ctx_kernel_ms", self._ctx, family.encode(), ctypes.byref(ms), ctypes.byref(n))
         return ms.value, n.value
 
+    @staticmethod
+    def copy_bandwidth(nbytes=1 << 30, reps=10):
+        """GB/s (read + written) of a plain device-to-device copy: the measured ceiling the roofline fractions sit under."""
+        gbs = ctypes.c_double(0)
+        _lib.call("mhip_copy_bandwidth", _lib.i64(nbytes), ctypes.c_int32(reps), ctypes.byref(gbs))
+        return gbs.value
+
     def get_int(self, key):
         v = ctypes.c_int64(0)
         _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))

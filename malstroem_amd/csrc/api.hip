@@ -1023,10 +1023,12 @@ static int stage_fill(mhip_ctx *c, hipStream_t s, bool with_depths = true)
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_FILL, s, &e1));
     FillStats st;
-    MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st));
+    bool depths_done = false;   // the priority-flood's last pass writes filled - dem next to the filled surface
+    MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st, c->r[MHIP_R_DEPTHS].as<float>(),
+                          &depths_done));
     c->have[MHIP_R_FILLED] = true;
-    c->have[MHIP_R_DEPTHS] = false;
-    if (with_depths) MH_TRY(stage_depths(c, s));
+    c->have[MHIP_R_DEPTHS] = depths_done;
+    if (with_depths && !depths_done) MH_TRY(stage_depths(c, s));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_FILL] = true;
     c->fill_rounds = st.rounds;
@@ -1229,7 +1231,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
             int rc_l = rc_e == MHIP_OK ? fill_fut.get() : rc_e;   // ev_fork has been recorded on the main stream
             if (rc_l == MHIP_OK && hipStreamWaitEvent(sb, c->ev_fork, 0) != hipSuccess) rc_l = MHIP_EHIP;
             if (rc_l == MHIP_OK && (mask & MHIP_STAGE_LABEL)) rc_l = stage_label(c, sb);   // incl. the bluespot depths
-            else if (rc_l == MHIP_OK && do_fill) rc_l = stage_depths(c, sb);
+            else if (rc_l == MHIP_OK && do_fill && !c->have[MHIP_R_DEPTHS]) rc_l = stage_depths(c, sb);
             // both consumers (WATERSHED here, POURPOINTS on the main thread) want the final labels: settle them once
             if (rc_l == MHIP_OK && (mask & (MHIP_STAGE_WATERSHED | MHIP_STAGE_POURPOINTS)) && c->have[MHIP_R_LABELS]) {
                 rc_l = ctx_ensure_labels_final(c, sb);
@@ -1329,6 +1331,8 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "fill_visits") *value = c->fill_st.visits;
     else if (k == "fill_cycles") *value = c->fill_st.cycles;
     else if (k == "fill_tiles") *value = c->fill_st.tiles;
+    else if (k == "fill_algorithm") *value = c->fill_st.algorithm;   // 0 iterative tile schedule, 1 tiled priority-flood
+    else if (k == "fill_launches") *value = c->fill_st.rounds;
     else if (k == "noflat_visits") *value = c->noflat_st.visits;
     else if (k == "noflat_cycles") *value = c->noflat_st.cycles;
     else if (k == "H") *value = c->H;

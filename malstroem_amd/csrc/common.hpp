@@ -108,6 +108,7 @@ struct FillStats {
     int64_t visits = 0;   // tile visits over all rounds
     int64_t cycles = 0;   // local (down, up, right, left) cycles over all visits
     int64_t tiles = 0;    // tiles in the raster
+    int32_t algorithm = 0;  // 0: iterative tile schedule (fill.hip), 1: tiled priority-flood (pflood.hip; rounds = kernel launches)
 };
 
 // fill.hip
@@ -134,7 +135,10 @@ struct FillRun {
     int finish(hipStream_t s, FillStats *st);
 };
 void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_t ncells_global);
-int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st);
+int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st, float *d_depths = nullptr,
+                   bool *depths_done = nullptr);
+// pflood.hip
+int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);

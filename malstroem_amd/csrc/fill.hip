@@ -936,8 +936,23 @@ static int fill_run_to_convergence(FillRun &f, hipStream_t s, FillStats *st)
 }
 
 
-int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st)
+// fill.fill_terrain on one raster.  The exact tiled priority-flood (pflood.hip) is the default; the iterative tile schedule
+// of this file takes over when a tile exceeds one of the flood's capacities, for rasters without an interior, and when
+// MHIP_FILL=iterative is set.  d_depths (optional): filled - dem, written by the flood's last pass (*depths_done = true) --
+// the iterative path leaves it to the caller.
+int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st, float *d_depths, bool *depths_done)
 {
+    static const bool force_iter = [] { const char *e = getenv("MHIP_FILL"); return e && std::string(e) == "iterative"; }();
+    if (depths_done) *depths_done = false;
+    if (!force_iter && H >= 3 && W >= 3) {
+        const int rc = fill_plain_pflood_dev(d_dem, d_out, d_depths, H, W, s, st);
+        if (rc == MHIP_OK) {
+            if (depths_done) *depths_done = d_depths != nullptr;
+            if (st) st->algorithm = 1;
+            return MHIP_OK;
+        }
+        if (rc != MHIP_ELIMIT) return rc;
+    }
     FillRun f;
     f.noflat = false; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W;
     return fill_run_to_convergence(f, s, st);

@@ -134,6 +134,8 @@ class SocketComm(Comm):
 
     ``SocketComm.from_env()`` reads RANK / WORLD_SIZE / MASTER_ADDR / MALSTROEM_COMM_PORT (default MASTER_PORT + 17)."""
 
+    one_rank_per_device = True   # ranks are processes, by convention one per GPU: BandPipeline may put the rows on RCCL
+
     def __init__(self, rank, size, addr="127.0.0.1", port=29517, timeout_s=300.0, _socks=None):
         self.rank, self.size, self._addr, self._port, self._timeout = int(rank), int(size), addr, int(port), float(timeout_s)
         self._lock = threading.Lock()
@@ -488,8 +490,8 @@ class BandPipeline(object):
         self.H, self.W = int(shape[0]), int(shape[1])
         self.row0, self.nrows = band_rows(self.H, comm.size, comm.rank)
         factory = backend_factory or HipBand
-        if rccl is None:
-            rccl = comm.size > 1 and factory is HipBand
+        if rccl is None:   # RCCL wants one rank per device: only transports between processes say so (SocketComm; a launcher's own)
+            rccl = comm.size > 1 and factory is HipBand and bool(getattr(comm, "one_rank_per_device", False))
         self.band, err = None, None
         try:
             uid = None

@@ -8,6 +8,7 @@ import pytest
 import scipy.ndimage
 
 import oracle
+from _cases import fbm
 
 pytestmark = pytest.mark.gpu
 
@@ -232,3 +233,25 @@ def test_label_stats_on_non_float32_rasters(alg):
     got, want = alg.label.label_stats(data, lab, 45), oracle.label_stats(data.astype(np.float32), lab, 45)
     assert len(got) == 46 and np.isnan(got["sum"][lab[3, 3]]) and got["count"][45] == 0 and got["min"][45] == np.inf
     assert np.array_equal(got["count"], want["count"])
+
+
+def test_priority_flood_and_its_fallback_give_the_same_fill(alg):
+    """fill_terrain runs the tiled priority-flood (pflood.hip); a tile that exceeds one of its capacities (here: a pit in
+    every other cell -> more adjacent basin pairs than the LDS hash holds) sends the whole raster through the iterative
+    tile schedule instead.  Both paths and the oracle agree bit for bit; the context reports which one ran."""
+    from malstroem_amd.pipeline import HydroPipeline
+    rng = np.random.default_rng(33)
+    smooth = fbm(300, 260, beta=2.0, seed=12)
+    pits = (1.0 + rng.random((300, 260))).astype(np.float32)
+    pits[::2, ::2] = (rng.random((150, 130)) * 0.5).astype(np.float32)
+    plateau = np.round(fbm(200, 330, beta=2.5, seed=13) / 4).astype(np.float32)     # integer steps: large plateaus
+    for dem, algorithm in ((smooth, 1), (pits, 0), (plateau, 1)):
+        with HydroPipeline(dem.shape) as pipe:
+            pipe.upload("dem", dem)
+            pipe.run("fill")
+            pipe.sync()
+            got, dep = pipe.download("filled"), pipe.download("depths")
+            assert pipe.get_int("fill_algorithm") == algorithm
+        want = oracle.fill_terrain(dem)
+        assert np.array_equal(got, want)
+        assert np.array_equal(dep, oracle.depths(want, dem))

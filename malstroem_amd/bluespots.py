@@ -95,13 +95,15 @@ class BluespotTool(object):
         if pipe is None:
             depths = self.input_depths.read()
             pipe, own = HydroPipeline(depths.shape, device=self.device), True
+            if not self.input_accum:
+                # pour points at the minimum of the no-flats surface (bluespots.py:203-205).  The DEM goes up FIRST: a new
+                # DEM invalidates every raster derived from the previous one
+                pipe.upload("dem", self.input_dem.read())
+                pipe.run("noflat")
             pipe.upload("depths", depths)
             pipe.upload("flowdir", self.input_flowdir.read())
             if self.input_accum:
                 pipe.upload("accum", self.input_accum.read())
-            elif self.input_dem:
-                pipe.upload("dem", self.input_dem.read())
-                pipe.run("noflat")
         try:
             self.logger.info("Calculating unfiltered bluespots")
             pipe.run("label")

@@ -40,8 +40,9 @@ constexpr int WN = 64, TI = 62, NC = WN * WN;
 constexpr int NBMAX = 1024;        // basins per tile
 constexpr int HE = 2048;           // basin-pair hash entries
 constexpr int SE = 512;            // seed-pair hash entries
-constexpr int SPMAX = 256;         // spill edges stored per tile
-constexpr int LMAX = 384;          // links stored per tile
+constexpr int SPMAX = 192;         // spill edges stored per tile (unused entries hold ~0)
+constexpr int LMAX = 256;          // links stored per tile (unused entries hold ~0)
+constexpr int NSMAX = 128;         // seeds per tile (compact indices; OCEAN stays 255)
 constexpr int LH = 1024;           // link hash entries
 constexpr uint32_t KINV = 0xFFFFFFFFu;   // key of a cell outside the raster (above +inf)
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
@@ -54,16 +55,31 @@ struct PfArgs {
     const float *dem;
     uint16_t *bslot;        // [H * W]
     uint32_t *tabV;         // [ntiles * NBMAX] spill level keys, then (pf_final_kernel) final level keys
-    uint8_t *tabL;          // [ntiles * NBMAX] seed labels
+    uint8_t *tabL;          // [ntiles * NBMAX] seed of the basin (compact index inside the tile, or OCEAN)
     int *tileNB;            // [ntiles]
-    uint8_t *ringLab;       // [ntiles * 256]
+    uint8_t *ringLab;       // [ntiles * 256] seed (compact index) of every ring cell, by ring position
     unsigned long long *spill;  // [ntiles * SPMAX]  (la << 40 | lb << 32 | w)
     int *tileNS;            // [ntiles]
     unsigned long long *links;  // [ntiles * LMAX]   (myLab << 48 | dir << 40 | nbrLab << 32 | w)
     int *tileNL;            // [ntiles]
-    uint32_t *Lv;           // [ntiles * 256] minimax level of every seed (keys)
+    uint32_t *Lv;           // [ntiles * NSMAX] minimax level of every seed (keys)
     unsigned int *flags;    // [0]: overflow
+    unsigned long long *prof;   // -DPF_PROFILE builds: clock ticks per phase of pf_tile_kernel, summed over the tiles
 };
+
+#ifdef PF_PROFILE
+#define PF_STAMP(i)                                                               \
+    do {                                                                          \
+        __syncthreads();                                                          \
+        if (threadIdx.x == 0) {                                                   \
+            const long long now_ = __builtin_amdgcn_s_memtime();                  \
+            atomicAdd(&a.prof[i], (unsigned long long)(now_ - pf_t0_));           \
+            pf_t0_ = now_;                                                        \
+        }                                                                         \
+    } while (0)
+#else
+#define PF_STAMP(i)
+#endif
 
 __device__ __forceinline__ uint32_t dem_key(float v)
 {
@@ -88,63 +104,78 @@ __device__ __forceinline__ void ring_cell(int p, int &wr, int &wc)
 }
 
 // ---- K1 -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pf_tile_kernel(PfArgs a)
+constexpr int NT = 512;            // threads per tile: eight wavefronts, a 8-row x 1-column strip of the window per thread
+constexpr int CPT = NC / NT;       // cells per thread
+constexpr int EPT = HE / NT;       // (compacted) basin pairs per thread in the label-correcting loop
+
+struct WinGeom {
+    int64_t r0, c0, H, W;
+};
+// class of window cell ci: valid / raster border / window ring (the last two exclude each other)
+__device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
 {
+    const int wr = ci >> 6, wc = ci & 63;
+    const int64_t rr = g.r0 + wr, cc = g.c0 + wc;
+    if (rr >= g.H || cc >= g.W) return 0;
+    if (rr == 0 || rr == g.H - 1 || cc == 0 || cc == g.W - 1) return C_VALID | C_BORDER;
+    if (wr == 0 || wr == WN - 1 || wc == 0 || wc == WN - 1) return C_VALID | C_RING;
+    return C_VALID;
+}
+
+__global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
+{
+    // LDS plan (49 KB: three workgroups = 24 wavefronts per CU; the phases below are bound by LDS / barrier latency, not by
+    // LDS bandwidth, so residency is what pays):
+    //   zk   16 KB  elevation keys of the window                      -> after S5: the compacted basin pairs (ek | ew)
+    //   ptr   8 KB  steepest-descent pointer -> pit (root) of a cell  -> S4: basin slot of a root -> S5: basin slot of a cell
+    //   hkv  16 KB  plateau ids | plateau drains (16 bit each, S2b)   -> basin-pair hash (keys | values, S5)
+    //                                                                  -> S6: seed map, seed-pair hash
+    //   bkey  8 KB + btype 1 KB  (level, seed) and kind of every basin
     __shared__ uint32_t zk[NC];
     __shared__ uint16_t ptr[NC];
-    __shared__ uint32_t aux[NC];          // plateau ids, then slot of a root
-    __shared__ uint8_t cls[NC];
-    __shared__ uint32_t hkv[2 * HE];      // basin-pair hash: keys | values (also: the plateau drains, one word per cell)
+    __shared__ uint32_t hkv[2 * HE];
     __shared__ unsigned long long bkey[NBMAX];
-    __shared__ uint16_t broot[NBMAX];
     __shared__ uint8_t btype[NBMAX];      // 1: interior pit (level to be found), 0: ring pit or raster border (fixed)
-    __shared__ uint32_t sk[SE], sv[SE];
-    __shared__ int s_scan[8];
-    __shared__ int s_cnt;
+    __shared__ int s_scan[NT / 64];
+    __shared__ int s_cnt, s_ne;
 
     const int t = threadIdx.x, wc = t & 63, q = t >> 6;
     const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
-    const int64_t r0 = (int64_t)ti * TI, c0 = (int64_t)tj * TI;
-    const int64_t H = a.H, W = a.W;
-    uint32_t *hk = hkv, *hv = hkv + HE, *drn = hkv;
-    static_assert(2 * HE == NC, "the plateau drains reuse the hash arrays: one word per window cell");
-
+    WinGeom g;
+    g.r0 = (int64_t)ti * TI; g.c0 = (int64_t)tj * TI; g.H = a.H; g.W = a.W;
+    const int64_t W = a.W;
+    uint32_t *hk = hkv, *hv = hkv + HE;
+    static_assert(2 * HE == NC, "plateau ids / drains (one 16-bit word per cell each) share the hash arrays");
+    const int wr0 = q * CPT;
+#ifdef PF_PROFILE
+    long long pf_t0_ = __builtin_amdgcn_s_memtime();
+#endif
     // ---- S1: window -> LDS
-    const int64_t cc = c0 + wc;
+    const int64_t cc = g.c0 + wc;
+    uint8_t mycls[CPT];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int wr = q * 16 + k;
-        const int64_t rr = r0 + wr;
-        const bool valid = rr < H && cc < W;
-        uint32_t key = KINV;
-        uint8_t c = 0;
-        if (valid) {
-            key = dem_key(a.dem[rr * W + cc]);
-            c = C_VALID;
-            if (rr == 0 || rr == H - 1 || cc == 0 || cc == W - 1) c |= C_BORDER;
-            else if (wr == 0 || wr == WN - 1 || wc == 0 || wc == WN - 1) c |= C_RING;
-        }
-        zk[wr * WN + wc] = key;
-        cls[wr * WN + wc] = c;
+    for (int k = 0; k < CPT; ++k) {
+        const int wr = wr0 + k;
+        const uint8_t c = cell_class(g, wr * WN + wc);
+        mycls[k] = c;
+        zk[wr * WN + wc] = c ? dem_key(a.dem[(g.r0 + wr) * W + cc]) : KINV;
     }
-    for (int i = t; i < HE; i += 256) { hk[i] = EMPTY; hv[i] = EMPTY; }
-    for (int i = t; i < SE; i += 256) { sk[i] = EMPTY; sv[i] = EMPTY; }
-    if (t == 0) s_cnt = 0;
+    if (t == 0) { s_cnt = 0; s_ne = 0; }
     __syncthreads();
+    PF_STAMP(0);
 
     // ---- S2: steepest descent pointer of every cell (lowest neighbour if strictly lower, ties -> lowest index)
     auto ld = [&](int wr, int c) -> uint32_t { return (wr < 0 || wr >= WN || c < 0 || c >= WN) ? KINV : zk[wr * WN + c]; };
     unsigned eqmask = 0, lowmask = 0;
     {
         uint32_t up[3], mid[3], dn[3];
-        const int wr0 = q * 16;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             up[j] = ld(wr0 - 1, wc - 1 + j);
             mid[j] = ld(wr0, wc - 1 + j);
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < CPT; ++k) {
             const int wr = wr0 + k, ci = wr * WN + wc;
 #pragma unroll
             for (int j = 0; j < 3; ++j) dn[j] = ld(wr + 1, wc - 1 + j);
@@ -164,69 +195,77 @@ __global__ __launch_bounds__(256) void pf_tile_kernel(PfArgs a)
             const bool lower = valid && best < own;
             if (eq) eqmask |= 1u << k;
             if (lower) lowmask |= 1u << k;
-            const bool border = (cls[ci] & C_BORDER) != 0;
-            ptr[ci] = (uint16_t)((lower && !border) ? bi : ci);   // a raster border cell is a root by decree (OCEAN)
+            ptr[ci] = (uint16_t)((lower && !(mycls[k] & C_BORDER)) ? bi : ci);   // a raster border cell is a root by decree (OCEAN)
 #pragma unroll
             for (int j = 0; j < 3; ++j) { up[j] = mid[j]; mid[j] = dn[j]; }
         }
     }
-    // ---- S2b: plateaus (connected equal cells) drain through ANY member that has a lower neighbour (or is a border cell)
+    // ---- S2b: plateaus (connected equal cells) drain through ANY member that has a lower neighbour (or is a border cell).
+    // Rare on float terrain, the rule on integer-valued DEMs.  Two 16-bit words per cell, each written by its own thread
+    // only: the plateau id (smallest member index) and the plateau's drain (smallest candidate index), both found by min
+    // propagation over equal neighbours with a jump through the current id.
     if (__syncthreads_or(eqmask != 0)) {
+        uint16_t *comp = reinterpret_cast<uint16_t *>(hkv), *drain = comp + NC;
+        constexpr uint16_t NODRAIN = 0xFFFF;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) aux[(q * 16 + k) * WN + wc] = (uint32_t)((q * 16 + k) * WN + wc);
+        for (int k = 0; k < CPT; ++k) {
+            const int ci = (wr0 + k) * WN + wc;
+            comp[ci] = (uint16_t)ci;
+            uint16_t cand = NODRAIN;
+            if ((eqmask >> k) & 1u) {
+                if (mycls[k] & C_BORDER) cand = (uint16_t)ci;
+                else if ((lowmask >> k) & 1u) cand = ptr[ci];       // still the steepest-descent target
+            }
+            drain[ci] = cand;
+        }
         __syncthreads();
-        for (int it = 0; it < 4 * NC; ++it) {   // min-index propagation over equal neighbours with pointer jumping
+        for (int it = 0; it < 4 * NC; ++it) {
             bool ch = false;
 #pragma unroll 1
-            for (int k = 0; k < 16; ++k) {
+            for (int k = 0; k < CPT; ++k) {
                 if (!((eqmask >> k) & 1u)) continue;
-                const int wr = q * 16 + k, ci = wr * WN + wc;
+                const int wr = wr0 + k, ci = wr * WN + wc;
                 const uint32_t own = zk[ci];
-                uint32_t m = aux[ci];
+                uint16_t m = comp[ci], dmin = drain[ci];
                 for (int dr = -1; dr <= 1; ++dr)
                     for (int dc = -1; dc <= 1; ++dc) {
                         const int rr = wr + dr, c2 = wc + dc;
                         if ((dr | dc) == 0 || rr < 0 || rr >= WN || c2 < 0 || c2 >= WN) continue;
-                        if (zk[rr * WN + c2] == own) m = min(m, aux[rr * WN + c2]);
+                        if (zk[rr * WN + c2] == own) {
+                            m = min(m, comp[rr * WN + c2]);
+                            dmin = min(dmin, drain[rr * WN + c2]);
+                        }
                     }
-                m = min(m, aux[m]);
-                if (m < aux[ci]) {
-                    atomicMin(&aux[ci], m);
+                m = min(m, comp[m]);
+                dmin = min(dmin, drain[m]);
+                if (m < comp[ci] || dmin < drain[ci]) {
+                    comp[ci] = m;
+                    drain[ci] = dmin;
                     ch = true;
                 }
             }
             if (!__syncthreads_or(ch)) break;
         }
-        for (int i = t; i < NC; i += 256) drn[i] = EMPTY;   // hk + hv are re-initialised below
-        __syncthreads();
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            if (!((eqmask >> k) & 1u)) continue;
-            const int ci = (q * 16 + k) * WN + wc;
-            if (cls[ci] & C_BORDER) atomicMin(&drn[aux[ci]], (uint32_t)ci);
-            else if ((lowmask >> k) & 1u) atomicMin(&drn[aux[ci]], (uint32_t)ptr[ci]);   // still the steepest-descent target
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (!((eqmask >> k) & 1u) || (mycls[k] & C_BORDER)) continue;
+            const int ci = (wr0 + k) * WN + wc;
+            const uint16_t root = comp[ci];
+            if (root != (uint16_t)ci) ptr[ci] = root;
+            else ptr[ci] = drain[ci] != NODRAIN ? drain[ci] : (uint16_t)ci;
         }
         __syncthreads();
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            if (!((eqmask >> k) & 1u)) continue;
-            const int ci = (q * 16 + k) * WN + wc;
-            if (cls[ci] & C_BORDER) continue;
-            const uint32_t root = aux[ci];
-            if (root != (uint32_t)ci) ptr[ci] = (uint16_t)root;
-            else ptr[ci] = (uint16_t)(drn[ci] != EMPTY ? drn[ci] : (uint32_t)ci);
-        }
-        __syncthreads();
-        for (int i = t; i < HE; i += 256) { hk[i] = EMPTY; hv[i] = EMPTY; }
     }
+    for (int i = t; i < 2 * HE; i += NT) hkv[i] = EMPTY;   // the basin-pair hash
     __syncthreads();
+    PF_STAMP(1);
 
     // ---- S3: pointer doubling -> ptr[c] = the pit (root) c drains to
     for (int it = 0; it < 16; ++it) {
         bool ch = false;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int ci = (q * 16 + k) * WN + wc;
+        for (int k = 0; k < CPT; ++k) {
+            const int ci = (wr0 + k) * WN + wc;
             const uint16_t p = ptr[ci], pp = ptr[p];
             if (pp != p) {
                 ptr[ci] = pp;
@@ -235,14 +274,17 @@ __global__ __launch_bounds__(256) void pf_tile_kernel(PfArgs a)
         }
         if (!__syncthreads_or(ch)) break;
     }
+    PF_STAMP(2);
 
-    // ---- S4: number the roots (basin slots)
+    // ---- S4: number the roots (basin slots); the slot of a root replaces its (self) pointer
     int nroot = 0;
     unsigned rootmask = 0;
+    uint16_t myroot[CPT];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int ci = (q * 16 + k) * WN + wc;
-        if ((cls[ci] & C_VALID) && ptr[ci] == (uint16_t)ci) {
+    for (int k = 0; k < CPT; ++k) {
+        const int ci = (wr0 + k) * WN + wc;
+        myroot[k] = ptr[ci];
+        if (mycls[k] && myroot[k] == (uint16_t)ci) {
             rootmask |= 1u << k;
             ++nroot;
         }
@@ -254,122 +296,250 @@ __global__ __launch_bounds__(256) void pf_tile_kernel(PfArgs a)
         if (wc >= o) incl += v;
     }
     if (wc == 63) s_scan[q] = incl;
-    __syncthreads();
-    int base = incl - nroot;
-    for (int w = 0; w < q; ++w) base += s_scan[w];
-    const int NB = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-    const bool too_many = NB > NBMAX;
-    if (!too_many) {
+    __syncthreads();          // also: every thread has read its pointers
+    int base = incl - nroot, NB = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (!((rootmask >> k) & 1u)) continue;
-            const int wr = q * 16 + k, ci = wr * WN + wc, s = base++;
-            aux[ci] = (uint32_t)s;
-            broot[s] = (uint16_t)ci;
-            const uint8_t c = cls[ci];
-            unsigned long long key = ~0ull;
-            uint8_t ty = 1;
-            if (c & C_BORDER) { key = ((unsigned long long)zk[ci] << 32) | OCEAN; ty = 0; }
-            else if (c & C_RING) { key = ((unsigned long long)zk[ci] << 32) | (unsigned)ring_pos(wr, wc); ty = 0; }
-            bkey[s] = key;
-            btype[s] = ty;
-        }
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < q) base += s_scan[w];
+        NB += s_scan[w];
+    }
+    if (NB > NBMAX) {         // block-uniform
+        if (t == 0) atomicOr(a.flags, 1u);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        if (!((rootmask >> k) & 1u)) continue;
+        const int wr = wr0 + k, ci = wr * WN + wc, s = base++;
+        ptr[ci] = (uint16_t)s;
+        unsigned long long key = ~0ull;
+        uint8_t ty = 1;
+        if (mycls[k] & C_BORDER) { key = ((unsigned long long)zk[ci] << 32) | OCEAN; ty = 0; }
+        else if (mycls[k] & C_RING) { key = ((unsigned long long)zk[ci] << 32) | (unsigned)ring_pos(wr, wc); ty = 0; }
+        bkey[s] = key;
+        btype[s] = ty;
     }
     __syncthreads();
-    bool overflow = too_many;
-    if (!too_many) {
-        // ring cells inside an interior-pit basin are outlets of that basin at their own elevation
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int wr = q * 16 + k, ci = wr * WN + wc;
-            if (!(cls[ci] & C_RING)) continue;
-            const int s = (int)aux[ptr[ci]];
-            if (btype[s]) atomicMin(&bkey[s], ((unsigned long long)zk[ci] << 32) | (unsigned)ring_pos(wr, wc));
+    uint16_t myslot[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) myslot[k] = mycls[k] ? ptr[myroot[k]] : (uint16_t)0xFFFF;
+    __syncthreads();
+    // ring cells inside an interior-pit basin are outlets of that basin at their own elevation; and every cell's basin slot
+    // replaces its pointer
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int wr = wr0 + k;
+        ptr[wr * WN + wc] = myslot[k];
+        if (!(mycls[k] & C_RING)) continue;
+        const int s = myslot[k];
+        if (btype[s]) atomicMin(&bkey[s], ((unsigned long long)zk[wr * WN + wc] << 32) | (unsigned)ring_pos(wr, wc));
+    }
+    __syncthreads();
+    PF_STAMP(3);
+    // ---- S5: min pass height between adjacent basins.  Neighbour slots / elevations of the strip come in one batch of
+    // independent LDS reads; the four pairs of a row go to the hash together (independent atomics in flight).  A pair is
+    // skipped when the same thread (row above) or the lane to the left has just offered the same pair at a weight at least
+    // as low -- adjacent cells mostly straddle the same two basins, and same-address LDS atomics serialise.
+    bool overflow = false;
+    {
+        constexpr uint16_t NONE = 0xFFFF;
+        uint16_t sl[CPT + 1], sr[CPT + 1];
+        uint32_t zl[CPT + 1], zr[CPT + 1], myz[CPT];
+#pragma unroll
+        for (int j = 0; j <= CPT; ++j) {
+            const int row = wr0 + j;
+            const bool okl = row < WN && wc > 0, okr = row < WN && wc < WN - 1;
+            sl[j] = okl ? ptr[row * WN + wc - 1] : NONE;
+            zl[j] = okl ? zk[row * WN + wc - 1] : KINV;
+            sr[j] = okr ? ptr[row * WN + wc + 1] : NONE;
+            zr[j] = okr ? zk[row * WN + wc + 1] : KINV;
         }
-        // ---- S5: min pass height between adjacent basins
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-            const int wr = q * 16 + k, ci = wr * WN + wc;
-            const uint32_t own = zk[ci];
-            if (own == KINV) continue;
-            const uint16_t ra = ptr[ci];
-            const int dr[4] = {0, 1, 1, 1}, dc[4] = {1, -1, 0, 1};
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) myz[k] = zk[(wr0 + k) * WN + wc];
+        const bool below = wr0 + CPT < WN;
+        const uint16_t s_dn = below ? ptr[(wr0 + CPT) * WN + wc] : NONE;
+        const uint32_t z_dn = below ? zk[(wr0 + CPT) * WN + wc] : KINV;
+        uint32_t lastk[4] = {EMPTY, EMPTY, EMPTY, EMPTY}, lastw[4] = {0, 0, 0, 0};
+#ifdef PF_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long pf_s5a = __builtin_amdgcn_s_memtime();
+        unsigned pf_ncand = 0, pf_nlive = 0, pf_nslow = 0;
+#endif
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const uint32_t sa = myslot[k], own = myz[k];
+            const uint16_t nb[4] = {sr[k], sl[k + 1], k + 1 < CPT ? myslot[k + 1] : s_dn, sr[k + 1]};
+            const uint32_t nz[4] = {zr[k], zl[k + 1], k + 1 < CPT ? myz[k + 1] : z_dn, zr[k + 1]};
+            uint32_t key[4], w[4], prev[4];
+            unsigned h[4];
+            bool live[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const int rr = wr + dr[d], c2 = wc + dc[d];
-                if (rr >= WN || c2 < 0 || c2 >= WN) continue;
-                const int cj = rr * WN + c2;
-                const uint32_t other = zk[cj];
-                if (other == KINV) continue;
-                const uint16_t rb = ptr[cj];
-                if (ra == rb) continue;
-                const uint32_t sa = aux[ra], sb = aux[rb];
-                const uint32_t key = sa < sb ? (sa << 10 | sb) : (sb << 10 | sa);
-                const uint32_t w = max(own, other);
-                unsigned h = (key * 2654435761u) >> 21;
-                bool done = false;
+                const uint32_t sb = nb[d];
+                const bool cand = sa != NONE && sb != NONE && sb != sa;
+                key[d] = cand ? (sa < sb ? (sa << 10 | sb) : (sb << 10 | sa)) : EMPTY;
+                w[d] = max(own, nz[d]);
+                // the lane to the left (all lanes execute the shifts: no divergence around them)
+                const uint32_t lkey = (uint32_t)__builtin_amdgcn_update_dpp((int)EMPTY, (int)key[d], 0x138, 0xf, 0xf, false);
+                const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[d], 0x138, 0xf, 0xf, false);
+                live[d] = cand && !(key[d] == lastk[d] && w[d] >= lastw[d]) && !(key[d] == lkey && w[d] >= lw);
+#ifdef PF_PROFILE
+                pf_ncand += cand; pf_nlive += live[d];
+#endif
+                if (cand) { lastk[d] = key[d]; lastw[d] = w[d]; }
+                h[d] = (key[d] * 2654435761u) >> 21;
+                prev[d] = EMPTY;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (live[d]) prev[d] = atomicCAS(&hk[h[d]], EMPTY, key[d]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (!live[d]) continue;
+                if (prev[d] == EMPTY || prev[d] == key[d]) {
+                    atomicMin(&hv[h[d]], w[d]);
+                    continue;
+                }
+                bool done = false;   // collision: linear probing
+#ifdef PF_PROFILE
+                ++pf_nslow;
+#endif
+                unsigned hh = (h[d] + 1) & (HE - 1);
                 for (int probe = 0; probe < 64; ++probe) {
-                    const uint32_t prev = atomicCAS(&hk[h], EMPTY, key);
-                    if (prev == EMPTY || prev == key) {
-                        atomicMin(&hv[h], w);
+                    const uint32_t pv = atomicCAS(&hk[hh], EMPTY, key[d]);
+                    if (pv == EMPTY || pv == key[d]) {
+                        atomicMin(&hv[hh], w[d]);
                         done = true;
                         break;
                     }
-                    h = (h + 1) & (HE - 1);
+                    hh = (hh + 1) & (HE - 1);
                 }
                 if (!done) overflow = true;
             }
         }
+#ifdef PF_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t == 0) {
+            atomicAdd(&a.prof[14], (unsigned long long)(pf_s5a - pf_t0_));
+            atomicAdd(&a.prof[15], (unsigned long long)(__builtin_amdgcn_s_memtime() - pf_s5a));
+        }
+        atomicAdd(&a.prof[16], (unsigned long long)pf_ncand);
+        atomicAdd(&a.prof[17], (unsigned long long)pf_nlive);
+        atomicAdd(&a.prof[18], (unsigned long long)pf_nslow);
+#endif
     }
     if (__syncthreads_or(overflow)) {
         if (t == 0) atomicOr(a.flags, 1u);
         return;
     }
+    PF_STAMP(4);
+    // compact the pairs into the memory of the elevation keys (every thread holds what it still needs in registers)
+    uint32_t *ek = zk, *ew = zk + HE;
+    for (int h = t; h < HE; h += NT) {
+        const uint32_t key = hk[h];
+        if (key == EMPTY) continue;
+        const int i = atomicAdd(&s_ne, 1);
+        ek[i] = key;
+        ew[i] = hv[h];
+    }
+    __syncthreads();
+    const int NE = s_ne;
+    PF_STAMP(5);
     // ---- label-correcting on the basin graph: (level, seed) of every interior-pit basin
-    for (int it = 0; it < 4 * NBMAX; ++it) {
-        bool ch = false;
-        for (int h = t; h < HE; h += 256) {
-            const uint32_t key = hk[h];
-            if (key == EMPTY) continue;
-            const int sa = (int)(key >> 10), sb = (int)(key & 1023u);
-            const unsigned long long w = hv[h];
-            const unsigned long long ka = bkey[sa], kb = bkey[sb];
-            if (btype[sa]) {
-                const unsigned long long hi = max(w, kb >> 32), cand = (hi << 32) | (kb & 0xffffffffull);
-                if (cand < ka) { atomicMin(&bkey[sa], cand); ch = true; }
-            }
-            if (btype[sb]) {
-                const unsigned long long hi = max(w, ka >> 32), cand = (hi << 32) | (ka & 0xffffffffull);
-                if (cand < kb) { atomicMin(&bkey[sb], cand); ch = true; }
+    {
+        int e_sa[EPT], e_sb[EPT];
+        unsigned long long e_w[EPT];
+        unsigned live = 0;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int e = t + j * NT;
+            e_sa[j] = e_sb[j] = 0;
+            e_w[j] = 0;
+            if (e < NE) {
+                const uint32_t key = ek[e];
+                e_sa[j] = (int)(key >> 10);
+                e_sb[j] = (int)(key & 1023u);
+                e_w[j] = ew[e];
+                if (btype[e_sa[j]]) live |= 1u << (2 * j);
+                if (btype[e_sb[j]]) live |= 2u << (2 * j);
             }
         }
-        if (!__syncthreads_or(ch)) break;
+        for (int it = 0; it < 4 * NBMAX; ++it) {
+            bool ch = false;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                if (!((live >> (2 * j)) & 3u)) continue;
+                const unsigned long long ka = bkey[e_sa[j]], kb = bkey[e_sb[j]];
+                if ((live >> (2 * j)) & 1u) {
+                    const unsigned long long hi = max(e_w[j], kb >> 32), cand = (hi << 32) | (kb & 0xffffffffull);
+                    if (cand < ka) { atomicMin(&bkey[e_sa[j]], cand); ch = true; }
+                }
+                if ((live >> (2 * j)) & 2u) {
+                    const unsigned long long hi = max(e_w[j], ka >> 32), cand = (hi << 32) | (ka & 0xffffffffull);
+                    if (cand < kb) { atomicMin(&bkey[e_sb[j]], cand); ch = true; }
+                }
+            }
+            if (!__syncthreads_or(ch)) break;
+        }
     }
-    // ---- S6: outputs
-    for (int s = t; s < NB; s += 256) {
-        a.tabV[(size_t)tile * NBMAX + s] = (uint32_t)(bkey[s] >> 32);
-        a.tabL[(size_t)tile * NBMAX + s] = (uint8_t)(bkey[s] & 0xffu);
+    PF_STAMP(6);
+    // ---- S6: outputs.  The seeds in use (ring positions) get compact indices 0 .. NS-1 inside the tile; OCEAN stays 255.
+    // The hash arrays are free again: seed map | in-use flags | seed-pair hash
+    uint8_t *cmap = reinterpret_cast<uint8_t *>(hkv);        // [256]
+    uint32_t *used = hkv + 64;                               // [256]
+    uint32_t *sk = hkv + 512, *sv = sk + SE;                 // [SE] each
+    for (int i = t; i < 256; i += NT) used[i] = 0u;
+    for (int i = t; i < SE; i += NT) { sk[i] = EMPTY; sv[i] = EMPTY; }
+    __syncthreads();
+    for (int sI = t; sI < NB; sI += NT) {
+        const uint32_t lab = (uint32_t)(bkey[sI] & 0xffu);
+        if (lab != (uint32_t)OCEAN) used[lab] = 1u;
+    }
+    __syncthreads();
+    if (t < 256) {
+        const bool u = used[t] != 0u;
+        const unsigned long long m = __ballot(u);
+        if (wc == 0) s_scan[q] = __builtin_popcountll(m);
+        const int within = __builtin_popcountll(m & ((1ull << wc) - 1ull));
+        used[t] = u ? (uint32_t)within | 0x100u : 0u;       // bit 8: in use; low bits: rank inside the wavefront
+    }
+    __syncthreads();
+    const int NS = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    if (t < 256) {
+        int off = 0;
+        for (int w2 = 0; w2 < (t >> 6); ++w2) off += s_scan[w2];
+        cmap[t] = (used[t] & 0x100u) ? (uint8_t)(off + (int)(used[t] & 0xffu)) : (uint8_t)NOLAB;
+        if (t == OCEAN) cmap[t] = (uint8_t)OCEAN;
+    }
+    __syncthreads();
+    if (NS > NSMAX) {   // block-uniform
+        if (t == 0) atomicOr(a.flags, 1u);
+        return;
+    }
+    for (int sI = t; sI < NB; sI += NT) {
+        a.tabV[(size_t)tile * NBMAX + sI] = (uint32_t)(bkey[sI] >> 32);
+        a.tabL[(size_t)tile * NBMAX + sI] = cmap[(int)(bkey[sI] & 0xffu)];
     }
     if (t == 0) a.tileNB[tile] = NB;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int wr = q * 16 + k, ci = wr * WN + wc;
-        const uint8_t c = cls[ci];
-        if (!(c & C_VALID) || (c & C_BORDER)) continue;
-        const int s = (int)aux[ptr[ci]];
-        if (c & C_RING) a.ringLab[(size_t)tile * 256 + ring_pos(wr, wc)] = (uint8_t)(bkey[s] & 0xffu);
-        else a.bslot[(r0 + wr) * W + cc] = (uint16_t)s;
+    for (int k = 0; k < CPT; ++k) {
+        const int wr = wr0 + k;
+        const uint8_t c = mycls[k];
+        if (!c || (c & C_BORDER)) continue;
+        const int sI = myslot[k];
+        if (c & C_RING) a.ringLab[(size_t)tile * 256 + ring_pos(wr, wc)] = cmap[(int)(bkey[sI] & 0xffu)];
+        else a.bslot[(g.r0 + wr) * W + cc] = (uint16_t)sI;
     }
+    PF_STAMP(7);
     // min spill elevation between pairs of seeds
     bool ov2 = false;
-    for (int h = t; h < HE; h += 256) {
-        const uint32_t key = hk[h];
-        if (key == EMPTY) continue;
+    for (int e = t; e < NE; e += NT) {
+        const uint32_t key = ek[e];
         const int sa = (int)(key >> 10), sb = (int)(key & 1023u);
         const unsigned long long ka = bkey[sa], kb = bkey[sb];
-        const uint32_t la = (uint32_t)(ka & 0xffu), lb = (uint32_t)(kb & 0xffu);
-        if (la == lb) continue;
-        const uint32_t ww = max(hv[h], max((uint32_t)(ka >> 32), (uint32_t)(kb >> 32)));
+        if ((ka & 0xffu) == (kb & 0xffu)) continue;
+        const uint32_t la = cmap[(int)(ka & 0xffu)], lb = cmap[(int)(kb & 0xffu)];
+        const uint32_t ww = max(ew[e], max((uint32_t)(ka >> 32), (uint32_t)(kb >> 32)));
         const uint32_t k2 = la < lb ? (la << 8 | lb) : (lb << 8 | la);
         unsigned hh = (k2 * 2654435761u) >> 23;
         bool done = false;
@@ -385,7 +555,7 @@ __global__ __launch_bounds__(256) void pf_tile_kernel(PfArgs a)
         if (!done) ov2 = true;
     }
     __syncthreads();
-    for (int h = t; h < SE; h += 256) {
+    for (int h = t; h < SE; h += NT) {
         if (sk[h] == EMPTY) continue;
         const int i = atomicAdd(&s_cnt, 1);
         if (i < SPMAX) a.spill[(size_t)tile * SPMAX + i] = ((unsigned long long)sk[h] << 32) | sv[h];
@@ -395,7 +565,17 @@ __global__ __launch_bounds__(256) void pf_tile_kernel(PfArgs a)
         if (t == 0) atomicOr(a.flags, 1u);
         return;
     }
+    for (int i = s_cnt + t; i < SPMAX; i += NT) a.spill[(size_t)tile * SPMAX + i] = ~0ull;
     if (t == 0) a.tileNS[tile] = s_cnt;
+    PF_STAMP(8);
+#ifdef PF_PROFILE
+    if (t == 0) {
+        atomicAdd(&a.prof[9], (unsigned long long)NB);
+        atomicAdd(&a.prof[10], (unsigned long long)NE);
+        atomicAdd(&a.prof[13], (unsigned long long)s_cnt);
+        atomicAdd(&a.prof[11], (unsigned long long)NS);
+    }
+#endif
 }
 
 // ---- K2: the two seeds of a ring cell (its own tile's and its owner's) are joined at the owner's fill level of the cell
@@ -457,71 +637,115 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
         if (t == 0) atomicOr(a.flags, 1u);
         return;
     }
+    for (int i = s_cnt + t; i < LMAX; i += 256) a.links[(size_t)tile * LMAX + i] = ~0ull;
     if (t == 0) a.tileNL[tile] = s_cnt;
-    // start values of the solve: +inf for every seed, OCEAN below everything
-    a.Lv[(size_t)tile * 256 + t] = t == OCEAN ? 0u : EMPTY;
+#ifdef PF_PROFILE
+    if (t == 0) atomicAdd(&a.prof[12], (unsigned long long)s_cnt);
+#endif
+    // start values of the solve: +inf for every seed (OCEAN is not stored: its level is below everything)
+    if (t < NSMAX) a.Lv[(size_t)tile * NSMAX + t] = EMPTY;
 }
 
 // ---- K3: one round of the seed-graph solve; a wavefront visits a tile -------------------------------------------------
+// Worklist without atomics: one "active" byte per tile, double buffered over the rounds.  Tile -> wavefront is a fixed map
+// (tile = l * nw + gw, l < chunk: a wavefront's bytes are contiguous, the tiles of a moving front spread over all
+// wavefronts); a visit that lowered a seed sets the bytes of the neighbours that hold a link to it with plain stores and
+// raises the round's "somebody appended" word.  Levels are read and written with plain loads / stores: a value written in
+// this round may or may not be seen by a neighbour visited in the same round (it is only ever lower: harmless), and the
+// neighbour is visited again in the next round -- a new launch -- where it is seen for sure.  (Returning atomics on a
+// list head / append counter / mark word and agent-scope atomic loads made a visit ~70 us under load; measured.)
 struct SolveArgs {
     PfArgs a;
-    int *list_cur, *list_nxt;
-    unsigned int *mark_nxt;
-    unsigned int *count_cur, *count_nxt, *head;
+    uint8_t *act_cur, *act_nxt;
+    unsigned int *any_nxt;
     unsigned long long *visits;
-    int first;    // 1: every tile (statically strided), no list
+    int nw, chunk;   // wavefronts of the launch (fixed over the rounds), tiles per wavefront
+    int first;       // 1: every tile
 };
 
 __global__ __launch_bounds__(256) void pf_solve_kernel(SolveArgs sa)
 {
-    __shared__ uint32_t Ls[4][256];
+    // per wavefront: the levels of the 3 x 3 tiles around the visited one ([4] = its own) and its own levels as loaded
+    __shared__ uint32_t Ls[4][9][NSMAX], Lo[4][NSMAX];
+    __shared__ unsigned int s_dirs[4];
     const PfArgs &a = sa.a;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t *L = Ls[wave];
+    uint32_t(*Ln)[NSMAX] = Ls[wave];
+    uint32_t *L = Ln[4], *Lold = Lo[wave];
     const int ntiles = a.ntr * a.ntc;
-    const int gw = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= sa.nw) return;
+    constexpr int LPL = LMAX / 64, SPL = SPMAX / 64, VPL = NSMAX / 64;   // links / spill edges / levels per lane
+    const size_t slot0 = (size_t)gw * sa.chunk;
+    bool mine = false;
+    if (lane < sa.chunk) {
+        const int tile = lane * sa.nw + gw;
+        mine = tile < ntiles && (sa.first || sa.act_cur[slot0 + lane] != 0);
+        if (mine && !sa.first) sa.act_cur[slot0 + lane] = 0;   // this buffer is appended to again two rounds from now
+    }
+    unsigned long long todo = __ballot(mine);
     unsigned nvis = 0;
-    const unsigned n = sa.first ? (unsigned)ntiles : *sa.count_cur;
-    for (;;) {
-        unsigned i;
-        if (sa.first) {
-            i = (unsigned)gw + nvis * (unsigned)nwaves;
-        } else {
-            i = 0;
-            if (lane == 0) i = atomicAdd(sa.head, 1u);
-            i = __builtin_amdgcn_readfirstlane(i);
-        }
-        if (i >= n) break;
-        const int tile = sa.first ? (int)i : sa.list_cur[i];
+    bool pushed = false;
+    while (todo) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int tile = l * sa.nw + gw;
         ++nvis;
         const int ti = tile / a.ntc, tj = tile - ti * a.ntc;
-        uint32_t old[4];
+        // ONE batch of loads: the levels of the nine tiles, my links, my spill edges (unused entries are ~0)
+        uint32_t lv[9][VPL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            old[k] = __hip_atomic_load(&a.Lv[(size_t)tile * 256 + lane * 4 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            L[lane * 4 + k] = old[k];
+        for (int x = 0; x < 9; ++x) {
+            const int p = ti + x / 3 - 1, qq = tj + x % 3 - 1;
+            const bool ok = p >= 0 && p < a.ntr && qq >= 0 && qq < a.ntc;
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) lv[x][k] = ok ? a.Lv[(size_t)(p * a.ntc + qq) * NSMAX + lane + 64 * k] : EMPTY;
         }
+#ifdef PF_PROFILE
+        const long long k3_t0 = __builtin_amdgcn_s_memtime();
+#endif
+        unsigned long long lk[LPL], sp[SPL];
+#pragma unroll
+        for (int j = 0; j < LPL; ++j) lk[j] = a.links[(size_t)tile * LMAX + lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) sp[j] = a.spill[(size_t)tile * SPMAX + lane + 64 * j];
+#ifdef PF_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long k3_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        if (lane == 0) s_dirs[wave] = 0u;
+#pragma unroll
+        for (int x = 0; x < 9; ++x)
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) Ln[x][lane + 64 * k] = lv[x][k];
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) Lold[lane + 64 * k] = lv[4][k];
         __builtin_amdgcn_wave_barrier();
-        const int nl = a.tileNL[tile], ns = a.tileNS[tile];
-        for (int e = lane; e < nl; e += 64) {
-            const unsigned long long v = a.links[(size_t)tile * LMAX + e];
-            const uint32_t key = (uint32_t)(v >> 32), w = (uint32_t)v;
-            const int mylab = (int)(key >> 16), dir = (int)((key >> 8) & 0xffu), nlab = (int)(key & 0xffu);
-            uint32_t ln = 0u;
-            if (nlab != OCEAN) {
-                const int nt = (ti + dir / 3 - 1) * a.ntc + (tj + dir % 3 - 1);
-                ln = __hip_atomic_load(&a.Lv[(size_t)nt * 256 + nlab], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < LPL; ++j)
+            if (lk[j] != ~0ull) {
+                const uint32_t key = (uint32_t)(lk[j] >> 32);
+                const int mylab = (int)(key >> 16), dir = (int)((key >> 8) & 0xffu), nlab = (int)(key & 0xffu);
+                const uint32_t ln = nlab == OCEAN ? 0u : Ln[dir][nlab];
+                atomicMin(&L[mylab], max((uint32_t)lk[j], ln));
             }
-            atomicMin(&L[mylab], max(w, ln));
-        }
         __builtin_amdgcn_wave_barrier();
-        for (int it = 0; it < 256; ++it) {   // spill edges inside the tile, to a local fixed point
+#ifdef PF_PROFILE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long k3_t2 = __builtin_amdgcn_s_memtime();
+        unsigned k3_it = 0;
+#endif
+        for (int it = 0; it < 2 * NSMAX; ++it) {   // spill edges inside the tile, to a local fixed point
             bool ch = false;
-            for (int e = lane; e < ns; e += 64) {
-                const unsigned long long v = a.spill[(size_t)tile * SPMAX + e];
-                const uint32_t key = (uint32_t)(v >> 32), w = (uint32_t)v;
+#ifdef PF_PROFILE
+            ++k3_it;
+#endif
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                if (sp[j] == ~0ull) continue;
+                const uint32_t key = (uint32_t)(sp[j] >> 32), w = (uint32_t)sp[j];
                 const int la = (int)(key >> 8), lb = (int)(key & 0xffu);
-                const uint32_t va = L[la], vb = L[lb];
+                const uint32_t va = la == OCEAN ? 0u : L[la], vb = lb == OCEAN ? 0u : L[lb];
                 const uint32_t ca = max(w, vb), cb = max(w, va);
                 if (la != OCEAN && ca < va) { atomicMin(&L[la], ca); ch = true; }
                 if (lb != OCEAN && cb < vb) { atomicMin(&L[lb], cb); ch = true; }
@@ -529,31 +753,54 @@ __global__ __launch_bounds__(256) void pf_solve_kernel(SolveArgs sa)
             __builtin_amdgcn_wave_barrier();
             if (!__any(ch)) break;
         }
+#ifdef PF_PROFILE
+        const long long k3_t3 = __builtin_amdgcn_s_memtime();
+#endif
         bool changed = false;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t v = L[lane * 4 + k];
-            if (v < old[k]) {
-                __hip_atomic_store(&a.Lv[(size_t)tile * 256 + lane * 4 + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < VPL; ++k) {
+            const uint32_t v = L[lane + 64 * k];
+            if (v < lv[4][k]) {
+                a.Lv[(size_t)tile * NSMAX + lane + 64 * k] = v;
                 changed = true;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (__any(changed) && lane < 9 && lane != 4) {
-            const int p = ti + lane / 3 - 1, qq = tj + lane % 3 - 1;
-            if (p >= 0 && p < a.ntr && qq >= 0 && qq < a.ntc) {
-                const int nt = p * a.ntc + qq;
-                if (atomicExch(&sa.mark_nxt[nt], 1u) == 0u) sa.list_nxt[atomicAdd(sa.count_nxt, 1u)] = nt;
+        if (__any(changed)) {
+            // only the neighbours that hold a link to a seed whose level dropped can gain anything
+            unsigned dirs = 0;
+#pragma unroll
+            for (int j = 0; j < LPL; ++j)
+                if (lk[j] != ~0ull) {
+                    const uint32_t key = (uint32_t)(lk[j] >> 32);
+                    const int mylab = (int)(key >> 16);
+                    if (L[mylab] < Lold[mylab]) dirs |= 1u << ((key >> 8) & 0xffu);
+                }
+            if (dirs) atomicOr(&s_dirs[wave], dirs);
+            __builtin_amdgcn_wave_barrier();
+            dirs = s_dirs[wave];
+            if (lane < 9 && ((dirs >> lane) & 1u)) {
+                const int nt = (ti + lane / 3 - 1) * a.ntc + (tj + lane % 3 - 1);
+                sa.act_nxt[(size_t)(nt % sa.nw) * sa.chunk + nt / sa.nw] = 1;
             }
+            pushed = pushed || dirs != 0;
         }
+        __builtin_amdgcn_wave_barrier();
+#ifdef PF_PROFILE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const long long k3_t4 = __builtin_amdgcn_s_memtime();
+            atomicAdd(&a.prof[19], (unsigned long long)(k3_t1 - k3_t0));
+            atomicAdd(&a.prof[20], (unsigned long long)(k3_t2 - k3_t1));
+            atomicAdd(&a.prof[21], (unsigned long long)(k3_t3 - k3_t2));
+            atomicAdd(&a.prof[22], (unsigned long long)(k3_t4 - k3_t3));
+            atomicAdd(&a.prof[23], (unsigned long long)k3_it);
+        }
+#endif
     }
-    if (lane == 0 && nvis) atomicAdd(sa.visits, (unsigned long long)nvis);
-}
-
-__global__ __launch_bounds__(256) void pf_clear_marks_kernel(const int *list, const unsigned int *count, unsigned int *mark)
-{
-    const unsigned n = *count;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) mark[list[i]] = 0u;
+    if (lane == 0) {
+        if (pushed) *sa.any_nxt = 1u;
+        if (nvis) atomicAdd(sa.visits, (unsigned long long)nvis);
+    }
 }
 
 // ---- K4: final level of every basin, then the raster ---------------------------------------------------------------------
@@ -563,7 +810,8 @@ __global__ __launch_bounds__(256) void pf_final_kernel(PfArgs a)
     const int nb = a.tileNB[tile];
     for (int s = threadIdx.x; s < nb; s += 256) {
         const size_t i = (size_t)tile * NBMAX + s;
-        a.tabV[i] = max(a.tabV[i], a.Lv[(size_t)tile * 256 + a.tabL[i]]);
+        const int lab = a.tabL[i];
+        a.tabV[i] = max(a.tabV[i], lab == OCEAN ? 0u : a.Lv[(size_t)tile * NSMAX + lab]);
     }
 }
 
@@ -615,14 +863,21 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     const size_t o_ns = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_links = off; off = al(off + (size_t)ntiles * LMAX * 8);
     const size_t o_nl = off; off = al(off + (size_t)ntiles * 4);
-    const size_t o_lv = off; off = al(off + (size_t)ntiles * 256 * 4);
-    const size_t o_list = off; off = al(off + (size_t)ntiles * 2 * 4);
-    const size_t o_mark = off; off = al(off + (size_t)ntiles * 2 * 4);
-    const size_t o_cnt = off; off = al(off + (size_t)(MAXR + 2) * 4 * 2 + 64);
+    const size_t o_lv = off; off = al(off + (size_t)ntiles * NSMAX * 4);
+    // solve worklist: nw wavefronts (every resident slot of the chip, fewer on small rasters), chunk tiles each (<= 64)
+    int nw = (int)(ntiles < 8192 ? ntiles : 8192);
+    int chunk = (int)cdiv(ntiles, nw);
+    if (chunk > 64) {
+        chunk = 64;
+        nw = (int)cdiv(ntiles, 64);
+    }
+    const size_t nslots = (size_t)nw * chunk;
+    const size_t o_act = off; off = al(off + nslots * 2);
+    const size_t o_cnt = off; off = al(off + (size_t)(MAXR + 2) * 4 + 64 + 32 * 8);
     DevBuf ws;
     MH_TRY(ws.alloc(off));
     char *b = ws.as<char>();
-    MH_HIP(hipMemsetAsync(b + o_mark, 0, off - o_mark, s));               // marks, counters, heads, flags, visits
+    MH_HIP(hipMemsetAsync(b + o_act, 0, off - o_act, s));                 // active bytes, per-round words, flags, visits
     MH_HIP(hipMemsetAsync(b + o_ring, NOLAB, (size_t)ntiles * 256, s));
     PfArgs a;
     a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = d_dem;
@@ -636,32 +891,28 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     a.links = reinterpret_cast<unsigned long long *>(b + o_links);
     a.tileNL = reinterpret_cast<int *>(b + o_nl);
     a.Lv = reinterpret_cast<uint32_t *>(b + o_lv);
-    unsigned int *count = reinterpret_cast<unsigned int *>(b + o_cnt);    // [MAXR + 2]
-    unsigned int *head = count + (MAXR + 2);                               // [MAXR + 2]
-    a.flags = head + (MAXR + 2);
+    unsigned int *any = reinterpret_cast<unsigned int *>(b + o_cnt);      // [MAXR + 2] "round r was handed work"
+    a.flags = any + (MAXR + 2);
     unsigned long long *visits = reinterpret_cast<unsigned long long *>(a.flags + 2);
-    int *lists = reinterpret_cast<int *>(b + o_list);
-    unsigned int *marks = reinterpret_cast<unsigned int *>(b + o_mark);
+    a.prof = visits + 1;   // 24 words (inside the zeroed tail of the workspace)
+    uint8_t *act = reinterpret_cast<uint8_t *>(b + o_act);
 
-    hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
     MH_HIP(hipGetLastError());
     int launches = 2, round = 0;
-    const unsigned grid = (unsigned)(cdiv(ntiles, 4) < 1024 ? cdiv(ntiles, 4) : 1024);
+    const unsigned grid = (unsigned)cdiv(nw, 4);
     auto launch_round = [&](int r) {
         SolveArgs sa;
         sa.a = a;
-        sa.list_cur = lists + (size_t)(r & 1) * ntiles;
-        sa.list_nxt = lists + (size_t)((r + 1) & 1) * ntiles;
-        sa.mark_nxt = marks + (size_t)((r + 1) & 1) * ntiles;
-        sa.count_cur = count + r;
-        sa.count_nxt = count + r + 1;
-        sa.head = head + r;
+        sa.act_cur = act + (size_t)(r & 1) * nslots;
+        sa.act_nxt = act + (size_t)((r + 1) & 1) * nslots;
+        sa.any_nxt = any + r + 1;
         sa.visits = visits;
+        sa.nw = nw;
+        sa.chunk = chunk;
         sa.first = r == 0;
         hipLaunchKernelGGL(pf_solve_kernel, dim3(grid), dim3(256), 0, s, sa);
-        // the marks of the list this round consumed must be clear before the round after next appends to them again
-        if (r > 0) hipLaunchKernelGGL(pf_clear_marks_kernel, dim3(64), dim3(256), 0, s, sa.list_cur, sa.count_cur, marks + (size_t)(r & 1) * ntiles);
     };
     constexpr int BATCH = 32;
     std::vector<unsigned int> h_cnt(BATCH + 1);
@@ -675,10 +926,15 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
         for (int k = 0; k < BATCH; ++k) launch_round(round + k);
         launches += BATCH;
         MH_HIP(hipGetLastError());
-        MH_HIP(hipMemcpyAsync(h_cnt.data(), count + round + 1, sizeof(unsigned int) * BATCH, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(h_cnt.data(), any + round + 1, sizeof(unsigned int) * BATCH, hipMemcpyDeviceToHost, s));
         MH_HIP(hipMemcpyAsync(&h_flag, a.flags, 4, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         if (h_flag) return MHIP_ELIMIT;
+        if (getenv("MHIP_PF_DEBUG")) {
+            fprintf(stderr, "[pf_solve] rounds %d..%d appended work:", round, round + BATCH - 1);
+            for (int k = 0; k < BATCH; ++k) fprintf(stderr, " %u", h_cnt[k]);
+            fprintf(stderr, "\n");
+        }
         for (int k = 0; k < BATCH; ++k)
             if (h_cnt[k] == 0) {   // round (round + k) appended nothing: converged; the launches after it were no-ops
                 done = true;
@@ -692,6 +948,30 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     hipLaunchKernelGGL(pf_apply_kernel, dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, s, a, d_out, d_depths);
     MH_HIP(hipGetLastError());
     launches += 2;
+#ifdef PF_PROFILE
+    {
+        unsigned long long h_prof[24];
+        MH_HIP(hipMemcpyAsync(h_prof, a.prof, sizeof(h_prof), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));
+        const char *names[9] = {"load", "descent+plateaus", "doubling", "slots", "pairs", "compact", "label-correcting", "outputs", "spill"};
+        double tot = 0;
+        for (int i = 0; i < 9; ++i) tot += (double)h_prof[i];
+        fprintf(stderr, "[pf_tile profile] ticks/tile:");
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " %s=%.0f", names[i], (double)h_prof[i] / (double)ntiles);
+        fprintf(stderr, " | total=%.0f basins/tile=%.1f pairs/tile=%.1f seeds/tile=%.1f links/tile=%.1f spill/tile=%.1f\n", tot / (double)ntiles,
+                (double)h_prof[9] / (double)ntiles, (double)h_prof[10] / (double)ntiles, (double)h_prof[11] / (double)ntiles,
+                (double)h_prof[12] / (double)ntiles, (double)h_prof[13] / (double)ntiles);
+        {
+            unsigned long long hv_ = 0;
+            (void)hipMemcpy(&hv_, visits, 8, hipMemcpyDeviceToHost);
+            const double nv = (double)(hv_ ? hv_ : 1);
+            fprintf(stderr, "[pf_solve, per visit] load ticks=%.0f links=%.0f spill loop=%.0f (%.1f iterations) store+push=%.0f | visits=%llu\n", (double)h_prof[19] / nv,
+                    (double)h_prof[20] / nv, (double)h_prof[21] / nv, (double)h_prof[23] / nv, (double)h_prof[22] / nv, hv_);
+        }
+        fprintf(stderr, "[pf_tile S5, wave 0] preload ticks=%.0f insert ticks=%.0f | per tile: candidates=%.0f live=%.0f slow-path=%.0f\n", (double)h_prof[14] / (double)ntiles,
+                (double)h_prof[15] / (double)ntiles, (double)h_prof[16] / (double)ntiles, (double)h_prof[17] / (double)ntiles, (double)h_prof[18] / (double)ntiles);
+    }
+#endif
     if (st) {
         unsigned long long h_vis = 0;
         MH_HIP(hipMemcpyAsync(&h_vis, visits, 8, hipMemcpyDeviceToHost, s));

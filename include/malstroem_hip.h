@@ -110,6 +110,25 @@ int mhip_label_max(const int32_t *labels, int64_t n, int32_t *out_max);
  * _flow.pyx:276-403. In place on labels. Terminates on flow cycles (reference does not). */
 int mhip_watersheds_i32(const uint8_t *flowdir, int32_t *labels_inout, int64_t H, int64_t W, int32_t unassigned);
 
+/* net.next_downstream_label(flowdir, labeled, cell, background_label, geometry) for a BATCH of cells -- what
+ * net.pourpoint_network / geometric_pourpoint_network loop over (reference net.py:142-192, 195-224).  cells_rc: n (row, col)
+ * pairs.  Per cell: out_found = 1 and out_label = the first label on the downstream walk that differs from the start cell's
+ * (and from `background` when use_background), else out_found = 0 (the reference's None); out_len = number of cells walked,
+ * start and end included (the reference's geometry).  Geometry in a second call: offsets = n + 1 prefix sums of out_len,
+ * out_cells receives the walked cells as linear indices row * W + col.  Any output pointer may be NULL.  A walk caught in
+ * a flow cycle (the reference never returns from it) is cut after H * W steps and reports "none". */
+int mhip_trace_downstream_i32(const uint8_t *flowdir, const int32_t *labels, int64_t H, int64_t W, const int64_t *cells_rc, int64_t n,
+                              int use_background, int32_t background, int32_t *out_label, int32_t *out_found, int64_t *out_len,
+                              const int64_t *offsets, int64_t *out_cells);
+
+/* network.Network.rain_event for several rain events at once (reference network.py:75-129, rain.py:48-87): leaf-to-root fill
+ * and spill over the node forest.  Host code (O(nodes) per event), no device needed.  down_index[i]: position of node i's
+ * downstream node, -1 = root (downstream id None), -2 = downstream id unknown (the node is never evaluated, like in the
+ * reference).  Outputs are [nevents][n]; NaN marks "not evaluated" and, in pctv, the reference's None (bspot_vol == 0).
+ * order[0 .. *ncomputed): the nodes in the reference's evaluation (= result list) order. */
+int mhip_rain_events(int64_t n, const int64_t *down_index, const double *wshed_area, const double *bspot_vol, int32_t nevents,
+                     const double *mmrain, double *rainv, double *spillv, double *v, double *pctv, int64_t *order, int64_t *ncomputed);
+
 /* ---- device-resident pipeline (DemTool / BluespotTool sequences, reference dem.py:53-93,
  *      bluespots.py:138-216): one upload, all stages in HBM, downloads only for the writers. ------- */
 typedef struct mhip_ctx mhip_ctx;
@@ -201,6 +220,9 @@ int mhip_ctx_upload(mhip_ctx *ctx, int which, const void *host);     /* any rast
 int mhip_ctx_download(mhip_ctx *ctx, int which, void *host);         /* H_local x W */
 int mhip_ctx_run(mhip_ctx *ctx, int stage_mask);                     /* asynchronous on the ctx stream */
 int mhip_ctx_sync(mhip_ctx *ctx);
+/* mhip_trace_downstream_i32 on the context's resident flow directions and bluespot labels (StreamTool after BluespotTool) */
+int mhip_ctx_trace_downstream(mhip_ctx *ctx, const int64_t *cells_rc, int64_t n, int use_background, int32_t background,
+                              int32_t *out_label, int32_t *out_found, int64_t *out_len, const int64_t *offsets, int64_t *out_cells);
 /* after mhip_ctx_sync: milliseconds (HIP events on the ctx stream) of `stage` (single bit) in the last run */
 int mhip_ctx_stage_ms(mhip_ctx *ctx, int stage, float *ms);
 /* milliseconds / launch count of one named kernel family in the last run ("d8", "fill_round", ...) */

@@ -383,6 +383,51 @@ int mhip_watersheds_i32(const uint8_t *flowdir, int32_t *labels, int64_t H, int6
     return download(labels, d_l, n * 4, s);
 }
 
+/* net.next_downstream_label for a batch of cells (reference net.py:142-169): labels / found flags / path lengths, and -- when
+ * offsets (n + 1 prefix sums of the lengths of an earlier call) and out_cells are given -- the cells of every path as linear
+ * indices row * W + col.  The two rasters are host arrays here; mhip_ctx_trace_downstream walks the resident ones. */
+static int trace_on_device(const uint8_t *d_fd, const int32_t *d_lab, int64_t H, int64_t W, const int64_t *cells_rc, int64_t n, int use_bg,
+                           int32_t bg, int32_t *out_label, int32_t *out_found, int64_t *out_len, const int64_t *offsets, int64_t *out_cells,
+                           hipStream_t s)
+{
+    DevBuf d_c, d_l, d_f, d_n, d_o, d_p;
+    MH_TRY(upload(d_c, cells_rc, (size_t)n * 16, s));
+    MH_TRY(d_l.alloc((size_t)n * 4));
+    MH_TRY(d_f.alloc((size_t)n * 4));
+    MH_TRY(d_n.alloc((size_t)n * 8));
+    int64_t total = 0;
+    if (offsets && out_cells) {
+        total = offsets[n];
+        MH_ARG(total >= 0, "trace: offsets[n] must be the total path length");
+        MH_TRY(upload(d_o, offsets, (size_t)(n + 1) * 8, s));
+        MH_TRY(d_p.alloc((size_t)(total > 0 ? total : 1) * 8));
+    }
+    MH_TRY(trace_downstream_dev(d_fd, d_lab, H, W, d_c.as<int64_t>(), n, use_bg, bg, d_l.as<int32_t>(), d_f.as<int32_t>(), d_n.as<int64_t>(),
+                                total ? d_o.as<int64_t>() : nullptr, total ? d_p.as<int64_t>() : nullptr, s));
+    if (out_label) MH_HIP(hipMemcpyAsync(out_label, d_l.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (out_found) MH_HIP(hipMemcpyAsync(out_found, d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (out_len) MH_HIP(hipMemcpyAsync(out_len, d_n.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (total) MH_HIP(hipMemcpyAsync(out_cells, d_p.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
+}
+
+int mhip_trace_downstream_i32(const uint8_t *flowdir, const int32_t *labels, int64_t H, int64_t W, const int64_t *cells_rc, int64_t n,
+                              int use_background, int32_t background, int32_t *out_label, int32_t *out_found, int64_t *out_len,
+                              const int64_t *offsets, int64_t *out_cells)
+{
+    MH_ARG(flowdir && labels && H >= 1 && W >= 1 && n >= 0 && (n == 0 || cells_rc), "trace_downstream_i32(flowdir, labels, H, W, cells, n, ...)");
+    MH_TRY(require_device());
+    if (n == 0) return MHIP_OK;
+    hipStream_t s = 0;
+    const size_t nc = (size_t)(H * W);
+    DevBuf d_fd, d_lab;
+    MH_TRY(upload(d_fd, flowdir, nc, s));
+    MH_TRY(upload(d_lab, labels, nc * 4, s));
+    return trace_on_device(d_fd.as<uint8_t>(), d_lab.as<int32_t>(), H, W, cells_rc, n, use_background, background, out_label, out_found, out_len,
+                           offsets, out_cells, s);
+}
+
 /* ================================================================================================
  * device-resident pipeline
  * ================================================================================================ */
@@ -968,6 +1013,19 @@ int mhip_ctx_fill_end(mhip_ctx *c, int kind)
         c->have[MHIP_R_DEPTHS] = true;
     }
     return MHIP_OK;
+}
+
+/* the same walk over the context's resident flow directions and (filtered) bluespot labels: no raster leaves the device */
+int mhip_ctx_trace_downstream(mhip_ctx *c, const int64_t *cells_rc, int64_t n, int use_background, int32_t background, int32_t *out_label,
+                              int32_t *out_found, int64_t *out_len, const int64_t *offsets, int64_t *out_cells)
+{
+    MH_ARG(c && n >= 0 && (n == 0 || cells_rc), "ctx_trace_downstream(ctx, cells, n, ...)");
+    MH_ARG(c->have[MHIP_R_FLOWDIR] && c->have[MHIP_R_LABELS], "ctx_trace_downstream needs flow directions and labels");
+    MH_ARG(!c->ht && !c->hb, "stream tracing runs on an undivided raster");
+    if (n == 0) return MHIP_OK;
+    MH_HIP(hipSetDevice(c->device));
+    return trace_on_device(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->H, c->W, cells_rc, n, use_background,
+                           background, out_label, out_found, out_len, offsets, out_cells, c->stream);
 }
 
 int mhip_ctx_sync(mhip_ctx *c)

@@ -150,6 +150,10 @@ int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, 
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
 int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s);
 int row_update_async(void *d_dst, const void *d_src, int64_t nbytes, int *d_changed, hipStream_t s);
+// trace.hip
+int trace_downstream_dev(const uint8_t *d_fd, const int32_t *d_lab, int64_t H, int64_t W, const int64_t *d_cells, int64_t n, int use_bg,
+                         int32_t bg, int32_t *d_label, int32_t *d_found, int64_t *d_len, const int64_t *d_offsets, int64_t *d_out_cells,
+                         hipStream_t s);
 // comm.hip (RCCL, opened at run time)
 int comm_unique_id(void *id128);
 int comm_create(void **comm, const void *id128, int rank, int nranks);

@@ -19,7 +19,7 @@ __all__ = [
     "build", "fill_terrain", "fill_terrain_no_flats", "minimum_safe_short_and_diag",
     "terrain_flowdirection", "accumulated_flow", "connected_components", "label_stats",
     "label_min_index", "label_max_index", "label_count", "keep_labels", "watersheds_from_labels",
-    "depths", "STAT_DTYPE", "INDEX_DTYPE",
+    "depths", "STAT_DTYPE", "INDEX_DTYPE", "next_downstream_label", "rain_event",
 ]
 
 
@@ -174,3 +174,58 @@ def depths(filled, dem):
     out = np.empty_like(f)
     _check(_lib().orc_depths_f32(_p(f), _p(d), _p(out), ctypes.c_int64(f.size)), "depths")
     return out
+
+
+# ---- stream network (test infrastructure like everything in this package) -------------------------------------------------
+
+def next_downstream_label(flowdir, labeled, cell, background_label=None, max_steps=None):
+    """Plain-Python restatement of reference net.py:142-169 on top of flow.trace_downstream (flow.py:286-301): walk from
+    ``cell`` along the flow directions; -> (first label that differs from the start cell's and from the background, or None;
+    list of walked cells).  ``max_steps`` cuts flow cycles (the reference never returns from one)."""
+    deltas = ((-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1))
+    H, W = flowdir.shape
+    r, c = int(cell[0]), int(cell[1])
+    geom = []
+    if not (0 <= r < H and 0 <= c < W):
+        return None, geom
+    src = labeled[r, c]
+    cap = H * W if max_steps is None else max_steps
+    while len(geom) < cap:
+        geom.append((r, c))
+        lbl = labeled[r, c]
+        if lbl != src and (background_label is None or lbl != background_label):
+            return int(lbl), geom
+        k = int(flowdir[r, c])
+        if k > 7:
+            break
+        r, c = r + deltas[k][0], c + deltas[k][1]
+        if not (0 <= r < H and 0 <= c < W):
+            break
+    return None, geom
+
+
+def rain_event(nodes, mmrain):
+    """Plain-Python restatement of reference network.py:75-129: leaf-to-root fill / spill on the node forest.
+    ``nodes``: dicts with nodeid, dstrnodeid, wshed_area, bspot_vol.  -> list of event dicts in the reference's order."""
+    index, upstream, roots = {}, {}, []
+    for n in nodes:
+        index[n['nodeid']] = n
+        upstream.setdefault(n['dstrnodeid'], []).append(n['nodeid'])
+        if n['dstrnodeid'] is None:
+            roots.append(n['nodeid'])
+    values = {}
+    for root in roots:
+        order, stack = [], [root]
+        while stack:
+            x = stack.pop()
+            order.append(x)
+            stack.extend(upstream.get(x, []))
+        for x in reversed(order):
+            node = index[x]
+            rainv = float(node['wshed_area']) * mmrain * 0.001
+            capacity = float(node['bspot_vol'])
+            inflow = sum([values[u]['spillv'] for u in upstream.get(x, [])]) if upstream.get(x) else 0.0
+            total = rainv + inflow
+            values[x] = dict(nodeid=x, rainv=rainv, spillv=max(0, total - capacity), v=min(total, capacity),
+                             pctv=None if not capacity else 100.0 * min(total, capacity) / capacity)
+    return list(values.values())

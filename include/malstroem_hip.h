@@ -218,6 +218,11 @@ int mhip_ctx_band_foreign_counts(mhip_ctx *ctx, int64_t lo, int64_t hi, int64_t 
 int mhip_ctx_upload_dem(mhip_ctx *ctx, const float *dem_band);       /* H_local x W host raster */
 int mhip_ctx_upload(mhip_ctx *ctx, int which, const void *host);     /* any raster (for sub-commands) */
 int mhip_ctx_download(mhip_ctx *ctx, int which, void *host);         /* H_local x W */
+/* the same in row windows [row0, row0 + nrows) of the owned raster (the reference's io.py:21-159 moves whole rasters): a
+ * streaming reader / writer keeps one window on the host whatever the raster's size; a raster counts as present once its
+ * last row has arrived */
+int mhip_ctx_upload_rows(mhip_ctx *ctx, int which, int64_t row0, int64_t nrows, const void *host);
+int mhip_ctx_download_rows(mhip_ctx *ctx, int which, int64_t row0, int64_t nrows, void *host);
 int mhip_ctx_run(mhip_ctx *ctx, int stage_mask);                     /* asynchronous on the ctx stream */
 int mhip_ctx_sync(mhip_ctx *ctx);
 /* mhip_trace_downstream_i32 on the context's resident flow directions and bluespot labels (StreamTool after BluespotTool) */

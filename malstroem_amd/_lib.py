@@ -34,7 +34,7 @@ SYMBOLS = [
     "mhip_label_argmin_f64", "mhip_label_argmax_f64", "mhip_label_count", "mhip_label_max", "mhip_watersheds_i32",
     "mhip_trace_downstream_i32", "mhip_ctx_trace_downstream", "mhip_rain_events",
     "mhip_ctx_create", "mhip_comm_unique_id", "mhip_ctx_create_band", "mhip_ctx_destroy", "mhip_ctx_upload_dem",
-    "mhip_ctx_upload", "mhip_ctx_download", "mhip_ctx_run", "mhip_ctx_sync", "mhip_ctx_stage_ms",
+    "mhip_ctx_upload", "mhip_ctx_download", "mhip_ctx_upload_rows", "mhip_ctx_download_rows", "mhip_ctx_run", "mhip_ctx_sync", "mhip_ctx_stage_ms",
     "mhip_ctx_kernel_ms", "mhip_ctx_get_i64", "mhip_ctx_get_f64", "mhip_ctx_raw_stats", "mhip_ctx_apply_keep",
     "mhip_ctx_stats", "mhip_ctx_watershed_counts", "mhip_ctx_pourpoints",
     "mhip_ctx_band_info", "mhip_ctx_get_edge_row", "mhip_ctx_set_halo_row", "mhip_ctx_get_edge_row_dev",

@@ -601,6 +601,39 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
 
 int mhip_ctx_upload_dem(mhip_ctx *c, const float *dem) { return mhip_ctx_upload(c, MHIP_R_DEM, dem); }
 
+/* Windowed transfers (reference io.py:21-159 moves whole rasters through the host): rows [row0, row0 + nrows) of the OWNED
+ * raster.  A raster counts as present once its last row has been uploaded; uploading DEM rows invalidates what was derived
+ * from the previous DEM.  The host side needs one window, whatever the raster's size. */
+int mhip_ctx_upload_rows(mhip_ctx *c, int which, int64_t row0, int64_t nrows, const void *host)
+{
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_ && row0 >= 0 && nrows >= 1 && row0 + nrows <= c->H_owned,
+           "ctx_upload_rows(ctx, which, row0, nrows, host)");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, which));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    if (which == MHIP_R_DEM)
+        for (int k = 0; k < MHIP_R_COUNT_; ++k) c->have[k] = false;
+    MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * (size_t)(c->ht + row0), host, rowb * (size_t)nrows, hipMemcpyHostToDevice, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));      // the caller reuses its window buffer
+    if (row0 + nrows == c->H_owned) {
+        c->have[which] = true;
+        if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; }
+    }
+    return MHIP_OK;
+}
+
+int mhip_ctx_download_rows(mhip_ctx *c, int which, int64_t row0, int64_t nrows, void *host)
+{
+    MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_ && row0 >= 0 && nrows >= 1 && row0 + nrows <= c->H_owned,
+           "ctx_download_rows(ctx, which, row0, nrows, host)");
+    MH_ARG(c->have[which], "raster has not been computed or uploaded");
+    MH_HIP(hipSetDevice(c->device));
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * (size_t)(c->ht + row0), rowb * (size_t)nrows, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
+    return MHIP_OK;
+}
+
 int mhip_ctx_download(mhip_ctx *c, int which, void *host)
 {
     MH_ARG(c && host && which >= 0 && which < MHIP_R_COUNT_, "ctx_download(ctx, which, host)");

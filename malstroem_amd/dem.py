@@ -27,26 +27,33 @@ class DemTool(object):
         self.logger = logging.getLogger(__name__)
 
     def process(self, keep_pipeline=False):
-        dem = self.input_dem.read().astype(dtypes.DTYPE_DTM, casting='same_kind', copy=False)
+        streaming = hasattr(self.input_dem, "iter_windows") and hasattr(self.input_dem, "shape")
+        dem = None if streaming else self.input_dem.read().astype(dtypes.DTYPE_DTM, casting='same_kind', copy=False)
         transform = self.input_dem.transform
         assert abs(abs(transform[1]) - abs(transform[5])) < 0.01 * abs(transform[1]), "Input cells must be square"
         if not speedups.enabled:
             raise RuntimeError("malstroem_amd: HIP backend not available and there is no CPU fallback")
 
-        pipe = HydroPipeline(dem.shape, device=self.device)
+        pipe = HydroPipeline(self.input_dem.shape if streaming else dem.shape, device=self.device)
         try:
-            pipe.upload("dem", dem)
+            if streaming:
+                # windowed reader (malstroem_amd.io.RasterReader): the DEM goes to the device window by window, the results
+                # come back the same way -- the host never holds a whole raster (reference io.py:60-73 / 141-159 do)
+                for row0, window in self.input_dem.iter_windows():
+                    pipe.upload_rows("dem", row0, window.astype(dtypes.DTYPE_DTM, casting='same_kind', copy=False))
+            else:
+                pipe.upload("dem", dem)
             self.logger.info("Calculating filled DEM and bluespot depths")
             pipe.run("fill")
-            self.output_filled.write(pipe.download("filled"))
-            self.output_depths.write(pipe.download("depths"))
+            pipe.download_to("filled", self.output_filled)
+            pipe.download_to("depths", self.output_depths)
             self.logger.info("Calculating flow directions")
             pipe.run("noflat", "flowdir")
-            self.output_flowdir.write(pipe.download("flowdir"))
+            pipe.download_to("flowdir", self.output_flowdir)
             if self.output_accum:
                 self.logger.info("Calculating flow accumulation")
                 pipe.run("accum")
-                self.output_accum.write(pipe.download("accum"))
+                pipe.download_to("accum", self.output_accum)
             self.logger.info("Done")
         except Exception:
             pipe.close()

@@ -59,6 +59,39 @@ class HydroPipeline(object):
         _lib.call("mhip_ctx_download", self._ctx, which, _lib.ptr(out))
         return out
 
+    # ---- windowed data movement (malstroem_amd.io readers / writers): one window on the host, whatever the raster's size
+    def upload_rows(self, name, row0, array):
+        which = RASTERS[name]
+        a = np.ascontiguousarray(array, dtype=RASTER_DTYPE[which])
+        if a.ndim != 2 or a.shape[1] != self.shape[1]:
+            raise ValueError("window must be full-width rows of the pipeline's raster")
+        _lib.call("mhip_ctx_upload_rows", self._ctx, which, _lib.i64(row0), _lib.i64(a.shape[0]), _lib.ptr(a))
+
+    def download_rows(self, name, row0, nrows):
+        which = RASTERS[name]
+        out = np.empty((int(nrows), self.shape[1]), dtype=RASTER_DTYPE[which])
+        _lib.call("mhip_ctx_download_rows", self._ctx, which, _lib.i64(row0), _lib.i64(nrows), _lib.ptr(out))
+        return out
+
+    def upload_from(self, name, reader, max_rows=None):
+        """Stream raster ``name`` from a reader with ``iter_windows`` (malstroem_amd.io.RasterReader); falls back to ``read()``."""
+        if hasattr(reader, "iter_windows"):
+            for row0, window in reader.iter_windows(max_rows):
+                self.upload_rows(name, row0, window)
+        else:
+            self.upload(name, reader.read())
+
+    def download_to(self, name, writer, max_rows=4096):
+        """Stream raster ``name`` into a writer with ``open`` / ``write_window`` / ``close``; falls back to ``write(array)``."""
+        if hasattr(writer, "write_window"):
+            writer.open(self.shape, RASTER_DTYPE[RASTERS[name]])
+            for row0 in range(0, self.shape[0], int(max_rows)):
+                n = min(int(max_rows), self.shape[0] - row0)
+                writer.write_window(row0, self.download_rows(name, row0, n))
+            writer.close()
+        else:
+            writer.write(self.download(name))
+
     # ---- stages ------------------------------------------------------------------------------------
     def run(self, *stages):
         mask = 0

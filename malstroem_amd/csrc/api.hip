@@ -1416,7 +1416,13 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     MH_ARG(c && key && value, "ctx_get_i64(ctx, key, value)");
     const std::string k(key);
     if (k == "nlabels_raw") *value = c->nlabels_raw;
-    else if (k == "nlabels") *value = c->nlabels;
+    else if (k == "nlabels") {
+        if (c->nlabels < 0 && c->have[MHIP_R_LABELS]) {   // labels came in by upload: their count is max(labelled), like the reference takes it
+            MH_HIP(hipSetDevice(c->device));
+            MH_TRY(ctx_label_max(c, c->stream));
+        }
+        *value = c->nlabels;
+    }
     else if (k == "fill_rounds") *value = c->fill_rounds;
     else if (k == "noflat_rounds") *value = c->noflat_rounds;
     else if (k == "fill_visits") *value = c->fill_st.visits;

@@ -185,6 +185,11 @@ int mhip_ctx_dem_minmax(mhip_ctx *ctx, float *mn, float *mx, int32_t *has_nan); 
 int mhip_ctx_fill_begin(mhip_ctx *ctx, int kind, double short_, double diag, int32_t *active);
 int mhip_ctx_fill_batch(mhip_ctx *ctx, int kind, int32_t *active);
 int mhip_ctx_fill_halo_changed(mhip_ctx *ctx, int kind, int side);
+/* certification: one sweep over EVERY tile of the band, iterated to local convergence; *changed = some tile moved.  The
+ * launcher calls it once all bands are quiescent and resumes the exchange loop if any band reports a change: a sweep that
+ * changes nothing anywhere proves the global state is the fixed point (the worklist schedule itself only revisits tiles
+ * whose halo a neighbour's probe saw drop) */
+int mhip_ctx_fill_certify(mhip_ctx *ctx, int kind, int32_t *changed);
 int mhip_ctx_fill_end(mhip_ctx *ctx, int kind);   /* kind 0 also computes the bluespot depths */
 /* accumulation on a band: mhip_ctx_zero_raster(ACCUM) once, then { mhip_ctx_run(ACCUM); swap ACCUM edge rows } until no
  * halo row changes (a halo value <= 0 means "not known yet" and blocks the cells below it). */

@@ -1022,6 +1022,16 @@ int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
     return MHIP_OK;
 }
 
+int mhip_ctx_fill_certify(mhip_ctx *c, int kind, int32_t *changed)
+{
+    MH_ARG(c && changed && (kind == 0 || kind == 1) && c->run[kind], "ctx_fill_certify needs ctx_fill_begin");
+    MH_HIP(hipSetDevice(c->device));
+    bool ch = false;
+    MH_TRY(c->run[kind]->certify(c->stream, &ch));
+    *changed = ch ? 1 : 0;
+    return MHIP_OK;
+}
+
 int mhip_ctx_fill_halo_changed(mhip_ctx *c, int kind, int side)
 {
     MH_ARG(c && (kind == 0 || kind == 1) && c->run[kind] && (side == 0 || side == 1), "ctx_fill_halo_changed needs ctx_fill_begin");

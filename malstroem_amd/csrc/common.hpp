@@ -132,6 +132,7 @@ struct FillRun {
     int begin(hipStream_t s, bool *active);      // initialising round over every tile
     int batch(hipStream_t s, bool *active);      // a batch of rounds; *active == false: locally converged
     int activate_row(int side, hipStream_t s);   // halo row `side` (0 top, 1 bottom) changed: revisit its tile row
+    int certify(hipStream_t s, bool *changed);   // one sweep over EVERY tile, iterated to local convergence; *changed: a tile moved
     int finish(hipStream_t s, FillStats *st);
 };
 void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_t ncells_global);

@@ -296,6 +296,7 @@ template <> struct Inf<double> { static __device__ __forceinline__ double v() { 
 // so the work is balanced while every queue head / append counter only sees 1/NSHARD of the traffic (one shared
 // word saturates at ~90 atomics per microsecond on this chip).  sum(count[k+1][*]) == 0  <=>  converged.
 constexpr int NSHARD = 8;
+constexpr int STAT_CHANGED = 140;   // stats word: visits (after the initialising round) that changed their tile
 #ifndef MH_MAXIT
 #define MH_MAXIT 2
 #endif
@@ -521,7 +522,7 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
     const bool changed = anyAll != 0;
     MH_STAMP(tp2);
     visits += has_tile ? 1 : 0;
-    cycles += ncyc;
+    cycles += ncyc + ((changed & has_tile & !first_round) ? (1u << 20) : 0u);   // bits 20..: visits that changed their tile (certify())
     // ---- stage-out: interior cells that are not raster border cells (those never move)
     if (has_tile && (changed || first_round)) {
         const bool lane_ok = upd & col_in & (cc != 0) & (cc != Wd - 1);
@@ -698,7 +699,8 @@ __global__ __launch_bounds__(256, NOFLAT ? 1 : 2) void fill_round_kernel(RoundAr
     if (lane == 0 && visits) {
         unsigned long long *sh = a.stats + 2 * ((g * 4 + wave) & 63);
         atomicAdd(&sh[0], (unsigned long long)visits);
-        atomicAdd(&sh[1], (unsigned long long)cycles);
+        atomicAdd(&sh[1], (unsigned long long)(cycles & 0xfffffu));
+        if (cycles >> 20) atomicAdd(&a.stats[STAT_CHANGED], (unsigned long long)(cycles >> 20));
 #ifdef MH_PROFILE_VISIT
         unsigned long long *pr = a.stats + 128;
         atomicAdd(&pr[0], (unsigned long long)pf.load); atomicAdd(&pr[1], (unsigned long long)pf.pass);
@@ -724,6 +726,15 @@ __global__ void activate_tile_row_kernel(int ti, int ntc, int shard_cap, int *li
     const int tj = blockIdx.x * blockDim.x + threadIdx.x;
     if (tj >= ntc) return;
     const int t = ti * ntc + tj, sh = t % NSHARD;
+    if (atomicExch(&mark[t], 0xfu) == 0u) list[(size_t)sh * shard_cap + atomicAdd(&count[sh], 1u)] = t;
+}
+
+// marks every macro tile active for the round that is launched next (certify(): one full sweep over the raster)
+__global__ void activate_all_kernel(int nt, int shard_cap, int *list, unsigned int *mark, unsigned int *count)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
+    const int sh = t % NSHARD;
     if (atomicExch(&mark[t], 0xfu) == 0u) list[(size_t)sh * shard_cap + atomicAdd(&count[sh], 1u)] = t;
 }
 
@@ -884,6 +895,29 @@ int FillRun::activate_row(int side, hipStream_t s)
     return MHIP_OK;
 }
 
+// Certification sweep.  The worklist schedule visits a tile again only when a neighbour's probe says its halo would drop; a
+// wake-up lost anywhere (observed: ONE cell of 1.07 G left too high on a 16384 x 65536 raster filled as four concurrent bands)
+// would leave a state that is not a fixed point.  certify() visits EVERY tile once more and iterates to local convergence:
+// a sweep that changes no tile proves the state is a fixed point reached from above, i.e. the reference's result.
+int FillRun::certify(hipStream_t s, bool *changed)
+{
+    Impl &m = *impl;
+    *changed = false;
+    if (m.trivial) return MHIP_OK;
+    unsigned long long c0 = 0, c1 = 0;
+    MH_HIP(hipMemcpyAsync(&c0, m.d_stats + STAT_CHANGED, 8, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(activate_all_kernel, dim3((unsigned)cdiv(m.nt, 256)), dim3(256), 0, s, (int)m.nt, m.shard_cap,
+                       m.lists + (size_t)(m.round & 1) * m.list_elems, m.marks + (size_t)(m.round & 1) * m.nt,
+                       m.count + (size_t)m.round * NSHARD);
+    MH_HIP(hipGetLastError());
+    bool active = true;
+    while (active) MH_TRY(batch(s, &active));
+    MH_HIP(hipMemcpyAsync(&c1, m.d_stats + STAT_CHANGED, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    *changed = c1 != c0;
+    return MHIP_OK;
+}
+
 int FillRun::finish(hipStream_t s, FillStats *st)
 {
     Impl &m = *impl;
@@ -932,6 +966,7 @@ static int fill_run_to_convergence(FillRun &f, hipStream_t s, FillStats *st)
     bool active = false;
     MH_TRY(f.begin(s, &active));
     while (active) MH_TRY(f.batch(s, &active));
+    for (bool changed = true; changed;) MH_TRY(f.certify(s, &changed));   // until a full sweep changes nothing
     return f.finish(s, st);
 }
 

@@ -399,6 +399,12 @@ class HipBand(object):
     def fill_halo_changed(self, kind, side):
         _lib.call("mhip_ctx_fill_halo_changed", self._ctx, int(kind), int(side))
 
+    def fill_certify(self, kind):
+        """one sweep over every tile of the band, iterated to local convergence -> did any tile move?"""
+        changed = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_fill_certify", self._ctx, int(kind), ctypes.byref(changed))
+        return bool(changed.value)
+
     def fill_end(self, kind):
         _lib.call("mhip_ctx_fill_end", self._ctx, int(kind))
 
@@ -572,7 +578,18 @@ class BandPipeline(object):
                 except Exception as e:
                     err = e
             if not self._vote(busy, err):
-                break
+                # every band is quiescent: certify -- one sweep over EVERY tile of every band.  The worklist schedule only
+                # revisits a tile when a neighbour's probe saw its halo drop; a sweep that moves nothing anywhere proves the
+                # state is the global fixed point (and repairs a lost wake-up if there ever was one: the loop resumes)
+                moved = False
+                try:
+                    moved = b.fill_certify(kind)
+                except Exception as e:
+                    err = e
+                if not self._vote(moved, err):
+                    break
+                active = False
+                continue
             try:
                 active = b.fill_batch(kind) if busy else False
             except Exception as e:

@@ -30,6 +30,9 @@ class CpuBand(object):
         if self._comm is not None:
             self._comm.close()
 
+    def fill_certify(self, kind):
+        return False      # the stand-in iterates whole-raster sweeps to a fixed point: nothing to certify
+
     @staticmethod
     def new_unique_id():
         import os

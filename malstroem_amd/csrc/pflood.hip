@@ -646,161 +646,153 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
     if (t < NSMAX) a.Lv[(size_t)tile * NSMAX + t] = EMPTY;
 }
 
-// ---- K3: one round of the seed-graph solve; a wavefront visits a tile -------------------------------------------------
-// Worklist without atomics: one "active" byte per tile, double buffered over the rounds.  Tile -> wavefront is a fixed map
-// (tile = l * nw + gw, l < chunk: a wavefront's bytes are contiguous, the tiles of a moving front spread over all
-// wavefronts); a visit that lowered a seed sets the bytes of the neighbours that hold a link to it with plain stores and
-// raises the round's "somebody appended" word.  Levels are read and written with plain loads / stores: a value written in
-// this round may or may not be seen by a neighbour visited in the same round (it is only ever lower: harmless), and the
-// neighbour is visited again in the next round -- a new launch -- where it is seen for sure.  (Returning atomics on a
-// list head / append counter / mark word and agent-scope atomic loads made a visit ~70 us under load; measured.)
+// ---- K3: one round of the seed-graph solve; a workgroup visits a BLOCK of BT x BT tiles --------------------------------------
+// The levels L of the block's seeds and of the ring of tiles around it (a (BT+2)^2 region), and the block's edges (links and
+// spill edges, as directed relaxations dst <- max(w, src)) sit in LDS; the block iterates to ITS fixed point there, with the
+// ring frozen, and writes its levels back.  Information crosses BT tiles per round (the per-tile version of this kernel
+// needed ~225 rounds at 16384^2 and was bound by the latency of ~25 small dependent global accesses per visit).
+// Worklist without atomics: one "active" byte per block, double buffered over the rounds; a block that lowered a seed with a
+// link into a neighbouring block sets that block's byte for the next round with a plain store and raises the round's
+// "somebody appended" word.  Levels move with plain loads / stores: a value written in this round may or may not be seen by
+// a neighbour visited in the same round (it is only ever lower: harmless), and that neighbour is visited again in the next
+// round -- a new launch -- where it is seen for sure.
+constexpr int BT = 4;                      // tiles per block edge
+constexpr int RT = BT + 2;                 // region edge (block + ring)
+constexpr int EMAX = 6144;                 // directed relaxations held in LDS per block (the rest is streamed from memory)
 struct SolveArgs {
     PfArgs a;
-    uint8_t *act_cur, *act_nxt;
+    uint8_t *act_cur, *act_nxt;            // [nbr * nbc]
     unsigned int *any_nxt;
     unsigned long long *visits;
-    int nw, chunk;   // wavefronts of the launch (fixed over the rounds), tiles per wavefront
-    int first;       // 1: every tile
+    int nbr, nbc;                          // blocks
+    int first;                             // 1: every block
 };
 
-__global__ __launch_bounds__(256) void pf_solve_kernel(SolveArgs sa)
+constexpr int ST = 1024;                  // threads per block visit (the LDS fixed point is barrier bound: more, shorter strides)
+__global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
 {
-    // per wavefront: the levels of the 3 x 3 tiles around the visited one ([4] = its own) and its own levels as loaded
-    __shared__ uint32_t Ls[4][9][NSMAX], Lo[4][NSMAX];
-    __shared__ unsigned int s_dirs[4];
+    __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
+    __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
+    __shared__ unsigned long long E[EMAX];             // 48 KB: dst << 48 | src << 32 | w   (src 0xFFFF = OCEAN)
+    __shared__ int s_wake, s_over;
     const PfArgs &a = sa.a;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t(*Ln)[NSMAX] = Ls[wave];
-    uint32_t *L = Ln[4], *Lold = Lo[wave];
-    const int ntiles = a.ntr * a.ntc;
-    const int gw = blockIdx.x * 4 + wave;
-    if (gw >= sa.nw) return;
-    constexpr int LPL = LMAX / 64, SPL = SPMAX / 64, VPL = NSMAX / 64;   // links / spill edges / levels per lane
-    const size_t slot0 = (size_t)gw * sa.chunk;
-    bool mine = false;
-    if (lane < sa.chunk) {
-        const int tile = lane * sa.nw + gw;
-        mine = tile < ntiles && (sa.first || sa.act_cur[slot0 + lane] != 0);
-        if (mine && !sa.first) sa.act_cur[slot0 + lane] = 0;   // this buffer is appended to again two rounds from now
+    const int t = threadIdx.x;
+    const int blk = blockIdx.x, bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
+    if (!sa.first) {
+        if (sa.act_cur[blk] == 0) return;              // block-uniform
+        __syncthreads();
+        if (t == 0) sa.act_cur[blk] = 0;               // this buffer is appended to again two rounds from now
     }
-    unsigned long long todo = __ballot(mine);
-    unsigned nvis = 0;
-    bool pushed = false;
-    while (todo) {
-        const int l = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int tile = l * sa.nw + gw;
-        ++nvis;
-        const int ti = tile / a.ntc, tj = tile - ti * a.ntc;
-        // ONE batch of loads: the levels of the nine tiles, my links, my spill edges (unused entries are ~0)
-        uint32_t lv[9][VPL];
-#pragma unroll
-        for (int x = 0; x < 9; ++x) {
-            const int p = ti + x / 3 - 1, qq = tj + x % 3 - 1;
-            const bool ok = p >= 0 && p < a.ntr && qq >= 0 && qq < a.ntc;
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) lv[x][k] = ok ? a.Lv[(size_t)(p * a.ntc + qq) * NSMAX + lane + 64 * k] : EMPTY;
-        }
-#ifdef PF_PROFILE
-        const long long k3_t0 = __builtin_amdgcn_s_memtime();
-#endif
-        unsigned long long lk[LPL], sp[SPL];
-#pragma unroll
-        for (int j = 0; j < LPL; ++j) lk[j] = a.links[(size_t)tile * LMAX + lane + 64 * j];
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) sp[j] = a.spill[(size_t)tile * SPMAX + lane + 64 * j];
-#ifdef PF_PROFILE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const long long k3_t1 = __builtin_amdgcn_s_memtime();
-#endif
-        if (lane == 0) s_dirs[wave] = 0u;
-#pragma unroll
-        for (int x = 0; x < 9; ++x)
-#pragma unroll
-            for (int k = 0; k < VPL; ++k) Ln[x][lane + 64 * k] = lv[x][k];
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) Lold[lane + 64 * k] = lv[4][k];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < LPL; ++j)
-            if (lk[j] != ~0ull) {
-                const uint32_t key = (uint32_t)(lk[j] >> 32);
-                const int mylab = (int)(key >> 16), dir = (int)((key >> 8) & 0xffu), nlab = (int)(key & 0xffu);
-                const uint32_t ln = nlab == OCEAN ? 0u : Ln[dir][nlab];
-                atomicMin(&L[mylab], max((uint32_t)lk[j], ln));
-            }
-        __builtin_amdgcn_wave_barrier();
-#ifdef PF_PROFILE
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const long long k3_t2 = __builtin_amdgcn_s_memtime();
-        unsigned k3_it = 0;
-#endif
-        for (int it = 0; it < 2 * NSMAX; ++it) {   // spill edges inside the tile, to a local fixed point
-            bool ch = false;
-#ifdef PF_PROFILE
-            ++k3_it;
-#endif
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) {
-                if (sp[j] == ~0ull) continue;
-                const uint32_t key = (uint32_t)(sp[j] >> 32), w = (uint32_t)sp[j];
-                const int la = (int)(key >> 8), lb = (int)(key & 0xffu);
-                const uint32_t va = la == OCEAN ? 0u : L[la], vb = lb == OCEAN ? 0u : L[lb];
-                const uint32_t ca = max(w, vb), cb = max(w, va);
-                if (la != OCEAN && ca < va) { atomicMin(&L[la], ca); ch = true; }
-                if (lb != OCEAN && cb < vb) { atomicMin(&L[lb], cb); ch = true; }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (!__any(ch)) break;
-        }
-#ifdef PF_PROFILE
-        const long long k3_t3 = __builtin_amdgcn_s_memtime();
-#endif
-        bool changed = false;
-#pragma unroll
-        for (int k = 0; k < VPL; ++k) {
-            const uint32_t v = L[lane + 64 * k];
-            if (v < lv[4][k]) {
-                a.Lv[(size_t)tile * NSMAX + lane + 64 * k] = v;
-                changed = true;
-            }
-        }
-        if (__any(changed)) {
-            // only the neighbours that hold a link to a seed whose level dropped can gain anything
-            unsigned dirs = 0;
-#pragma unroll
-            for (int j = 0; j < LPL; ++j)
-                if (lk[j] != ~0ull) {
-                    const uint32_t key = (uint32_t)(lk[j] >> 32);
-                    const int mylab = (int)(key >> 16);
-                    if (L[mylab] < Lold[mylab]) dirs |= 1u << ((key >> 8) & 0xffu);
-                }
-            if (dirs) atomicOr(&s_dirs[wave], dirs);
-            __builtin_amdgcn_wave_barrier();
-            dirs = s_dirs[wave];
-            if (lane < 9 && ((dirs >> lane) & 1u)) {
-                const int nt = (ti + lane / 3 - 1) * a.ntc + (tj + lane % 3 - 1);
-                sa.act_nxt[(size_t)(nt % sa.nw) * sa.chunk + nt / sa.nw] = 1;
-            }
-            pushed = pushed || dirs != 0;
-        }
-        __builtin_amdgcn_wave_barrier();
-#ifdef PF_PROFILE
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            const long long k3_t4 = __builtin_amdgcn_s_memtime();
-            atomicAdd(&a.prof[19], (unsigned long long)(k3_t1 - k3_t0));
-            atomicAdd(&a.prof[20], (unsigned long long)(k3_t2 - k3_t1));
-            atomicAdd(&a.prof[21], (unsigned long long)(k3_t3 - k3_t2));
-            atomicAdd(&a.prof[22], (unsigned long long)(k3_t4 - k3_t3));
-            atomicAdd(&a.prof[23], (unsigned long long)k3_it);
-        }
-#endif
+    if (t == 0) { s_wake = 0; s_over = 0; }
+    // ---- levels of the region
+    for (int i = t; i < RT * RT * NSMAX; i += ST) {
+        const int rt = i / NSMAX, k = i - rt * NSMAX;
+        const int p = bi * BT + rt / RT - 1, q = bj * BT + rt % RT - 1;
+        const bool ok = p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
+        L[i] = ok ? a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k] : EMPTY;
     }
-    if (lane == 0) {
-        if (pushed) *sa.any_nxt = 1u;
-        if (nvis) atomicAdd(sa.visits, (unsigned long long)nvis);
+    __syncthreads();
+    for (int i = t; i < BT * BT * NSMAX; i += ST) {
+        const int bt = i / NSMAX, k = i - bt * NSMAX;
+        Lold[i] = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
     }
+    // ---- edges of the block's tiles -> directed relaxations in LDS (fixed positions: tile segment + entry, no atomics)
+    __shared__ int s_seg[BT * BT + 1], s_nl[BT * BT];
+    if (t < BT * BT) {
+        const int p = bi * BT + t / BT, q = bj * BT + t % BT;
+        int nl = 0, ns = 0;
+        if (p < a.ntr && q < a.ntc) {
+            nl = a.tileNL[p * a.ntc + q];
+            ns = a.tileNS[p * a.ntc + q];
+        }
+        s_nl[t] = nl;
+        s_seg[t + 1] = nl + 2 * ns;
+    }
+    __syncthreads();
+    if (t == 0) {
+        s_seg[0] = 0;
+        for (int k = 0; k < BT * BT; ++k) s_seg[k + 1] += s_seg[k];
+        if (s_seg[BT * BT] > EMAX) s_over = 1;
+    }
+    __syncthreads();
+    if (s_over) {   // block-uniform; more relaxations than LDS holds (6144 ~ 16 x 380): tell the caller to fall back
+        if (t == 0) atomicOr(a.flags, 1u);
+        return;
+    }
+    const int NE = s_seg[BT * BT];
+    for (int bt = 0; bt < BT * BT; ++bt) {
+        const int p = bi * BT + bt / BT, q = bj * BT + bt % BT;
+        if (p >= a.ntr || q >= a.ntc) continue;        // block-uniform
+        const int tile = p * a.ntc + q;
+        const int nl = s_nl[bt], seg = s_seg[bt], ne = s_seg[bt + 1] - seg;
+        const int base = ((bt / BT + 1) * RT + bt % BT + 1) * NSMAX;     // this tile's levels in L
+        for (int e = t; e < nl; e += ST) {
+            const unsigned long long v = a.links[(size_t)tile * LMAX + e];
+            const uint32_t key = (uint32_t)(v >> 32);
+            const int mylab = (int)(key >> 16), dir = (int)((key >> 8) & 0xffu), nlab = (int)(key & 0xffu);
+            const int src = nlab == OCEAN ? 0xFFFF : ((bt / BT + dir / 3) * RT + bt % BT + dir % 3) * NSMAX + nlab;
+            E[seg + e] = ((unsigned long long)(base + mylab) << 48) | ((unsigned long long)src << 32) | (uint32_t)v;
+        }
+        for (int e = t; e < (ne - nl) / 2; e += ST) {
+            const unsigned long long v = a.spill[(size_t)tile * SPMAX + e];
+            const uint32_t key = (uint32_t)(v >> 32);
+            const int la = (int)(key >> 8), lb = (int)(key & 0xffu);
+            const int ia = la == OCEAN ? 0xFFFF : base + la, ib = lb == OCEAN ? 0xFFFF : base + lb;
+            E[seg + nl + 2 * e] = la != OCEAN ? ((unsigned long long)ia << 48) | ((unsigned long long)ib << 32) | (uint32_t)v : ~0ull;
+            E[seg + nl + 2 * e + 1] = lb != OCEAN ? ((unsigned long long)ib << 48) | ((unsigned long long)ia << 32) | (uint32_t)v : ~0ull;
+        }
+    }
+    __syncthreads();
+    // ---- the block's fixed point
+    for (int it = 0; it < BT * BT * NSMAX; ++it) {
+        bool ch = false;
+        for (int e = t; e < NE; e += ST) {
+            const unsigned long long r = E[e];
+            if (r == ~0ull) continue;
+            const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
+            const uint32_t v = max((uint32_t)r, src == 0xFFFF ? 0u : L[src]);
+            if (v < L[dst]) {
+                atomicMin(&L[dst], v);
+                ch = true;
+            }
+        }
+        if (!__syncthreads_or(ch)) break;
+    }
+    // ---- write back; wake the neighbouring blocks that hold a link to a seed whose level dropped
+    bool moved = false;
+    for (int i = t; i < BT * BT * NSMAX; i += ST) {
+        const int bt = i / NSMAX, k = i - bt * NSMAX;
+        const int p = bi * BT + bt / BT, q = bj * BT + bt % BT;
+        const uint32_t v = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
+        if (v < Lold[i] && p < a.ntr && q < a.ntc) {
+            a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k] = v;
+            moved = true;
+        }
+    }
+    if (__syncthreads_or(moved)) {
+        unsigned wake = 0;
+        for (int e = t; e < NE; e += ST) {
+            const unsigned long long r = E[e];
+            const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
+            if (src == 0xFFFF) continue;                                       // also the ~0 placeholders
+            const int st = src / NSMAX, si = st / RT, sj = st % RT;             // region tile of the source
+            if (si >= 1 && si <= BT && sj >= 1 && sj <= BT) continue;          // inside the block
+            const int dt = dst / NSMAX, di_ = dt / RT - 1, dj_ = dt % RT - 1;   // block-local tile of the destination
+            if (L[dst] < Lold[(di_ * BT + dj_) * NSMAX + dst % NSMAX]) {
+                const int wi = si == 0 ? 0 : (si == RT - 1 ? 2 : 1), wj = sj == 0 ? 0 : (sj == RT - 1 ? 2 : 1);
+                wake |= 1u << (wi * 3 + wj);
+            }
+        }
+        if (wake) atomicOr(&s_wake, (int)wake);
+        __syncthreads();
+        wake = (unsigned)s_wake;
+        if (t < 9 && ((wake >> t) & 1u)) {
+            const int p = bi + t / 3 - 1, q = bj + t % 3 - 1;
+            if (p >= 0 && p < sa.nbr && q >= 0 && q < sa.nbc) sa.act_nxt[p * sa.nbc + q] = 1;
+        }
+        if (t == 0 && wake) *sa.any_nxt = 1u;
+    }
+    if (t == 0) atomicAdd(sa.visits, 1ull);
 }
 
 // ---- K4: final level of every basin, then the raster ---------------------------------------------------------------------
@@ -817,6 +809,8 @@ __global__ __launch_bounds__(256) void pf_final_kernel(PfArgs a)
 
 __global__ __launch_bounds__(256) void pf_apply_kernel(PfArgs a, float *__restrict__ filled, float *__restrict__ depths)
 {
+    // four cells per lane: one 16-byte load of the DEM, one 8-byte load of the basin slots, 16-byte stores (4-byte stores
+    // cost 3.5x the bytes in write traffic here: partial lines).  Rows whose width is not a multiple of 4 take the scalar tail.
     const int64_t W = a.W, H = a.H;
     const int64_t groups = (W + 3) / 4;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -824,20 +818,44 @@ __global__ __launch_bounds__(256) void pf_apply_kernel(PfArgs a, float *__restri
     const int64_t r = g / groups, c4 = (g - r * groups) * 4;
     const bool rowb = r == 0 || r == H - 1;
     const int ti = (int)((r - 1) / TI);
+    const int64_t i0 = r * W + c4;
+    const bool vec = (W & 3) == 0;     // then every group is whole and 16-byte aligned
+    float d[4];
+    uint16_t sl[4];
+    if (vec) {
+        const float4 dv = *reinterpret_cast<const float4 *>(a.dem + i0);
+        const ushort4 sv = *reinterpret_cast<const ushort4 *>(a.bslot + i0);
+        d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+        sl[0] = sv.x; sl[1] = sv.y; sl[2] = sv.z; sl[3] = sv.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool in = c4 + k < W;
+            d[k] = in ? a.dem[i0 + k] : 0.0f;
+            sl[k] = in ? a.bslot[i0 + k] : (uint16_t)0;
+        }
+    }
+    float f[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t c = c4 + k;
-        if (c >= W) break;
-        const int64_t i = r * W + c;
-        const float d = a.dem[i];
-        float f = d;
-        if (!(rowb || c == 0 || c == W - 1)) {
+        f[k] = d[k];
+        if (!(rowb || c == 0 || c >= W - 1)) {
             const int tj = (int)((c - 1) / TI);
-            const uint32_t lev = a.tabV[(size_t)(ti * a.ntc + tj) * NBMAX + a.bslot[i]];
-            f = key_f32(max(dem_key(d), lev));
+            const uint32_t lev = a.tabV[(size_t)(ti * a.ntc + tj) * NBMAX + sl[k]];
+            f[k] = key_f32(max(dem_key(d[k]), lev));
         }
-        filled[i] = f;
-        if (depths) depths[i] = f - d;
+    }
+    if (vec) {
+        *reinterpret_cast<float4 *>(filled + i0) = make_float4(f[0], f[1], f[2], f[3]);
+        if (depths) *reinterpret_cast<float4 *>(depths + i0) = make_float4(f[0] - d[0], f[1] - d[1], f[2] - d[2], f[3] - d[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c4 + k < W) {
+                filled[i0 + k] = f[k];
+                if (depths) depths[i0 + k] = f[k] - d[k];
+            }
     }
 }
 
@@ -864,14 +882,9 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     const size_t o_links = off; off = al(off + (size_t)ntiles * LMAX * 8);
     const size_t o_nl = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_lv = off; off = al(off + (size_t)ntiles * NSMAX * 4);
-    // solve worklist: nw wavefronts (every resident slot of the chip, fewer on small rasters), chunk tiles each (<= 64)
-    int nw = (int)(ntiles < 8192 ? ntiles : 8192);
-    int chunk = (int)cdiv(ntiles, nw);
-    if (chunk > 64) {
-        chunk = 64;
-        nw = (int)cdiv(ntiles, 64);
-    }
-    const size_t nslots = (size_t)nw * chunk;
+    // solve worklist: one active byte per block of BT x BT tiles, double buffered
+    const int nbr = (int)cdiv(ntr, BT), nbc = (int)cdiv(ntc, BT);
+    const size_t nslots = (size_t)nbr * nbc;
     const size_t o_act = off; off = al(off + nslots * 2);
     const size_t o_cnt = off; off = al(off + (size_t)(MAXR + 2) * 4 + 64 + 32 * 8);
     DevBuf ws;
@@ -901,7 +914,6 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
     MH_HIP(hipGetLastError());
     int launches = 2, round = 0;
-    const unsigned grid = (unsigned)cdiv(nw, 4);
     auto launch_round = [&](int r) {
         SolveArgs sa;
         sa.a = a;
@@ -909,10 +921,10 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
         sa.act_nxt = act + (size_t)((r + 1) & 1) * nslots;
         sa.any_nxt = any + r + 1;
         sa.visits = visits;
-        sa.nw = nw;
-        sa.chunk = chunk;
+        sa.nbr = nbr;
+        sa.nbc = nbc;
         sa.first = r == 0;
-        hipLaunchKernelGGL(pf_solve_kernel, dim3(grid), dim3(256), 0, s, sa);
+        hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)nslots), dim3(ST), 0, s, sa);
     };
     constexpr int BATCH = 32;
     std::vector<unsigned int> h_cnt(BATCH + 1);

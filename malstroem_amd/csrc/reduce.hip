@@ -134,9 +134,9 @@ int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s)
     hipEvent_t e0, e1;
     MH_HIP(hipEventCreate(&e0));
     MH_HIP(hipEventCreate(&e1));
-    hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, s, a.as<v4f>(), b.as<v4f>(), n);   // warm-up
+    hipLaunchKernelGGL(copy16_kernel, dim3(256 * 32), dim3(256), 0, s, a.as<v4f>(), b.as<v4f>(), n);   // warm-up
     MH_HIP(hipEventRecord(e0, s));
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, s, a.as<v4f>(), b.as<v4f>(), n);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 32), dim3(256), 0, s, a.as<v4f>(), b.as<v4f>(), n);
     MH_HIP(hipEventRecord(e1, s));
     MH_HIP(hipStreamSynchronize(s));
     float ms = 0;

@@ -895,26 +895,69 @@ int FillRun::activate_row(int side, hipStream_t s)
     return MHIP_OK;
 }
 
-// Certification sweep.  The worklist schedule visits a tile again only when a neighbour's probe says its halo would drop; a
-// wake-up lost anywhere (observed: ONE cell of 1.07 G left too high on a 16384 x 65536 raster filled as four concurrent bands)
-// would leave a state that is not a fixed point.  certify() visits EVERY tile once more and iterates to local convergence:
-// a sweep that changes no tile proves the state is a fixed point reached from above, i.e. the reference's result.
+// Certification.  The worklist schedule visits a tile again only when a neighbour's probe says its halo would drop; a wake-up
+// lost anywhere (observed: ONE cell of 1.07 G left too high on a 16384 x 65536 raster filled as four concurrent bands) would
+// leave a state that is not a fixed point.  certify() streams over the raster once (a 3 x 3 stencil: 8 / 12 bytes per cell)
+// and queues the tile of every cell that could still drop -- W[c] > max(dtm[c], candidate from its neighbours) -- then runs
+// the schedule to local convergence again.  No such cell anywhere proves the state is a fixed point reached from above,
+// i.e. the reference's result.
+namespace {
+template <typename WT, bool NOFLAT>
+__global__ __launch_bounds__(256) void verify_kernel(const float *__restrict__ dem, const WT *__restrict__ W, int64_t H, int64_t Wd, double sh,
+                                                     double dg, int fixed_top, int fixed_bot, int mt, int mtc, int shard_cap, int *list,
+                                                     unsigned int *mark, unsigned int *count)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.y + 1;
+    if (c < 1 || c >= Wd - 1 || r >= H - 1) return;   // interior cells only (band halo rows are local rows 0 / H-1: never updated here)
+    (void)fixed_top;
+    (void)fixed_bot;
+    auto at = [&](int64_t rr, int64_t cc) -> WT {
+        const WT v = W[rr * Wd + cc];
+        return is_nan_bits(v) ? Inf<WT>::v() : v;        // a NaN neighbour never wins a minimum (bit test: -fno-honor-nans)
+    };
+    const WT own = W[r * Wd + c];
+    const float dv = dem[r * Wd + c];
+    if (is_nan_bits(own) || is_nan_bits(dv)) return;      // NaN cells never move
+    const WT me = fmin(fmin(at(r - 1, c), at(r + 1, c)), fmin(at(r, c - 1), at(r, c + 1)));
+    const WT md = fmin(fmin(at(r - 1, c - 1), at(r - 1, c + 1)), fmin(at(r + 1, c - 1), at(r + 1, c + 1)));
+    WT cand;
+    if constexpr (NOFLAT) cand = fmin(__dadd_rn((double)md, dg), __dadd_rn((double)me, sh));
+    else cand = fmin(md, me);
+    if (own > fmax((WT)dv, cand)) {                      // the cell would still drop: queue its tile
+        const int ti = (int)((r - 1) / TI), tj = (int)((c - 1) / TI);
+        const int t = (ti / mt) * mtc + tj / mt, shd = t % NSHARD;
+        const unsigned bit = mt == 2 ? 1u << ((ti & 1) * 2 + (tj & 1)) : 1u;
+        if (atomicOr(&mark[t], bit) == 0u) list[(size_t)shd * shard_cap + atomicAdd(&count[shd], 1u)] = t;
+    }
+}
+}  // namespace
+
 int FillRun::certify(hipStream_t s, bool *changed)
 {
     Impl &m = *impl;
     *changed = false;
     if (m.trivial) return MHIP_OK;
-    unsigned long long c0 = 0, c1 = 0;
-    MH_HIP(hipMemcpyAsync(&c0, m.d_stats + STAT_CHANGED, 8, hipMemcpyDeviceToHost, s));
-    hipLaunchKernelGGL(activate_all_kernel, dim3((unsigned)cdiv(m.nt, 256)), dim3(256), 0, s, (int)m.nt, m.shard_cap,
-                       m.lists + (size_t)(m.round & 1) * m.list_elems, m.marks + (size_t)(m.round & 1) * m.nt,
-                       m.count + (size_t)m.round * NSHARD);
+    const dim3 grid((unsigned)cdiv(W, 256), (unsigned)(H - 2));
+    int *list = m.lists + (size_t)(m.round & 1) * m.list_elems;
+    unsigned int *mark = m.marks + (size_t)(m.round & 1) * m.nt, *cnt = m.count + (size_t)m.round * NSHARD;
+    const int mt = noflat ? 1 : 2;
+    if (noflat)
+        hipLaunchKernelGGL((verify_kernel<double, true>), grid, dim3(256), 0, s, dem, reinterpret_cast<const double *>(out), H, W, sh, dg, fixed_top,
+                           fixed_bot, mt, m.mtc, m.shard_cap, list, mark, cnt);
+    else
+        hipLaunchKernelGGL((verify_kernel<float, false>), grid, dim3(256), 0, s, dem, reinterpret_cast<const float *>(out), H, W, sh, dg, fixed_top,
+                           fixed_bot, mt, m.mtc, m.shard_cap, list, mark, cnt);
     MH_HIP(hipGetLastError());
+    unsigned int h_cnt[NSHARD];
+    MH_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    unsigned int queued = 0;
+    for (int k = 0; k < NSHARD; ++k) queued += h_cnt[k];
+    if (!queued) return MHIP_OK;
+    *changed = true;
     bool active = true;
     while (active) MH_TRY(batch(s, &active));
-    MH_HIP(hipMemcpyAsync(&c1, m.d_stats + STAT_CHANGED, 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
-    *changed = c1 != c0;
     return MHIP_OK;
 }
 

@@ -359,62 +359,77 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
         const bool below = wr0 + CPT < WN;
         const uint16_t s_dn = below ? ptr[(wr0 + CPT) * WN + wc] : NONE;
         const uint32_t z_dn = below ? zk[(wr0 + CPT) * WN + wc] : KINV;
-        uint32_t lastk[4] = {EMPTY, EMPTY, EMPTY, EMPTY}, lastw[4] = {0, 0, 0, 0};
+        // LDS atomics are the expensive instruction here (several cycles per active lane, more when lanes share a slot): a
+        // thread first folds its 4 * CPT candidates into a register set of distinct pairs (adjacent cells mostly straddle the
+        // same two basins) and only the set goes to the hash; a candidate that finds the set full goes there directly
+        constexpr int NCK = 6;
+        uint32_t ck[NCK], cw[NCK];
+#pragma unroll
+        for (int j = 0; j < NCK; ++j) { ck[j] = EMPTY; cw[j] = EMPTY; }
 #ifdef PF_PROFILE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const long long pf_s5a = __builtin_amdgcn_s_memtime();
         unsigned pf_ncand = 0, pf_nlive = 0, pf_nslow = 0;
 #endif
+        auto hash_insert = [&](uint32_t key, uint32_t w) {
+            unsigned hh = (key * 2654435761u) >> 21;
+            for (int probe = 0; probe < 64; ++probe) {
+                const uint32_t pv = atomicCAS(&hk[hh], EMPTY, key);
+                if (pv == EMPTY || pv == key) {
+                    atomicMin(&hv[hh], w);
+                    return true;
+                }
+                hh = (hh + 1) & (HE - 1);
+            }
+            return false;
+        };
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const uint32_t sa = myslot[k], own = myz[k];
             const uint16_t nb[4] = {sr[k], sl[k + 1], k + 1 < CPT ? myslot[k + 1] : s_dn, sr[k + 1]};
             const uint32_t nz[4] = {zr[k], zl[k + 1], k + 1 < CPT ? myz[k + 1] : z_dn, zr[k + 1]};
-            uint32_t key[4], w[4], prev[4];
-            unsigned h[4];
-            bool live[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const uint32_t sb = nb[d];
                 const bool cand = sa != NONE && sb != NONE && sb != sa;
-                key[d] = cand ? (sa < sb ? (sa << 10 | sb) : (sb << 10 | sa)) : EMPTY;
-                w[d] = max(own, nz[d]);
-                // the lane to the left (all lanes execute the shifts: no divergence around them)
-                const uint32_t lkey = (uint32_t)__builtin_amdgcn_update_dpp((int)EMPTY, (int)key[d], 0x138, 0xf, 0xf, false);
-                const uint32_t lw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[d], 0x138, 0xf, 0xf, false);
-                live[d] = cand && !(key[d] == lastk[d] && w[d] >= lastw[d]) && !(key[d] == lkey && w[d] >= lw);
+                const uint32_t key = cand ? (sa < sb ? (sa << 10 | sb) : (sb << 10 | sa)) : EMPTY;
+                const uint32_t w = max(own, nz[d]);
+                bool placed = !cand;
+#pragma unroll
+                for (int j = 0; j < NCK; ++j) {
+                    const bool hit = !placed && (ck[j] == key || ck[j] == EMPTY);
+                    cw[j] = hit ? min(cw[j], w) : cw[j];
+                    ck[j] = hit ? key : ck[j];
+                    placed = placed || hit;
+                }
 #ifdef PF_PROFILE
-                pf_ncand += cand; pf_nlive += live[d];
+                pf_ncand += cand;
 #endif
-                if (cand) { lastk[d] = key[d]; lastw[d] = w[d]; }
-                h[d] = (key[d] * 2654435761u) >> 21;
-                prev[d] = EMPTY;
+                if (!placed) {   // set full (rare)
+#ifdef PF_PROFILE
+                    ++pf_nslow;
+#endif
+                    if (!hash_insert(key, w)) overflow = true;
+                }
+            }
+        }
+        {
+            uint32_t prev[NCK];
+            unsigned h[NCK];
+#pragma unroll
+            for (int j = 0; j < NCK; ++j) {
+                h[j] = (ck[j] * 2654435761u) >> 21;
+                prev[j] = EMPTY;
+                if (ck[j] != EMPTY) prev[j] = atomicCAS(&hk[h[j]], EMPTY, ck[j]);
             }
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (live[d]) prev[d] = atomicCAS(&hk[h[d]], EMPTY, key[d]);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if (!live[d]) continue;
-                if (prev[d] == EMPTY || prev[d] == key[d]) {
-                    atomicMin(&hv[h[d]], w[d]);
-                    continue;
-                }
-                bool done = false;   // collision: linear probing
+            for (int j = 0; j < NCK; ++j) {
+                if (ck[j] == EMPTY) continue;
 #ifdef PF_PROFILE
-                ++pf_nslow;
+                ++pf_nlive;
 #endif
-                unsigned hh = (h[d] + 1) & (HE - 1);
-                for (int probe = 0; probe < 64; ++probe) {
-                    const uint32_t pv = atomicCAS(&hk[hh], EMPTY, key[d]);
-                    if (pv == EMPTY || pv == key[d]) {
-                        atomicMin(&hv[hh], w[d]);
-                        done = true;
-                        break;
-                    }
-                    hh = (hh + 1) & (HE - 1);
-                }
-                if (!done) overflow = true;
+                if (prev[j] == EMPTY || prev[j] == ck[j]) atomicMin(&hv[h[j]], cw[j]);
+                else if (!hash_insert(ck[j], cw[j])) overflow = true;
             }
         }
 #ifdef PF_PROFILE

@@ -194,6 +194,14 @@ int mhip_ctx_fill_end(mhip_ctx *ctx, int kind);   /* kind 0 also computes the bl
 /* accumulation on a band: mhip_ctx_zero_raster(ACCUM) once, then { mhip_ctx_run(ACCUM); swap ACCUM edge rows } until no
  * halo row changes (a halo value <= 0 means "not known yet" and blocks the cells below it). */
 int mhip_ctx_zero_raster(mhip_ctx *ctx, int which);
+/* ... or without iterating (two local passes + one all-gather of edge rows, however often a river crosses the seams):
+ * the boundary pass accumulates with the halo rows as sources of NO flux (ACCUM = the band's own contribution A0) and
+ * reports, for each halo cell k (top halo row: k = column, bottom halo row: k = W + column), exit_map[k] = side * W + column
+ * of the cell of the first (side 0) / last (side 1) owned row through which the flux of k leaves the band again, or -1 when
+ * it stays inside.  Every EXIT cell e then satisfies  x[e] = A0[e] + sum of x[neighbour's edge cell under k] over the halo
+ * cells k with exit_map[k] = e  -- a forest over all bands' edge cells that the launcher solves on the host; it writes the
+ * solved values into the ACCUM halo rows and runs mhip_ctx_run(ACCUM) once (reference: the same sums as _flow.pyx:212-247). */
+int mhip_ctx_band_accum_boundary(mhip_ctx *ctx, int32_t *exit_map /* 2 * W, host */);
 /* labelling on a band: local components -> host merges the boundary equivalences of all bands -> global LUT */
 int mhip_ctx_band_ccl_local(mhip_ctx *ctx, int64_t *nlocal);
 int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int64_t nlabels_global);

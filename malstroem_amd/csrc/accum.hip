@@ -79,6 +79,9 @@ struct Nodes {           // global perimeter-node arrays, index = tile * NODE_ST
     int32_t *dst;        // per EXIT cell: node index of the entry cell it flows into
     uint16_t *exit_of;   // per ENTRY cell: slot of the exit of its tile-local path (NO_EXIT: ends inside / leaves raster)
     uint8_t *flags;
+    int32_t *halo_first;  // band mode, boundary pass only (else nullptr): per halo cell (top row: [0, W), bottom row: [W, 2W))
+                          // where its path goes in its first tile, see accum_tile_kernel
+    int32_t *bexit;       // ... and per entry node: side * W + column of the cell from which its tile-local path flows into a halo row
 };
 
 #ifdef MH_PROFILE_ACCUM   // development aid: per-phase ticks of thread 0 of every block
@@ -94,7 +97,7 @@ template <bool FINAL>
 // final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
 // they never receive and are never written here.
 __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
-                                                        int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot)
+                                                        int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot, int halo_zero)
 {
     auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
     __shared__ uint64_t S[AT * AT];
@@ -171,8 +174,10 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         uint64_t v = inside ? 1ull : TAINT;   // not a raster cell: nothing flows into it (its neighbours see NODIR... it has none)
         const bool halo = inside && halo_row(r0 + r);
         if (halo) {  // the neighbouring band's cell: known (> 0) = a source of that much flux, else it blocks its path
-            const double ext = out[(r0 + r) * W + c0 + c];
-            v = ext > 0.0 ? (uint64_t)ext : TAINT;
+            // boundary pass of the band protocol (halo_zero): a known source of NO flux -- the local sums then are the band's own
+            // contribution, and the halo cell's path is traced to where it leaves the band (accum_band_exit_kernel)
+            const double ext = halo_zero ? 0.0 : out[(r0 + r) * W + c0 + c];
+            v = halo_zero ? 0ull : (ext > 0.0 ? (uint64_t)ext : TAINT);
             deg_ext = 0;
         }
         if (FINAL && deg_ext && inside) {
@@ -247,6 +252,36 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         return;
     }
 
+    // boundary pass: where does the path of every halo cell of this tile go?  -1: it ends inside the band (or never enters it),
+    // <= -2: it leaves the band again from the cell  -2 - value = side * W + column,  >= 0: it leaves the tile through that node
+    auto band_side = [&](int64_t gr) { return (fixed_top && gr == 0) ? (int64_t)0 : W; };
+    if (nd.halo_first) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int i = tid + 256 * j;
+            const int r = i / AT, c = i - r * AT;
+            if (!((r0 + r) < H && (c0 + c) < W && halo_row(r0 + r))) continue;
+            const uint64_t s = S[i];
+            int32_t first = -1;
+            const unsigned own = win[(r + 1) * FS + c + WOFF];
+            const bool enters = own <= 7u && dir_dr((int)own) != 0 && (r0 + r + dir_dr((int)own)) >= 0 && (r0 + r + dir_dr((int)own)) < H &&
+                                (c0 + c + dir_dc((int)own)) >= 0 && (c0 + c + dir_dc((int)own)) < W && !halo_row(r0 + r + dir_dr((int)own));
+            if (enters && ((s >> A_SHIFT) & A_MASK) == SENT13) {
+                const int last = (int)((s >> R_SHIFT) & R_MASK);
+                const int pr = last / AT, pc = last - pr * AT;
+                const unsigned cd = win[(pr + 1) * FS + pc + WOFF];
+                if (cd <= 7u) {
+                    const int nr = pr + dir_dr((int)cd), nc = pc + dir_dc((int)cd);
+                    const int64_t gr = r0 + nr, gc = c0 + nc;
+                    const bool in_raster = gr >= 0 && gr < H && gc >= 0 && gc < W;
+                    const bool out_of_tile = nr < 0 || nr >= AT || nc < 0 || nc >= AT;
+                    if (in_raster && last != i && halo_row(gr)) first = (int32_t)(-2 - (band_side(gr) + c0 + pc));
+                    else if (in_raster && out_of_tile) first = tile * NODE_STRIDE + perim_slot(pr, pc);
+                }
+            }
+            nd.halo_first[band_side(r0 + r) + c0 + c] = first;
+        }
+    }
     // phase 1: publish the perimeter
     if (tid < PERIM) {
         int r, c;
@@ -277,6 +312,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             }
         }
         uint16_t ex = NO_EXIT;
+        int32_t bex = -1;      // band mode: my path ends by flowing into a halo row from this cell of the first / last owned row
         if (entry) {
             fl |= F_ENTRY;
             // the last in-tile cell of my path (doubling above); the path leaves through it iff that cell flows into a
@@ -290,9 +326,11 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
                     const int nr = pr + dir_dr((int)cd), nc = pc + dir_dc((int)cd);
                     const int64_t gr = r0 + nr, gc = c0 + nc;
                     if ((nr < 0 || nr >= AT || nc < 0 || nc >= AT) && gr >= 0 && gr < H && gc >= 0 && gc < W) ex = (uint16_t)perim_slot(pr, pc);
+                    if (gr >= 0 && gr < H && gc >= 0 && gc < W && halo_row(gr)) bex = (int32_t)(band_side(gr) + c0 + pc);
                 }
             }
         }
+        if (nd.bexit) nd.bexit[node] = bex;
         nd.flags[node] = fl;
         nd.dst[node] = dst;
         nd.exit_of[node] = ex;
@@ -348,7 +386,42 @@ __global__ __launch_bounds__(256) void accum_graph_walk_kernel(Nodes nd, int64_t
 
 }  // namespace
 
-int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot)
+namespace {
+// Band protocol, boundary pass: follow every halo cell's path over the perimeter graph to the cell where it leaves the band
+// again.  exit_map[k] (k as in Nodes::halo_first) = side * W + column of that EXIT cell (side 0: first owned row, 1: last owned
+// row), or -1 when the flux of the halo cell stays inside the band (sink, raster border, flow cycle).
+__global__ __launch_bounds__(256) void accum_band_exit_kernel(Nodes nd, int64_t H, int64_t W, int ntc, int64_t ntiles, int fixed_top, int fixed_bot,
+                                                             int32_t *exit_map)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * W) return;
+    int32_t res = -1;
+    const bool present = k < W ? fixed_top != 0 : fixed_bot != 0;
+    int32_t x = present ? nd.halo_first[k] : -1;
+    if (x <= -2) res = -2 - x;
+    for (int64_t step = 0; x >= 0 && step < 4 * ntiles + 4; ++step) {     // x: an F_EXIT node; longer than every simple path = a flow cycle
+        const int32_t d = nd.dst[x];
+        int dr_, dc_, xr, xc;
+        perim_cell(d % NODE_STRIDE, dr_, dc_);
+        const int64_t dgr = (int64_t)((d / NODE_STRIDE) / ntc) * AT + dr_;
+        if ((fixed_top && dgr == 0) || (fixed_bot && dgr == H - 1)) {     // x flows into a halo row (x is an owned cell: halo -> halo never gets here)
+            perim_cell(x % NODE_STRIDE, xr, xc);
+            res = (int32_t)((dgr == 0 && fixed_top ? 0 : W) + (int64_t)((x / NODE_STRIDE) % ntc) * AT + xc);
+            break;
+        }
+        const uint16_t ex = nd.exit_of[d];
+        if (ex == NO_EXIT) {
+            res = nd.bexit[d];
+            break;
+        }
+        x = (d / NODE_STRIDE) * NODE_STRIDE + ex;
+    }
+    exit_map[k] = res;
+}
+}  // namespace
+
+int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot, int halo_zero,
+              int32_t *d_exit_map)
 {
     const int ntr = (int)cdiv(H, AT), ntc = (int)cdiv(W, AT);
     const int64_t ntiles = (int64_t)ntr * ntc, nnodes = ntiles * NODE_STRIDE;
@@ -361,7 +434,9 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     const size_t o_gstate = 0, o_inflow = align(o_gstate + 8 * (size_t)nnodes), o_arrived = align(o_inflow + 8 * (size_t)nnodes);
     const size_t o_next = align(o_arrived + 4 * (size_t)nnodes), o_dst = align(o_next + 4 * (size_t)nnodes);
     const size_t o_exit = align(o_dst + 4 * (size_t)nnodes), o_flags = align(o_exit + 2 * (size_t)nnodes);
-    MH_TRY(buf.alloc(o_flags + (size_t)nnodes));
+    const size_t o_halo = align(o_flags + (size_t)nnodes);
+    const size_t o_bexit = align(o_halo + (d_exit_map ? 8 * (size_t)W : 0));
+    MH_TRY(buf.alloc(o_bexit + (d_exit_map ? 4 * (size_t)nnodes : 0)));
     char *b = buf.as<char>();
     Nodes nd;
     nd.gstate = reinterpret_cast<uint64_t *>(b + o_gstate);
@@ -371,12 +446,17 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     nd.dst = reinterpret_cast<int32_t *>(b + o_dst);
     nd.exit_of = reinterpret_cast<uint16_t *>(b + o_exit);
     nd.flags = reinterpret_cast<uint8_t *>(b + o_flags);
+    nd.halo_first = d_exit_map ? reinterpret_cast<int32_t *>(b + o_halo) : nullptr;
+    nd.bexit = d_exit_map ? reinterpret_cast<int32_t *>(b + o_bexit) : nullptr;
+    if (d_exit_map) MH_HIP(hipMemsetAsync(nd.halo_first, 0xff, 8 * (size_t)W, s));
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
-    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot);
+    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     hipLaunchKernelGGL(accum_link_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
+    if (d_exit_map)
+        hipLaunchKernelGGL(accum_band_exit_kernel, dim3((unsigned)cdiv(2 * W, 256)), dim3(256), 0, s, nd, H, W, ntc, ntiles, fixed_top, fixed_bot, d_exit_map);
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
-    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot);
+    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
 #ifdef MH_PROFILE_ACCUM

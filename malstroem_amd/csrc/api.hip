@@ -773,6 +773,22 @@ int mhip_ctx_zero_raster(mhip_ctx *c, int which)
     return MHIP_OK;
 }
 
+/* accumulation on a band, boundary pass: the band's OWN contribution (halo rows = sources of no flux) into ACCUM, and for
+ * every halo cell the cell of the first / last owned row through which its flux leaves the band again (see accum.hip) */
+int mhip_ctx_band_accum_boundary(mhip_ctx *c, int32_t *exit_map)
+{
+    MH_ARG(c && exit_map && c->have[MHIP_R_FLOWDIR], "ctx_band_accum_boundary(ctx, exit_map[2 * W]) needs flow directions");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
+    DevBuf d_map;
+    MH_TRY(d_map.alloc(8 * (size_t)c->W));
+    MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, cs(c), c->ht, c->hb, 1,
+                     d_map.as<int32_t>()));
+    MH_HIP(hipMemcpyAsync(exit_map, d_map.p, 8 * (size_t)c->W, hipMemcpyDeviceToHost, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
+    return MHIP_OK;
+}
+
 /* connected components of the band's LOCAL raster (owned + halo rows) in a band-local label space 1..nlocal */
 int mhip_ctx_band_ccl_local(mhip_ctx *c, int64_t *nlocal)
 {

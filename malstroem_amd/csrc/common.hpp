@@ -163,7 +163,8 @@ int comm_exchange_rows(void *comm, int rank, int nranks, const void *first_row, 
                        hipStream_t s);
 int comm_allreduce_max(void *comm, double *d_value, hipStream_t s);
 // accum.hip
-int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0);
+int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0, int halo_zero = 0,
+              int32_t *d_exit_map = nullptr);
 // ccl.hip   (d_tmp: H*W int32 scratch)
 int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
                  hipStream_t s);

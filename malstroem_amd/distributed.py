@@ -419,6 +419,13 @@ class HipBand(object):
         _lib.call("mhip_ctx_run", self._ctx, STAGE_ACCUM)
         _lib.call("mhip_ctx_sync", self._ctx)
 
+    def accum_boundary(self):
+        """Boundary pass of the band accumulation (``mhip_ctx_band_accum_boundary``): ACCUM = the band's own contribution;
+        returns exit_map[2 * W] (halo cell -> side * W + column of the edge cell its flux leaves the band from, or -1)."""
+        out = np.empty(2 * self.W, dtype=np.int32)
+        _lib.call("mhip_ctx_band_accum_boundary", self._ctx, _lib.ptr(out))
+        return out
+
     def ccl_local(self):
         n = ctypes.c_int64(0)
         _lib.call("mhip_ctx_band_ccl_local", self._ctx, ctypes.byref(n))
@@ -484,6 +491,43 @@ class HipBand(object):
 
 
 # ---- the protocol ---------------------------------------------------------------------------------------------------
+
+def solve_band_accum(info, W):
+    """The seam system of the band accumulation.  ``info[b]`` = dict(a0=(first owned row, last owned row) of band b's own
+    contribution, exit=exit_map of ``mhip_ctx_band_accum_boundary``).  Node (b, s, c) = cell c of band b's first (s = 0) /
+    last (s = 1) row AS SEEN BY the neighbour on that side.  exit[k] = e for the halo cell k of band b makes the neighbour's
+    node under k a child of node (b, e): its whole flux arrives at e.  Leaves first (Kahn), vectorised per level; a node
+    whose own contribution is 0 (a flow cycle upstream, _flow.pyx:212-247 leaves such cells 0) or that has an unknown child
+    stays unknown = 0.  Returns per band (top halo row, bottom halo row) of known accumulations, 0 = unknown."""
+    R = len(info)
+    N = R * 2 * W
+    val = np.concatenate([np.asarray(r, dtype=np.float64) for i in info for r in i["a0"]])
+    parent = np.full(N, -1, dtype=np.int64)
+    cols = np.arange(W)
+    for b in range(R):
+        ex = np.asarray(info[b]["exit"], dtype=np.int64)
+        if b > 0:           # my top halo row = the last row of band b - 1
+            m = ex[:W] >= 0
+            parent[((b - 1) * 2 + 1) * W + cols[m]] = b * 2 * W + ex[:W][m]
+        if b < R - 1:       # my bottom halo row = the first row of band b + 1
+            m = ex[W:] >= 0
+            parent[((b + 1) * 2) * W + cols[m]] = b * 2 * W + ex[W:][m]
+    ok = val > 0
+    nchild = np.bincount(parent[parent >= 0], minlength=N)
+    final = np.zeros(N, dtype=bool)
+    frontier = np.flatnonzero(ok & (nchild == 0))
+    while frontier.size:
+        final[frontier] = True
+        p = parent[frontier]
+        m = p >= 0
+        np.add.at(val, p[m], val[frontier[m]])
+        np.subtract.at(nchild, p[m], 1)
+        cand = np.unique(p[m])
+        frontier = cand[(nchild[cand] == 0) & ok[cand]]
+    val[~final] = 0.0
+    val = val.reshape(R, 2, W)
+    return [(val[b - 1, 1] if b > 0 else None, val[b + 1, 0] if b < R - 1 else None) for b in range(R)]
+
 
 class BandPipeline(object):
     """One rank's share of a row-banded DEM.  Every rank calls the same methods in the same order (SPMD)."""
@@ -622,21 +666,32 @@ class BandPipeline(object):
         self._swap_edges("flowdir")
 
     def accum(self):
-        """flow.accumulated_flow over all bands: local accumulation with the neighbours' edge values as sources, repeated
-        until no halo row changes (one iteration per band crossing of the longest flow path)."""
-        b = self.band
-        b.zero_raster("accum")
+        """flow.accumulated_flow over all bands in two local passes and one all-gather, however often the rivers cross the
+        seams.  Pass 1 (``accum_boundary``) accumulates every band's OWN cells and finds, for each cell of a neighbour's edge
+        row that flows into the band, the edge cell through which that flux leaves the band again; with it the values of all
+        seam-crossing cells form a forest  x[e] = own[e] + sum(x[k] for the k that leave through e)  which every rank solves
+        identically (``solve_band_accum``); pass 2 is the local accumulation with the solved halo rows as known sources."""
+        b, W = self.band, self.W
         self.exchanges["accum"] = 0
-        while True:
-            err, ch_top, ch_bot = None, False, False
-            try:
-                b.run_accum()
-                ch_top, ch_bot = self._swap_edges("accum")
-                self.exchanges["accum"] += 1
-            except Exception as e:
-                err = e
-            if not self._vote(ch_top or ch_bot, err):
-                break
+        err, info = None, None
+        try:
+            exit_map = b.accum_boundary()
+            info = dict(a0=(b.get_edge_row("accum", 0), b.get_edge_row("accum", 1)), exit=exit_map)
+        except Exception as e:
+            err = e
+        self._vote(False, err)
+        allinfo = self._cur_comm().allgather(info)
+        self.exchanges["accum"] += 1
+        try:
+            top, bot = solve_band_accum(allinfo, W)[self.comm.rank]
+            if self.has_up:
+                b.set_halo_row("accum", 0, top)
+            if self.has_down:
+                b.set_halo_row("accum", 1, bot)
+            b.run_accum()
+        except Exception as e:
+            err = e
+        self._vote(False, err)
 
     def label(self):
         """label.connected_components over all bands with scipy's numbering (order of first raster pixel).

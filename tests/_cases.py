@@ -89,3 +89,29 @@ def assert_label_sums(got_sum, ref_sum, data, labels):
             inexact += 1
             assert abs(got_sum[l] - ref_sum[l]) <= 1e-12 * abs(ref_sum[l]), (l, got_sum[l], ref_sum[l])
     return inexact
+
+
+def serpentine_flowdir(h, w):
+    """One river through EVERY cell: down column 0, right, up column 1, right, ... -- it crosses every row seam w times and
+    the accumulated flow is the position along the river.  (AGNPS codes: 0 up, 2 right, 4 down, reference flow.py:30-38.)"""
+    fd = np.empty((h, w), np.uint8)
+    fd[:, 0::2] = 4
+    fd[:, 1::2] = 0
+    fd[h - 1, 0::2] = 2
+    fd[0, 1::2] = 2
+    return fd
+
+
+def random_flowdir(h, w, seed, p_none=0.05):
+    """Flow directions drawn at random: flow cycles, confluences, sinks and paths that wander across the seams."""
+    rng = np.random.default_rng(seed)
+    fd = rng.integers(0, 8, size=(h, w)).astype(np.uint8)
+    fd[rng.random((h, w)) < p_none] = 8
+    return fd
+
+
+def meander_flowdir(h, w, seed):
+    """Mostly downhill-to-the-right with vertical wiggles: long paths that collect tributaries while crossing seams."""
+    rng = np.random.default_rng(seed)
+    fd = rng.choice(np.array([1, 2, 3, 0, 4], np.uint8), size=(h, w), p=[0.3, 0.2, 0.3, 0.1, 0.1])
+    return fd.astype(np.uint8)

@@ -166,7 +166,35 @@ class CpuBand(object):
     def zero_raster(self, name):
         self._raster(name)[...] = 0
 
-    def run_accum(self):
+    def accum_boundary(self):
+        """stand-in for mhip_ctx_band_accum_boundary: own contribution (halo rows = sources of no flux) + exit map"""
+        fd = self.r["flowdir"]
+        H, W = self.H, self.W
+        DR = [-1, -1, 0, 1, 1, 1, 0, -1]
+        DC = [0, 1, 1, 1, 0, -1, -1, -1]
+        self.run_accum(halo_zero=True)
+        halo = {0: 0} if self.ht else {}
+        if self.hb:
+            halo[H - 1] = 1
+        exit_map = np.full(2 * W, -1, np.int32)
+        for hr, side in halo.items():
+            for c in range(W):
+                r, cc, steps = hr, c, 0
+                while steps <= H * W:
+                    d = fd[r, cc]
+                    if d > 7:
+                        break
+                    nr, nc = r + DR[d], cc + DC[d]
+                    if not (0 <= nr < H and 0 <= nc < W):
+                        break
+                    if nr in halo:
+                        if r not in halo:
+                            exit_map[side * W + c] = halo[nr] * W + cc
+                        break
+                    r, cc, steps = nr, nc, steps + 1
+        return exit_map
+
+    def run_accum(self, halo_zero=False):
         """Kahn accumulation of the owned rows; halo cells are sources when their value is known (> 0), else they block."""
         fd, acc = self.r["flowdir"], self._raster("accum")
         H, W = self.H, self.W
@@ -182,8 +210,8 @@ class CpuBand(object):
         for r in range(H):
             for c in range(W):
                 if halo[r]:
-                    val[r, c] = acc[r, c] if acc[r, c] > 0 else 0
-                    pend[r, c] = 0 if acc[r, c] > 0 else 99
+                    val[r, c] = acc[r, c] if acc[r, c] > 0 and not halo_zero else 0
+                    pend[r, c] = 0 if acc[r, c] > 0 or halo_zero else 99
                     continue
                 val[r, c] = 1
                 for k in range(8):

@@ -11,9 +11,9 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import fbm
+from _cases import fbm, meander_flowdir, random_flowdir, serpentine_flowdir
 from _cpu_band import CpuBand
-from malstroem_amd.distributed import BandPipeline, ThreadComm, band_rows
+from malstroem_amd.distributed import BandPipeline, ThreadComm, band_rows, solve_band_accum
 
 ROOT = Path(__file__).resolve().parent.parent
 KEYS = ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")
@@ -105,6 +105,62 @@ def test_protocol_threadcomm_cpu_backend(nbands):
     assert out[0]["short_diag"] == ref["short_diag"]
     assert all(o["nlabels"] == ref["nlabels"] for o in out)
     check_records(out, ref)
+
+
+def band_accum(fd, nbands, **kw):
+    """BandPipeline.accum() on given flow directions -> (accumulation of the undivided raster, exchanges per band)"""
+    out = [None] * nbands
+
+    def work(comm):
+        p = BandPipeline(comm, fd.shape, **kw)
+        p.band.upload("flowdir", fd[p.row0:p.row0 + p.nrows])
+        p._swap_edges("flowdir")
+        p.accum()
+        out[comm.rank] = (p.download("accum"), p.exchanges["accum"])
+        p.close()
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(300) for t in threads]
+    assert all(o is not None for o in out)
+    return np.concatenate([o[0] for o in out]), [o[1] for o in out]
+
+
+@pytest.mark.parametrize("name,fd,nbands", [
+    ("serpentine", serpentine_flowdir(12, 9), 3), ("serpentine-1row-bands", serpentine_flowdir(5, 8), 5),
+    ("random", random_flowdir(23, 17, 1), 4), ("random-1row-bands", random_flowdir(6, 31, 2), 6),
+    ("meander", meander_flowdir(30, 40, 3), 5), ("random-sparse", random_flowdir(19, 21, 4, p_none=0.4), 2)])
+def test_band_accumulation_needs_one_exchange_however_often_the_flow_crosses_the_seams(name, fd, nbands):
+    acc, exchanges = band_accum(fd, nbands, backend_factory=CpuBand)
+    want = oracle.accumulated_flow(fd)
+    assert np.array_equal(acc, want), name
+    assert exchanges == [1] * nbands
+    if name == "serpentine":
+        assert acc.max() == fd.size      # the river collects every cell
+
+
+def test_solve_band_accum_forest():
+    """three bands, W = 3: a chain  (band 0 last row, col 0) -> band 1, leaves from its last row col 2 -> band 2, plus a
+    tributary from band 2's first row (col 1) up into band 1 that joins the same exit, and an unknown (0) own value"""
+    W = 3
+    z = np.zeros(W)
+    none = np.full(2 * W, -1, np.int32)
+    e1 = none.copy()
+    e1[0] = 1 * W + 2           # top halo cell 0 leaves band 1 from (last row, col 2)
+    e1[W + 1] = 1 * W + 2       # bottom halo cell 1 (band 2's first row) leaves from the same cell
+    e2 = none.copy()
+    e2[2] = 0 * W + 0           # band 2: top halo cell 2 (= band 1's exit) turns round and leaves upwards from (first row, col 0)
+    info = [dict(a0=(z + 1, np.array([5.0, 1, 1])), exit=none),
+            dict(a0=(z + 1, np.array([1.0, 1, 7])), exit=e1),
+            dict(a0=(np.array([4.0, 3, 1]), z + 1), exit=e2)]
+    halos = solve_band_accum(info, W)
+    assert halos[0][0] is None and halos[2][1] is None
+    assert halos[1][0].tolist() == [5, 1, 1]                       # band 0's last row: nothing flows into band 0
+    assert halos[2][0].tolist() == [1, 1, 7 + 5 + 3]               # band 1's exit = own 7 + the chain 5 + the tributary 3
+    assert halos[1][1].tolist() == [4 + 15, 3, 1]                  # band 2's first row: col 0 carries what turned round
+    info[0]["a0"][1][0] = 0.0                                      # the source of the chain is unknown (a flow cycle upstream)
+    halos = solve_band_accum(info, W)
+    assert halos[1][0].tolist() == [0, 1, 1] and halos[2][0].tolist() == [1, 1, 0] and halos[1][1].tolist() == [0, 3, 1]
 
 
 WORKER = r'''

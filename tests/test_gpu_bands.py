@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import fbm, fixtures
+from _cases import fbm, fixtures, meander_flowdir, random_flowdir, serpentine_flowdir
 
 pytestmark = pytest.mark.gpu
 
@@ -97,6 +97,49 @@ def test_bands_match_oracle(nbands, h, w):
         else:
             for f in ("value", "row", "col"):
                 assert np.array_equal(got[f], w_[f]), f
+
+
+def band_accum(fd, nbands):
+    """BandPipeline.accum() on given flow directions -> (accumulation of the whole raster, exchanges per band)"""
+    from malstroem_amd.distributed import BandPipeline, ThreadComm
+    out, err = [None] * nbands, []
+
+    def work(comm):
+        try:
+            p = BandPipeline(comm, fd.shape, device=0)
+            p.band.upload("flowdir", fd[p.row0:p.row0 + p.nrows])
+            p._swap_edges("flowdir")
+            p.accum()
+            out[comm.rank] = (p.download("accum"), p.exchanges["accum"])
+            p.close()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+            raise
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(600) for t in threads]
+    assert not err, err
+    return np.concatenate([o[0] for o in out]), [o[1] for o in out]
+
+
+# band heights put the bottom halo row on the first row of a 64-row tile (64- and 63-row bands), in the middle of one, and
+# make bands of a single row (first owned row == last owned row)
+@pytest.mark.parametrize("name,fd,nbands", [
+    ("serpentine", serpentine_flowdir(300, 200), 3), ("serpentine-64", serpentine_flowdir(192, 130), 3),
+    ("serpentine-1row-bands", serpentine_flowdir(6, 300), 6), ("random", random_flowdir(260, 333, 1), 4),
+    ("random-63", random_flowdir(189, 257, 2), 3), ("random-64", random_flowdir(128, 64, 3), 2),
+    ("random-1row-bands", random_flowdir(5, 700, 4), 5), ("random-sparse", random_flowdir(500, 190, 5, p_none=0.5), 6),
+    ("meander", meander_flowdir(1000, 700, 6), 4), ("meander-big", meander_flowdir(2048, 2048, 7), 4),
+    ("random-big", random_flowdir(2048, 1500, 8), 5)])
+def test_band_accumulation_needs_one_exchange_however_often_the_flow_crosses_the_seams(name, fd, nbands):
+    acc, exchanges = band_accum(fd, nbands)
+    want = oracle.accumulated_flow(fd)
+    bad = np.argwhere(acc != want)
+    assert bad.size == 0, (name, len(bad), bad[:5].tolist(), acc[tuple(bad[0])], want[tuple(bad[0])])
+    assert exchanges == [1] * nbands
+    if name.startswith("serpentine"):
+        assert acc.max() == fd.size      # the river collects every cell
 
 
 def test_device_row_entry_points_match_host_ones():

@@ -108,7 +108,8 @@ struct FillStats {
     int64_t visits = 0;   // tile visits over all rounds
     int64_t cycles = 0;   // local (down, up, right, left) cycles over all visits
     int64_t tiles = 0;    // tiles in the raster
-    int32_t algorithm = 0;  // 0: iterative tile schedule (fill.hip), 1: tiled priority-flood (pflood.hip; rounds = kernel launches)
+    int32_t algorithm = 0;  // 0: iterative tile schedule (fill.hip), 1: tiled priority-flood (pflood.hip; rounds = kernel launches),
+                            // 2: integer geodesic transform (noflat_geo.hip)
 };
 
 // fill.hip
@@ -140,6 +141,9 @@ int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipSt
                    bool *depths_done = nullptr);
 // pflood.hip
 int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st);
+// noflat_geo.hip: MHIP_ELIMIT = not applicable, run the float64 relaxation
+int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
+                             FillStats *st);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);

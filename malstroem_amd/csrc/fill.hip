@@ -1053,6 +1053,9 @@ void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled)
 {
+    // the integer geodesic transform of noflat_geo.hip first; it hands back MHIP_ELIMIT for what it does not cover
+    const int rc = fill_noflat_geodesic_dev(d_dem, d_filled, d_out, H, W, sh, dg, s, st);
+    if (rc != MHIP_ELIMIT) return rc;
     FillRun f;
     f.noflat = true; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W; f.sh = sh; f.dg = dg;
     noflat_seed(f, d_filled, sh, dg, H * W);

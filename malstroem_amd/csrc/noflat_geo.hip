@@ -1,0 +1,614 @@
+// noflat_geo.hip -- the no-flats fill (reference fill.py:174-232, speedups/_fill.pyx:72-124) as an INTEGER geodesic
+// distance transform inside the level sets of the plain fill.  gfx950 only.
+//
+// What the reference computes.  Its sweeps lower W from +inf until W = max(dtm, min(W, min(diag nbrs) + diag, min(edge nbrs) +
+// short)) everywhere; the limit G is the greatest fixed point, i.e. the one solution of the STRICT equation
+//     G[c] = max(dtm[c], min_n fl(G[n] + eps_n))  (interior),  G = dtm (raster border)                                  (*)
+// ((*) has one solution: eps > 0 admits no self-supporting cycle).
+//
+// Structure of the solution.  Let F be the plain fill of the same DEM (fill.py:112-171).  A cell that has a neighbour with a
+// lower F, or lies on the raster border, keeps G = dtm = F: a SOURCE.  Every other cell c belongs to a flat of F (a lake
+// surface or a natural flat at level V = F[c]) and takes G[c] = min fl(G[n] + eps_n) over its neighbours ON THE SAME LEVEL
+// (higher neighbours are out of reach by more than a float32 step, lower ones do not exist): inside a level set, G - V is the
+// eps-geodesic distance to the sources of that level set, every step rounded to float64.
+// The rounding is what made this look inherently sequential.  But all values of one level set lie in ONE binade of float64
+// (V is a float32, the total rise stays far below a float32 step), where the ulp u is a constant and every value is a multiple
+// of u: fl(x + eps) = x + rn(eps / u) * u exactly, whatever x.  So  G = V + u * D  with D the chamfer distance for the INTEGER
+// weights S = rn(short / u), Dg = rn(diag / u) -- order independent, exact in uint32.  A level whose binade does not give such
+// weights (V = 0, denormals, NaN/inf, a tie in the rounding, weights out of range) is IRREGULAR; any irregular flat cell sends
+// the whole raster to the float64 relaxation of fill.hip.
+// None of this is trusted: after the distances are turned into G, ng_verify_kernel evaluates (*) at EVERY cell in the
+// reference's own float64 arithmetic.  One mismatch anywhere -> the caller runs the float64 relaxation instead.
+//
+// Kernels.  ng_classify (streaming): per cell a 16-bit word = same-level adjacency byte | binade class << 8.
+// ng_round (one launch per round): a wavefront holds a 64 x 64 window (62 x 62 tile + halo ring) of distances in 64 VGPRs
+// and relaxes it by row-sequential passes (down, up; transposed through wave-private LDS: right, left) with DPP neighbours;
+// a tile whose edge cells moved marks the neighbouring tiles for the next round (one byte per tile, plain stores -- no
+// atomics, no work lists: wave w owns the tiles w, w + nwaves, ... and scans their marks with one vector load).
+// ng_assemble (streaming): G = F + u * D.  ng_verify (streaming): (*).
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace mh {
+
+namespace {
+
+constexpr int WN = 64;  // window edge (tile + halo ring)
+constexpr int TI = 62;  // tile edge
+constexpr uint32_t DINF = 0xE0000000u;     // "not reached yet"; every weight is < 2**28, so DINF + weight does not wrap
+constexpr uint32_t WMAX = 1u << 28;
+constexpr uint32_t M_NOFLAT = 0xFF00u;     // class 255: not a flat cell (a source), or a flat cell of a level without integer weights (counted)
+constexpr int DPP_WF_SL1 = 0x130;          // lane i <- lane i+1
+constexpr int DPP_WF_SR1 = 0x138;          // lane i <- lane i-1
+#ifndef NG_MAXCYC
+#define NG_MAXCYC 2
+#endif
+enum { C_IRREGULAR = 0, C_UNREACHED = 1, C_MISMATCH = 2, C_STATS = 8 };   // counters[]; C_STATS: 64 x {visits, cycles}
+
+__device__ __forceinline__ uint32_t from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_WF_SR1, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_WF_SL1, 0xf, 0xf, true); }
+
+// biased float64-exponent class of the values just ABOVE V (where the flat's values live), 255: no class
+__device__ __forceinline__ uint32_t class_above(float V)
+{
+    const uint32_t b = __float_as_uint(V), ex = (b >> 23) & 0xffu;
+    if (ex == 0u || ex == 255u) return 255u;                 // zero, denormal, inf, NaN
+    return ((b >> 31) && (b & 0x7fffffu) == 0u) ? ex - 1u : ex;   // V = -2**k: the values above it are one binade down
+}
+// ulp of class e (float32 bias 127 -> float64 bias 1023, 52 mantissa bits)
+__device__ __forceinline__ double class_ulp(uint32_t e) { return __longlong_as_double((long long)(e + 1023u - 127u - 52u) << 52); }
+
+// ---- classification --------------------------------------------------------------------------------------------------
+// bits of the adjacency byte = AGNPS direction codes (common.hpp): U 0, UR 1, R 2, DR 3, D 4, DL 5, L 6, UL 7
+constexpr int CRB = 32;   // rows per thread
+__global__ __launch_bounds__(256) void ng_classify_kernel(const float *__restrict__ F, int64_t H, int64_t W, const uint32_t *__restrict__ tab,
+                                                          uint16_t *__restrict__ m16, unsigned long long *counters)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rb = (int64_t)blockIdx.y * CRB;
+    if (c >= W) return;
+    const float QNAN = __uint_as_float(0x7fc00000u);   // outside the raster: never lower, never equal
+    const bool cl = c > 0, cr = c + 1 < W;
+    auto row = [&](int64_t r, float (&v)[3]) {
+        const bool in = r >= 0 && r < H;
+        const float *p = F + (in ? r : 0) * W + c;
+        v[0] = (in && cl) ? p[-1] : QNAN;
+        v[1] = in ? p[0] : QNAN;
+        v[2] = (in && cr) ? p[1] : QNAN;
+    };
+    float a[3], b[3], n[3];
+    row(rb - 1, a);
+    row(rb, b);
+    unsigned nirr = 0;
+#pragma unroll 4
+    for (int i = 0; i < CRB; ++i) {
+        const int64_t r = rb + i;
+        if (r >= H) break;
+        row(r + 1, n);
+        const float V = b[1];
+        uint32_t m = M_NOFLAT;
+        if (V != V) {          // NaN anywhere: not for this path
+            m = M_NOFLAT;
+            ++nirr;
+        } else if (r > 0 && r < H - 1 && cl && cr) {
+            const bool lower = a[0] < V || a[1] < V || a[2] < V || b[0] < V || b[2] < V || n[0] < V || n[1] < V || n[2] < V;
+            if (!lower) {
+                const uint32_t adj = (a[1] == V ? 1u : 0u) | (a[2] == V ? 2u : 0u) | (b[2] == V ? 4u : 0u) | (n[2] == V ? 8u : 0u) |
+                                     (n[1] == V ? 16u : 0u) | (n[0] == V ? 32u : 0u) | (b[0] == V ? 64u : 0u) | (a[0] == V ? 128u : 0u);
+                const uint32_t e = class_above(V);
+                const bool regular = adj != 0u && e != 255u && tab[e] != 0u;
+                m = regular ? (adj | (e << 8)) : M_NOFLAT;
+                nirr += regular ? 0u : 1u;
+            }
+        }
+        m16[r * W + c] = (uint16_t)m;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a[k] = b[k];
+            b[k] = n[k];
+        }
+    }
+    if (nirr) atomicAdd(&counters[C_IRREGULAR], (unsigned long long)nirr);
+}
+
+// ---- one round of tile visits ------------------------------------------------------------------------------------------
+struct GeoArgs {
+    int64_t H, W;
+    int ntr, ntc, nt;
+    const uint16_t *m16;
+    uint32_t *d;
+    uint8_t *mark_cur, *mark_nxt;   // one byte per tile: visit it in this / the next round
+    uint32_t *any_nxt;              // set when this round marks anything
+    const uint32_t *tab;            // [256] S | [256] Dg by class
+    unsigned long long *counters;
+    int first;                      // first round: every tile, distances start from the classification alone
+};
+
+// 64 x 64 transpose of 32-bit words through a wave-private LDS scratch [64][65].  The DS instructions are written out: one
+// base register + immediate offsets (left to itself the compiler pairs the row writes into ds_write2 with 8-bit offsets, needs a
+// new base every four rows and then keeps -- and spills -- all sixteen of them for the next transpose).  `scr_b`: LDS byte
+// address of the scratch.  DS operations of one wave execute in order; the explicit waits make the data visible to the VALU.
+template <int R> __device__ __forceinline__ void lds_put(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(R) : "memory"); }
+template <int R> __device__ __forceinline__ uint32_t lds_get(uint32_t addr)
+{
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(R) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); }
+template <int R0, int N> __device__ __forceinline__ void lds_put_rows(uint32_t addr, const uint32_t (&x)[WN])
+{
+    if constexpr (N > 0) {
+        lds_put<R0 * (WN + 1) * 4>(addr, x[R0]);
+        lds_put_rows<R0 + 1, N - 1>(addr, x);
+    }
+}
+template <int C0, int N> __device__ __forceinline__ void lds_get_cols(uint32_t addr, uint32_t (&x)[WN])
+{
+    if constexpr (N > 0) {
+        x[C0] = lds_get<C0 * 4>(addr);
+        lds_get_cols<C0 + 1, N - 1>(addr, x);
+    }
+}
+__device__ __forceinline__ void transpose32(uint32_t (&x)[WN], uint32_t scr_b, int lane)
+{
+    lds_put_rows<0, WN>(scr_b + 4u * lane, x);
+    lds_wait();
+    lds_get_cols<0, WN>(scr_b + 4u * (WN + 1) * lane, x);
+    lds_wait();
+#pragma unroll
+    for (int c = 0; c < WN; ++c) asm volatile("" : "+v"(x[c]));   // uses stay behind the wait
+}
+
+struct UniformW {   // every flat cell of the window is of one class: scalar weights
+    uint32_t S, Dg;
+    __device__ __forceinline__ void get(uint32_t, const uint32_t *, uint32_t &s, uint32_t &g) const { s = S; g = Dg; }
+};
+struct LaneW {      // classes differ inside the window (it straddles a power of two): weights by the cell's own class
+    __device__ __forceinline__ void get(uint32_t mword, const uint32_t *tab_l, uint32_t &s, uint32_t &g) const
+    {
+        const uint32_t e = (mword >> 8) & 0xffu;
+        s = tab_l[e];
+        g = tab_l[256 + e];
+    }
+};
+
+// One row-sequential pass (DOWN: rows 1..62, else 62..1): row r is relaxed from the three cells of the row behind it.
+// ni[r]: low byte = INVERTED adjacency of the current layout, bits 8..15 = class.  A cell that must not move (source, halo
+// ring, outside the raster) has no adjacency: all its candidates become 0xffffffff.
+template <bool DOWN, typename WT>
+__device__ __forceinline__ void pass(uint32_t (&d)[WN], uint32_t (&ni)[WN], const WT wt, const uint32_t *tab_l, uint32_t &acc_all,
+                                     uint32_t &acc_first, uint32_t &acc_last)
+{
+    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
+    constexpr int bC = DOWN ? 0 : 4, bL = DOWN ? 7 : 5, bR = DOWN ? 1 : 3;   // behind-centre, behind-left (lane - 1), behind-right
+    // new names for the rows in every pass: what one pass derives from a row (table addresses, mask bits) must not be kept
+    // alive for the next one -- 62 extra live registers, i.e. spills inside the row loop
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]), "+v"(ni[r]));
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int r = first + dir * i;
+        const uint32_t behind = d[r - dir];
+        const uint32_t bl = from_left(behind), br = from_right(behind);
+        const uint32_t w = ni[r];
+        uint32_t S, G;
+        wt.get(w, tab_l, S, G);
+        const uint32_t c0 = (behind + S) | (uint32_t)__builtin_amdgcn_sbfe((int)w, bC, 1);
+        const uint32_t c1 = (bl + G) | (uint32_t)__builtin_amdgcn_sbfe((int)w, bL, 1);
+        const uint32_t c2 = (br + G) | (uint32_t)__builtin_amdgcn_sbfe((int)w, bR, 1);
+        const uint32_t cu = d[r];
+        const uint32_t nv = min(min(c0, c1), min(c2, cu));
+        const uint32_t x = nv ^ cu;
+        acc_all |= x;
+        asm volatile("" : "+v"(acc_all));   // accumulate row by row (a reassociated OR tree keeps all 62 differences alive)
+        if (r == 1) acc_first |= x;
+        if (r == TI) acc_last |= x;
+        d[r] = nv;
+        __builtin_amdgcn_sched_barrier(0);   // rows in program order: hoisted shifts / mask extractions blow the VGPR budget
+    }
+}
+
+template <typename WT>
+__device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], const WT wt, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &wake,
+                                      bool &changed, bool &capped, unsigned &cycles)
+{
+    // wake bits = neighbour k of the 3 x 3 block around the tile (k = 3 * (di + 1) + dj + 1)
+    const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
+    capped = true;
+#pragma nounroll
+    for (int cyc = 0; cyc < NG_MAXCYC; ++cyc) {
+        uint64_t chg = 0;
+        ++cycles;
+#pragma nounroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
+            pass<true>(d, ni, wt, tab_l, acc_all, acc_first, acc_last);
+            pass<false>(d, ni, wt, tab_l, acc_all, acc_first, acc_last);
+            const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
+            chg |= all;
+            // half 0: lane = column, first / last = row 1 / 62.  half 1: lane = row, first / last = column 1 / 62.
+            const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
+            const unsigned l1 = (all & B1) ? 1u : 0u, l62 = (all & B62) ? 1u : 0u;
+            const unsigned f1 = (fst & B1) ? 1u : 0u, f62 = (fst & B62) ? 1u : 0u, g1 = (lst & B1) ? 1u : 0u, g62 = (lst & B62) ? 1u : 0u;
+            if (half == 0)   // top | bottom | left | right | TL TR BL BR
+                wake |= (e_first << 1) | (e_last << 7) | (l1 << 3) | (l62 << 5) | (f1 << 0) | (f62 << 2) | (g1 << 6) | (g62 << 8);
+            else
+                wake |= (e_first << 3) | (e_last << 5) | (l1 << 1) | (l62 << 7) | (f1 << 0) | (f62 << 6) | (g1 << 2) | (g62 << 8);
+            transpose32(d, scr_b, lane);
+#pragma unroll
+            for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_alignbit(ni[r], ni[r], 16);   // the other layout's half word
+        }
+        changed |= chg != 0;
+        if (!chg) {
+            capped = false;
+            break;
+        }
+    }
+}
+
+__device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &visits, unsigned &cycles)
+{
+    const int64_t H = a.H, W = a.W;
+    const int ti = t / a.ntc, tj = t - ti * a.ntc;
+    const int64_t r0 = (int64_t)ti * TI, c0 = (int64_t)tj * TI;
+    const int64_t cc = c0 + lane;
+    const bool col_in = cc < W;
+    // Loads are clamped into the raster: a column >= W reads column W - 1, a row >= H reads row H - 1.  Those are raster BORDER
+    // cells: class 255, no adjacency -- to the window they look like sources nobody is adjacent to, which is all "outside the
+    // raster" has to mean here.
+    const uint32_t lane_c = (uint32_t)(col_in ? lane : W - 1 - c0);
+    const bool ring_lane = (lane == 0) | (lane == WN - 1);
+
+    // buffer addressing: one shared per-lane byte offset + a scalar row offset (no 64-bit address arithmetic in VGPRs)
+    const int64_t org = r0 * W + c0;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.m16 + org), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.d + org), 0, 0x7fffffff, 0x00020000);
+    const int Wi = (int)W;
+    const int last_row = (int)(H - 1 - r0 < WN - 1 ? H - 1 - r0 : WN - 1);   // last window row inside the raster
+    uint32_t ni[WN], d[WN];
+    // classification words (adjacency | class << 8; class 255 = not a flat cell).  The halo ring of the window loses its
+    // adjacency (its cells belong to the neighbouring tiles: they never move here), everything outside the raster is no cell.
+    uint32_t lake_any = 0;
+    {
+        int so = 0;
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            uint32_t mv = __builtin_amdgcn_raw_buffer_load_b16(rm, (int)(lane_c * 2u), so * 2, 0);
+            so = r < last_row ? so + Wi : so;
+            const bool ring = (r == 0) | (r == WN - 1) | ring_lane;
+            mv = ring ? (mv & 0xff00u) : mv;
+            lake_any |= mv;
+            ni[r] = mv;
+        }
+    }
+    if (!__any((lake_any & 0xffu) != 0u)) return;   // nothing in this tile can move
+    ++visits;
+    __builtin_amdgcn_sched_barrier(0);
+    // the column layout's words: direction (dr, dc) becomes (dc, dr) = bits 0..6 reversed, bit 7 stays.  Afterwards
+    // ni = (this layout's word | the other layout's word << 16) with both adjacency bytes INVERTED for the passes.
+    {
+        uint32_t tw[WN];
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            const uint32_t adj = ni[r] & 0xffu;
+            tw[r] = (__builtin_bitreverse32(adj << 25) | (adj & 0x80u)) | (ni[r] & 0xff00u);
+        }
+        lds_put_rows<0, WN>(scr_b + 4u * lane, tw);
+        lds_wait();
+        // read back in two halves: never more than 32 transposed words in flight next to the 64 of this layout
+        lds_get_cols<0, 32>(scr_b + 4u * (WN + 1) * lane, tw);
+        lds_wait();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            asm volatile("" : "+v"(tw[r]));
+            ni[r] = (ni[r] | (tw[r] << 16)) ^ 0x00ff00ffu;
+        }
+        lds_get_cols<32, 32>(scr_b + 4u * (WN + 1) * lane, tw);
+        lds_wait();
+#pragma unroll
+        for (int r = 32; r < WN; ++r) {
+            asm volatile("" : "+v"(tw[r]));
+            ni[r] = (ni[r] | (tw[r] << 16)) ^ 0x00ff00ffu;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // distances: a flat cell's lives in memory (from round 2 on), a source's is 0 wherever its tile never stored one
+    if (a.first) {
+#pragma unroll
+        for (int r = 0; r < WN; ++r) d[r] = ((ni[r] >> 8) & 0xffu) != 255u ? DINF : 0u;
+    } else {
+        int so = 0;
+#pragma unroll
+        for (int r = 0; r < WN; ++r) {
+            const uint32_t dv = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), so * 4, 0);
+            so = r < last_row ? so + Wi : so;
+            d[r] = ((ni[r] >> 8) & 0xffu) != 255u ? dv : 0u;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // one class in the whole window?  (from the words that stay live anyway: the adjacency byte is inverted by now)
+    uint32_t esel = 255u;
+#pragma unroll
+    for (int r = 1; r <= TI; ++r) esel = (ni[r] & 0xffu) != 0xffu ? (ni[r] >> 8) & 0xffu : esel;
+    const uint64_t has = __ballot(esel != 255u);
+    const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)esel, (int)__builtin_ctzll(has));   // has != 0: the tile holds a flat cell
+    uint32_t mism = 0;
+#pragma unroll
+    for (int r = 1; r <= TI; ++r) mism |= (ni[r] & 0xffu) != 0xffu ? ((ni[r] >> 8) & 0xffu) ^ eref : 0u;
+    const bool uniform = !__any(mism != 0u);
+    unsigned wake = 0;
+    bool changed = false, capped = false;
+    if (uniform) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, wake, changed, capped, cycles);
+    else relax(d, ni, LaneW{}, tab_l, scr_b, lane, wake, changed, capped, cycles);
+
+    if (changed || a.first) {
+        const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
+        if (lane_ok) {
+#pragma unroll
+            for (int r = 1; r <= TI; ++r)
+                if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(d[r], rd, lane * 4, r * Wi * 4, 0);   // row H - 1 is a border row
+        }
+    }
+    if (capped) wake |= 1u << 4;
+    if (wake) {
+        if (lane < 9 && ((wake >> lane) & 1u)) {
+            const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
+            if (p >= 0 && p < a.ntr && q >= 0 && q < a.ntc) a.mark_nxt[(int64_t)p * a.ntc + q] = 1;
+        }
+        if (lane == 0) *a.any_nxt = 1u;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void ng_round_kernel(GeoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t scr_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lds + wave * (WN * (WN + 1)));
+    uint32_t *tab_l = lds + 4 * (WN * (WN + 1));
+    for (int i = threadIdx.x; i < 512; i += 256) tab_l[i] = a.tab[i];
+    __syncthreads();
+    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
+    unsigned visits = 0, cycles = 0;
+    for (int64_t base = gw; base < a.nt; base += (int64_t)nwaves * 64) {
+        const int64_t tl = base + (int64_t)lane * nwaves;
+        bool on = tl < a.nt;
+        if (on && !a.first) {
+            on = a.mark_cur[tl] != 0;
+            if (on) a.mark_cur[tl] = 0;
+        }
+        uint64_t todo = __ballot(on);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            visit(a, (int)(base + (int64_t)l * nwaves), tab_l, scr_b, lane, visits, cycles);
+        }
+    }
+    if (lane == 0 && visits) {
+        unsigned long long *st = a.counters + C_STATS + 2 * (gw & 63);
+        atomicAdd(&st[0], (unsigned long long)visits);
+        atomicAdd(&st[1], (unsigned long long)cycles);
+    }
+}
+
+// ---- G = F + u * D -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ng_assemble_kernel(const float *__restrict__ F, const uint16_t *__restrict__ m16, const uint32_t *__restrict__ d,
+                                                          double *__restrict__ G, int64_t n, unsigned long long *counters)
+{
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    unsigned bad = 0;
+    if (i0 + 4 <= n) {
+        const float4 f = *reinterpret_cast<const float4 *>(F + i0);
+        const ushort4 m = *reinterpret_cast<const ushort4 *>(m16 + i0);
+        const uint4 dv = *reinterpret_cast<const uint4 *>(d + i0);
+        const float fv[4] = {f.x, f.y, f.z, f.w};
+        const unsigned mv[4] = {m.x, m.y, m.z, m.w};
+        const uint32_t dd[4] = {dv.x, dv.y, dv.z, dv.w};
+        double g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool flat = (mv[k] >> 8) != 255u;
+            bad += (flat && dd[k] >= 0x80000000u) ? 1u : 0u;
+            g[k] = flat ? (double)fv[k] + (double)dd[k] * class_ulp(mv[k] >> 8) : (double)fv[k];
+        }
+        typedef double __attribute__((ext_vector_type(2))) v2d;
+        *reinterpret_cast<v2d *>(G + i0) = v2d{g[0], g[1]};
+        *reinterpret_cast<v2d *>(G + i0 + 2) = v2d{g[2], g[3]};
+    } else {
+        for (int64_t i = i0; i < n; ++i) {
+            const unsigned mv = m16[i];
+            const bool flat = (mv >> 8) != 255u;
+            const uint32_t dd = flat ? d[i] : 0u;
+            bad += (flat && dd >= 0x80000000u) ? 1u : 0u;
+            G[i] = flat ? (double)F[i] + (double)dd * class_ulp(mv >> 8) : (double)F[i];
+        }
+    }
+    if (bad) atomicAdd(&counters[C_UNREACHED], (unsigned long long)bad);
+}
+
+// ---- the strict equation (*) at every cell, in the reference's arithmetic (_fill.pyx:107-117) ------------------------------
+constexpr int VRB = 16;   // rows per thread
+__global__ __launch_bounds__(256) void ng_verify_kernel(const float *__restrict__ dem, const double *__restrict__ G, int64_t H, int64_t W, double sh,
+                                                        double dg, unsigned long long *counters)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rb = (int64_t)blockIdx.y * VRB;
+    if (c >= W) return;
+    const double PINF = __builtin_inf();
+    const bool cl = c > 0, cr = c + 1 < W;
+    auto row = [&](int64_t r, double (&v)[3]) {
+        const bool in = r >= 0 && r < H;
+        const double *p = G + (in ? r : 0) * W + c;
+        v[0] = (in && cl) ? p[-1] : PINF;
+        v[1] = in ? p[0] : PINF;
+        v[2] = (in && cr) ? p[1] : PINF;
+    };
+    double a[3], b[3], n[3];
+    row(rb - 1, a);
+    row(rb, b);
+    unsigned bad = 0;
+#pragma unroll 4
+    for (int i = 0; i < VRB; ++i) {
+        const int64_t r = rb + i;
+        if (r >= H) break;
+        row(r + 1, n);
+        const double own = b[1], dv = (double)dem[r * W + c];
+        double want = dv;
+        if (r > 0 && r < H - 1 && cl && cr) {
+            const double md = fmin(fmin(a[0], a[2]), fmin(n[0], n[2])) + dg;
+            const double me = fmin(fmin(a[1], b[0]), fmin(b[2], n[1])) + sh;
+            want = fmax(fmin(md, me), dv);
+        }
+        bad += (own == want) ? 0u : 1u;   // NaN anywhere fails too
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a[k] = b[k];
+            b[k] = n[k];
+        }
+    }
+    if (bad) atomicAdd(&counters[C_MISMATCH], (unsigned long long)bad);
+}
+
+// rn(eps / 2**(E - 52)) for the binade class e (E = e - 127) with eps = M * 2**q exactly; 0: no integer weight in (0, 2**28)
+uint32_t class_weight(double eps, int e)
+{
+    if (!(eps > 0.0) || std::isinf(eps)) return 0;
+    int q;
+    const double fr = std::frexp(eps, &q);                       // eps = fr * 2**q, fr in [0.5, 1)
+    const uint64_t M = (uint64_t)std::ldexp(fr, 53);             // 53-bit integer, eps = M * 2**(q - 53)
+    const int k = (e - 127 - 52) - (q - 53);                     // eps / u = M >> k
+    if (k <= 24 || k > 52) return 0;                             // >= 2**28, or below one ulp
+    const uint64_t half = 1ull << (k - 1), rem = M & ((1ull << k) - 1);
+    if (rem == half) return 0;                                   // a tie: the rounding would depend on the running value
+    const uint64_t w = (M >> k) + (rem > half ? 1 : 0);
+    return (w >= 1 && w < WMAX) ? (uint32_t)w : 0;
+}
+
+}  // namespace
+
+// MHIP_OK: d_out holds the verified no-flats surface.  MHIP_ELIMIT: not applicable to this raster (irregular levels, a cell the
+// verification rejects, ...): the caller runs the float64 relaxation.
+int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
+                             FillStats *st)
+{
+    static const bool off = [] { const char *e = getenv("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
+    static const bool debug = getenv("MHIP_NG_DEBUG") != nullptr;
+    if (off || !d_filled || H < 3 || W < 3) return MHIP_ELIMIT;
+    if (!(sh > 0.0) || !(dg > 0.0) || std::isinf(sh) || std::isinf(dg)) return MHIP_ELIMIT;
+    const int64_t n = H * W;
+    std::vector<uint32_t> tab(512, 0u);
+    bool any_class = false;
+    for (int e = 0; e < 255; ++e) {
+        const uint32_t S = class_weight(sh, e), G = class_weight(dg, e);
+        if (S && G) {
+            tab[e] = S;
+            tab[256 + e] = G;
+            any_class = true;
+        }
+    }
+    if (!any_class) return MHIP_ELIMIT;
+
+    const int ntr = (int)((H - 2 + TI - 1) / TI), ntc = (int)((W - 2 + TI - 1) / TI);
+    const int64_t nt = (int64_t)ntr * ntc;
+    constexpr int MAXR = 4096, BATCH = 16;
+    auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
+    const size_t o_d = 0, o_m = align(o_d + 4 * (size_t)n), o_tab = align(o_m + 2 * (size_t)n), o_cnt = align(o_tab + 2048);
+    const size_t o_any = align(o_cnt + 8 * (C_STATS + 128)), o_mark = align(o_any + 4 * (size_t)(MAXR + BATCH));
+    DevBuf ws;
+    MH_TRY(ws.alloc(o_mark + 2 * (size_t)nt + 256));
+    char *b = ws.as<char>();
+    uint32_t *d_d = reinterpret_cast<uint32_t *>(b + o_d);
+    uint16_t *d_m = reinterpret_cast<uint16_t *>(b + o_m);
+    uint32_t *d_tab = reinterpret_cast<uint32_t *>(b + o_tab);
+    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(b + o_cnt);
+    uint32_t *d_any = reinterpret_cast<uint32_t *>(b + o_any);
+    uint8_t *d_mark = reinterpret_cast<uint8_t *>(b + o_mark);
+    MH_HIP(hipMemsetAsync(b + o_cnt, 0, o_mark + 2 * (size_t)nt - o_cnt, s));
+    MH_HIP(hipMemcpyAsync(d_tab, tab.data(), 2048, hipMemcpyHostToDevice, s));
+
+    hipLaunchKernelGGL(ng_classify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + CRB - 1) / CRB)), dim3(256), 0, s, d_filled, H, W, d_tab, d_m,
+                       d_cnt);
+    MH_HIP(hipGetLastError());
+    unsigned long long h_cnt[4] = {0, 0, 0, 0};
+    MH_HIP(hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
+    if (h_cnt[C_IRREGULAR]) {
+        if (debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells: float64 relaxation\n", h_cnt[C_IRREGULAR]);
+        return MHIP_ELIMIT;
+    }
+
+    const size_t lds = (4 * WN * (WN + 1) + 512) * sizeof(uint32_t);
+    {
+        static std::mutex mu;
+        static bool attr_done[64] = {};
+        int dev = 0;
+        MH_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+            MH_HIP(hipFuncSetAttribute((const void *)ng_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        }
+    }
+    GeoArgs a;
+    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.nt = (int)nt; a.m16 = d_m; a.d = d_d; a.tab = d_tab; a.counters = d_cnt;
+    const unsigned grid = (unsigned)std::min<int64_t>((nt + 3) / 4, 512);
+    int round = 0, used = 0;
+    bool active = true;
+    while (active) {
+        if (round + BATCH > MAXR) {
+            set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
+            return MHIP_ENOTCONV;
+        }
+        for (int k = 0; k < BATCH; ++k, ++round) {
+            a.first = round == 0;
+            a.mark_cur = d_mark + (size_t)(round & 1) * nt;
+            a.mark_nxt = d_mark + (size_t)((round + 1) & 1) * nt;
+            a.any_nxt = d_any + round;
+            hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), lds, s, a);
+        }
+        MH_HIP(hipGetLastError());
+        uint32_t h_any[BATCH];
+        MH_HIP(hipMemcpyAsync(h_any, d_any + (round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < BATCH; ++k) {
+            ++used;
+            if (!h_any[k]) {   // that round marked nothing: the later launches of the batch found no marks
+                active = false;
+                break;
+            }
+        }
+    }
+
+    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, d_filled, d_m, d_d, d_out, n, d_cnt);
+    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg,
+                       d_cnt);
+    MH_HIP(hipGetLastError());
+    unsigned long long h_all[C_STATS + 128];
+    MH_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    if (st) {
+        *st = FillStats();
+        st->rounds = used;
+        st->tiles = nt;
+        st->algorithm = 2;
+        for (int k = 0; k < 64; ++k) {
+            st->visits += (int64_t)h_all[C_STATS + 2 * k];
+            st->cycles += (int64_t)h_all[C_STATS + 2 * k + 1];
+        }
+    }
+    if (debug)
+        fprintf(stderr, "[noflat geodesic] %lld x %lld: rounds %d, unreached %llu, mismatches %llu\n", (long long)H, (long long)W, used, h_all[C_UNREACHED],
+                h_all[C_MISMATCH]);
+    if (h_all[C_UNREACHED] || h_all[C_MISMATCH]) return MHIP_ELIMIT;
+    return MHIP_OK;
+}
+
+}  // namespace mh

@@ -47,7 +47,10 @@ constexpr uint32_t M_NOFLAT = 0xFF00u;     // class 255: not a flat cell (a sour
 constexpr int DPP_WF_SL1 = 0x130;          // lane i <- lane i+1
 constexpr int DPP_WF_SR1 = 0x138;          // lane i <- lane i-1
 #ifndef NG_MAXCYC
-#define NG_MAXCYC 2
+#define NG_MAXCYC 1      // local (down, up, right, left) cycles per visit; a visit that is cut off re-queues its own tile
+#endif
+#ifndef NG_FIRSTCYC
+#define NG_FIRSTCYC 1    // ... in the first round: flats that fit into one tile are finished there
 #endif
 enum { C_IRREGULAR = 0, C_UNREACHED = 1, C_MISMATCH = 2, C_STATS = 8 };   // counters[]; C_STATS: 64 x {visits, cycles}
 
@@ -123,11 +126,14 @@ struct GeoArgs {
     int ntr, ntc, nt;
     const uint16_t *m16;
     uint32_t *d;
-    uint8_t *mark_cur, *mark_nxt;   // one byte per tile: visit it in this / the next round
-    uint32_t *any_nxt;              // set when this round marks anything
+    uint32_t *blk;                  // [nt][64][64] the tiles' window words as the passes want them (written by the first round)
+    uint32_t *hdr;                  // [nt] seams | uniform << 9 | class << 16 | active << 31
+    uint8_t *mark;                  // one byte per tile: visit it in the next round
+    const int *list;                // this round's tiles (ng_compact_kernel) ...
+    const uint32_t *count;          // ... and how many
     const uint32_t *tab;            // [256] S | [256] Dg by class
     unsigned long long *counters;
-    int first;                      // first round: every tile, distances start from the classification alone
+    int maxcyc;                     // local cycles per visit in this round
 };
 
 // 64 x 64 transpose of 32-bit words through a wave-private LDS scratch [64][65].  The DS instructions are written out: one
@@ -208,22 +214,23 @@ __device__ __forceinline__ void pass(uint32_t (&d)[WN], uint32_t (&ni)[WN], cons
         const uint32_t x = nv ^ cu;
         acc_all |= x;
         asm volatile("" : "+v"(acc_all));   // accumulate row by row (a reassociated OR tree keeps all 62 differences alive)
-        if (r == 1) acc_first |= x;
-        if (r == TI) acc_last |= x;
+        // row 1 / 62 matter to the neighbouring tile only through cells that are adjacent to something across the seam
+        if (r == 1) acc_first |= (w & 0x83u) != 0x83u ? x : 0u;
+        if (r == TI) acc_last |= (w & 0x38u) != 0x38u ? x : 0u;
         d[r] = nv;
         __builtin_amdgcn_sched_barrier(0);   // rows in program order: hoisted shifts / mask extractions blow the VGPR budget
     }
 }
 
 template <typename WT>
-__device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], const WT wt, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &wake,
-                                      bool &changed, bool &capped, unsigned &cycles)
+__device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], const WT wt, const uint32_t *tab_l, uint32_t scr_b, int lane, int maxcyc,
+                                      unsigned &wake, bool &changed, bool &capped, unsigned &cycles)
 {
     // wake bits = neighbour k of the 3 x 3 block around the tile (k = 3 * (di + 1) + dj + 1)
     const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
     capped = true;
 #pragma nounroll
-    for (int cyc = 0; cyc < NG_MAXCYC; ++cyc) {
+    for (int cyc = 0; cyc < maxcyc; ++cyc) {
         uint64_t chg = 0;
         ++cycles;
 #pragma nounroll
@@ -253,6 +260,12 @@ __device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], con
     }
 }
 
+// One tile visit.  FIRST (ng_first_kernel, every tile once): the window's words are built from the classification -- ring
+// cleared, column layout transposed in, adjacency inverted -- and kept for all later visits as a 16 KB block per tile together
+// with a header word (seams, class, "holds a flat cell at all"); distances start from the classification alone.  Later visits
+// (ng_round_kernel) load header, block and distances and go straight to the passes.
+constexpr uint32_t HDR_ACTIVE = 1u << 31, HDR_UNIFORM = 1u << 9;
+template <bool FIRST>
 __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &visits, unsigned &cycles)
 {
     const int64_t H = a.H, W = a.W;
@@ -264,66 +277,109 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     // cells: class 255, no adjacency -- to the window they look like sources nobody is adjacent to, which is all "outside the
     // raster" has to mean here.
     const uint32_t lane_c = (uint32_t)(col_in ? lane : W - 1 - c0);
-    const bool ring_lane = (lane == 0) | (lane == WN - 1);
 
     // buffer addressing: one shared per-lane byte offset + a scalar row offset (no 64-bit address arithmetic in VGPRs)
     const int64_t org = r0 * W + c0;
-    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.m16 + org), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.d + org), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.blk + (int64_t)t * (WN * WN)), 0, WN * WN * 4, 0x00020000);
     const int Wi = (int)W;
     const int last_row = (int)(H - 1 - r0 < WN - 1 ? H - 1 - r0 : WN - 1);   // last window row inside the raster
     uint32_t ni[WN], d[WN];
-    // classification words (adjacency | class << 8; class 255 = not a flat cell).  The halo ring of the window loses its
-    // adjacency (its cells belong to the neighbouring tiles: they never move here), everything outside the raster is no cell.
-    uint32_t lake_any = 0;
-    {
-        int so = 0;
+    uint32_t hdr;
+    if constexpr (FIRST) {
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.m16 + org), 0, 0x7fffffff, 0x00020000);
+        const bool ring_lane = (lane == 0) | (lane == WN - 1);
+        // classification words (adjacency | class << 8; class 255 = not a flat cell).  The halo ring of the window loses its
+        // adjacency: its cells belong to the neighbouring tiles, they never move here.
+        uint32_t lake_any = 0;
+        {
+            int so = 0;
 #pragma unroll
-        for (int r = 0; r < WN; ++r) {
-            uint32_t mv = __builtin_amdgcn_raw_buffer_load_b16(rm, (int)(lane_c * 2u), so * 2, 0);
-            so = r < last_row ? so + Wi : so;
-            const bool ring = (r == 0) | (r == WN - 1) | ring_lane;
-            mv = ring ? (mv & 0xff00u) : mv;
-            lake_any |= mv;
-            ni[r] = mv;
+            for (int r = 0; r < WN; ++r) {
+                uint32_t mv = __builtin_amdgcn_raw_buffer_load_b16(rm, (int)(lane_c * 2u), so * 2, 0);
+                so = r < last_row ? so + Wi : so;
+                const bool ring = (r == 0) | (r == WN - 1) | ring_lane;
+                mv = ring ? (mv & 0xff00u) : mv;
+                lake_any |= mv;
+                ni[r] = mv;
+            }
         }
-    }
-    if (!__any((lake_any & 0xffu) != 0u)) return;   // nothing in this tile can move
-    ++visits;
-    __builtin_amdgcn_sched_barrier(0);
-    // the column layout's words: direction (dr, dc) becomes (dc, dr) = bits 0..6 reversed, bit 7 stays.  Afterwards
-    // ni = (this layout's word | the other layout's word << 16) with both adjacency bytes INVERTED for the passes.
-    {
-        uint32_t tw[WN];
+        if (!__any((lake_any & 0xffu) != 0u)) {   // nothing in this tile can move, ever
+            if (lane == 0) a.hdr[t] = 0u;
+            return;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the column layout's words: direction (dr, dc) becomes (dc, dr) = bits 0..6 reversed, bit 7 stays.  Afterwards
+        // ni = (this layout's word | the other layout's word << 16) with both adjacency bytes INVERTED for the passes.
+        {
+            uint32_t tw[WN];
 #pragma unroll
-        for (int r = 0; r < WN; ++r) {
-            const uint32_t adj = ni[r] & 0xffu;
-            tw[r] = (__builtin_bitreverse32(adj << 25) | (adj & 0x80u)) | (ni[r] & 0xff00u);
-        }
-        lds_put_rows<0, WN>(scr_b + 4u * lane, tw);
-        lds_wait();
-        // read back in two halves: never more than 32 transposed words in flight next to the 64 of this layout
-        lds_get_cols<0, 32>(scr_b + 4u * (WN + 1) * lane, tw);
-        lds_wait();
+            for (int r = 0; r < WN; ++r) {
+                const uint32_t adj = ni[r] & 0xffu;
+                tw[r] = (__builtin_bitreverse32(adj << 25) | (adj & 0x80u)) | (ni[r] & 0xff00u);
+            }
+            lds_put_rows<0, WN>(scr_b + 4u * lane, tw);
+            lds_wait();
+            // read back in two halves: never more than 32 transposed words in flight next to the 64 of this layout
+            lds_get_cols<0, 32>(scr_b + 4u * (WN + 1) * lane, tw);
+            lds_wait();
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            asm volatile("" : "+v"(tw[r]));
-            ni[r] = (ni[r] | (tw[r] << 16)) ^ 0x00ff00ffu;
-        }
-        lds_get_cols<32, 32>(scr_b + 4u * (WN + 1) * lane, tw);
-        lds_wait();
+            for (int r = 0; r < 32; ++r) {
+                asm volatile("" : "+v"(tw[r]));
+                ni[r] = (ni[r] | (tw[r] << 16)) ^ 0x00ff00ffu;
+            }
+            lds_get_cols<32, 32>(scr_b + 4u * (WN + 1) * lane, tw);
+            lds_wait();
 #pragma unroll
-        for (int r = 32; r < WN; ++r) {
-            asm volatile("" : "+v"(tw[r]));
-            ni[r] = (ni[r] | (tw[r] << 16)) ^ 0x00ff00ffu;
+            for (int r = 32; r < WN; ++r) {
+                asm volatile("" : "+v"(tw[r]));
+                ni[r] = (ni[r] | (tw[r] << 16)) ^ 0x00ff00ffu;
+            }
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // distances: a flat cell's lives in memory (from round 2 on), a source's is 0 wherever its tile never stored one
-    if (a.first) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < WN; ++r) __builtin_amdgcn_raw_buffer_store_b32(ni[r], rb, lane * 4, r * WN * 4, 0);
+        // distances: a flat cell starts unreached, a source is 0
 #pragma unroll
         for (int r = 0; r < WN; ++r) d[r] = ((ni[r] >> 8) & 0xffu) != 255u ? DINF : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        // one class in the whole window?  (from the words that stay live anyway: the adjacency byte is inverted by now)
+        uint32_t esel = 255u;
+#pragma unroll
+        for (int r = 1; r <= TI; ++r) esel = (ni[r] & 0xffu) != 0xffu ? (ni[r] >> 8) & 0xffu : esel;
+        const uint64_t has = __ballot(esel != 255u);
+        const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)esel, (int)__builtin_ctzll(has));   // has != 0: the tile holds a flat cell
+        uint32_t mism = 0;
+#pragma unroll
+        for (int r = 1; r <= TI; ++r) mism |= (ni[r] & 0xffu) != 0xffu ? ((ni[r] >> 8) & 0xffu) ^ eref : 0u;
+        // which of the 8 neighbouring tiles share a flat with this one at all?  (bit numbering of `wake`)
+        unsigned seams = 1u << 4;
+        {
+            uint32_t l_or = 0xffu;   // AND of the inverted bytes over rows 1..62 = inverted OR of the adjacency
+#pragma unroll
+            for (int r = 1; r <= TI; ++r) l_or &= ni[r];
+            const uint64_t top = __ballot((ni[1] & 0x83u) != 0x83u), bot = __ballot((ni[TI] & 0x38u) != 0x38u);
+            const uint64_t lft = __ballot((l_or & 0xe0u) != 0xe0u), rgt = __ballot((l_or & 0x0eu) != 0x0eu);
+            const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
+            seams |= (top & INNER) ? 1u << 1 : 0u;
+            seams |= (bot & INNER) ? 1u << 7 : 0u;
+            seams |= (lft & B1) ? 1u << 3 : 0u;
+            seams |= (rgt & B62) ? 1u << 5 : 0u;
+            const uint64_t tl = __ballot((ni[1] & 0x80u) == 0u), tr = __ballot((ni[1] & 0x02u) == 0u);
+            const uint64_t bl = __ballot((ni[TI] & 0x20u) == 0u), br = __ballot((ni[TI] & 0x08u) == 0u);
+            seams |= (tl & B1) ? 1u << 0 : 0u;
+            seams |= (tr & B62) ? 1u << 2 : 0u;
+            seams |= (bl & B1) ? 1u << 6 : 0u;
+            seams |= (br & B62) ? 1u << 8 : 0u;
+        }
+        hdr = HDR_ACTIVE | seams | (__any(mism != 0u) ? 0u : HDR_UNIFORM) | (eref << 16);
+        if (lane == 0) a.hdr[t] = hdr;
     } else {
+        hdr = __builtin_amdgcn_readfirstlane(a.hdr[t]);
+        if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
+#pragma unroll
+        for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
+        // distances: a flat cell's lives in memory, a source's is 0 wherever its tile never stored one
         int so = 0;
 #pragma unroll
         for (int r = 0; r < WN; ++r) {
@@ -332,23 +388,16 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             d[r] = ((ni[r] >> 8) & 0xffu) != 255u ? dv : 0u;
         }
     }
+    ++visits;
     __builtin_amdgcn_sched_barrier(0);
-    // one class in the whole window?  (from the words that stay live anyway: the adjacency byte is inverted by now)
-    uint32_t esel = 255u;
-#pragma unroll
-    for (int r = 1; r <= TI; ++r) esel = (ni[r] & 0xffu) != 0xffu ? (ni[r] >> 8) & 0xffu : esel;
-    const uint64_t has = __ballot(esel != 255u);
-    const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)esel, (int)__builtin_ctzll(has));   // has != 0: the tile holds a flat cell
-    uint32_t mism = 0;
-#pragma unroll
-    for (int r = 1; r <= TI; ++r) mism |= (ni[r] & 0xffu) != 0xffu ? ((ni[r] >> 8) & 0xffu) ^ eref : 0u;
-    const bool uniform = !__any(mism != 0u);
+    const uint32_t eref = (hdr >> 16) & 0xffu;
     unsigned wake = 0;
     bool changed = false, capped = false;
-    if (uniform) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, wake, changed, capped, cycles);
-    else relax(d, ni, LaneW{}, tab_l, scr_b, lane, wake, changed, capped, cycles);
+    if (hdr & HDR_UNIFORM) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    wake &= hdr & 0x1ffu;
 
-    if (changed || a.first) {
+    if (changed || FIRST) {
         const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
         if (lane_ok) {
 #pragma unroll
@@ -360,13 +409,13 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     if (wake) {
         if (lane < 9 && ((wake >> lane) & 1u)) {
             const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
-            if (p >= 0 && p < a.ntr && q >= 0 && q < a.ntc) a.mark_nxt[(int64_t)p * a.ntc + q] = 1;
+            if (p >= 0 && p < a.ntr && q >= 0 && q < a.ntc) a.mark[(int64_t)p * a.ntc + q] = 1;
         }
-        if (lane == 0) *a.any_nxt = 1u;
     }
 }
 
-__global__ __launch_bounds__(256, 2) void ng_round_kernel(GeoArgs a)
+template <bool FIRST>
+__device__ __forceinline__ void round_body(const GeoArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63;
@@ -377,25 +426,43 @@ __global__ __launch_bounds__(256, 2) void ng_round_kernel(GeoArgs a)
     __syncthreads();
     const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
     unsigned visits = 0, cycles = 0;
-    for (int64_t base = gw; base < a.nt; base += (int64_t)nwaves * 64) {
-        const int64_t tl = base + (int64_t)lane * nwaves;
-        bool on = tl < a.nt;
-        if (on && !a.first) {
-            on = a.mark_cur[tl] != 0;
-            if (on) a.mark_cur[tl] = 0;
-        }
-        uint64_t todo = __ballot(on);
-        while (todo) {
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            visit(a, (int)(base + (int64_t)l * nwaves), tab_l, scr_b, lane, visits, cycles);
-        }
+    const int n = FIRST ? a.nt : (int)__builtin_amdgcn_readfirstlane((int)*a.count);
+    for (int i = gw; i < n; i += nwaves) {
+        const int t = FIRST ? i : __builtin_amdgcn_readfirstlane(a.list[i]);
+        visit<FIRST>(a, t, tab_l, scr_b, lane, visits, cycles);
     }
     if (lane == 0 && visits) {
         unsigned long long *st = a.counters + C_STATS + 2 * (gw & 63);
         atomicAdd(&st[0], (unsigned long long)visits);
         atomicAdd(&st[1], (unsigned long long)cycles);
     }
+}
+__global__ __launch_bounds__(256, 2) void ng_first_kernel(GeoArgs a) { round_body<true>(a); }
+__global__ __launch_bounds__(256, 2) void ng_round_kernel(GeoArgs a) { round_body<false>(a); }
+
+// ---- the marks of one round -> the tile list of the next (one workgroup; clears the marks) ------------------------------------
+// The mark bytes are read as 64-bit words (the array is padded to a multiple of 8 bytes); the order of the list is irrelevant,
+// so a slot range comes from one LDS atomic per thread that found something.
+__global__ __launch_bounds__(1024) void ng_compact_kernel(unsigned long long *mark8, int nwords, int *list, uint32_t *count)
+{
+    __shared__ uint32_t n_l;
+    if (threadIdx.x == 0) n_l = 0;
+    __syncthreads();
+    for (int w = threadIdx.x; w < nwords; w += 1024) {
+        const unsigned long long v = mark8[w];
+        if (v) {
+            mark8[w] = 0;
+            unsigned k = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) k += ((v >> (8 * j)) & 0xffull) ? 1u : 0u;
+            uint32_t o = atomicAdd(&n_l, k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((v >> (8 * j)) & 0xffull) list[o++] = 8 * w + j;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *count = n_l;
 }
 
 // ---- G = F + u * D -------------------------------------------------------------------------------------------------------
@@ -501,6 +568,8 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
 {
     static const bool off = [] { const char *e = getenv("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
     static const bool debug = getenv("MHIP_NG_DEBUG") != nullptr;
+    const int maxcyc = getenv("MHIP_NG_MAXCYC") ? atoi(getenv("MHIP_NG_MAXCYC")) : NG_MAXCYC;        // tuning knobs (development)
+    const int firstcyc = getenv("MHIP_NG_FIRSTCYC") ? atoi(getenv("MHIP_NG_FIRSTCYC")) : NG_FIRSTCYC;
     if (off || !d_filled || H < 3 || W < 3) return MHIP_ELIMIT;
     if (!(sh > 0.0) || !(dg > 0.0) || std::isinf(sh) || std::isinf(dg)) return MHIP_ELIMIT;
     const int64_t n = H * W;
@@ -522,8 +591,9 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
     auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t o_d = 0, o_m = align(o_d + 4 * (size_t)n), o_tab = align(o_m + 2 * (size_t)n), o_cnt = align(o_tab + 2048);
     const size_t o_any = align(o_cnt + 8 * (C_STATS + 128)), o_mark = align(o_any + 4 * (size_t)(MAXR + BATCH));
+    const size_t o_list = align(o_mark + (size_t)nt + 8), o_hdr = align(o_list + 4 * (size_t)nt), o_blk = align(o_hdr + 4 * (size_t)nt);
     DevBuf ws;
-    MH_TRY(ws.alloc(o_mark + 2 * (size_t)nt + 256));
+    MH_TRY(ws.alloc(o_blk + 4 * (size_t)nt * WN * WN + 256));
     char *b = ws.as<char>();
     uint32_t *d_d = reinterpret_cast<uint32_t *>(b + o_d);
     uint16_t *d_m = reinterpret_cast<uint16_t *>(b + o_m);
@@ -531,7 +601,9 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
     unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(b + o_cnt);
     uint32_t *d_any = reinterpret_cast<uint32_t *>(b + o_any);
     uint8_t *d_mark = reinterpret_cast<uint8_t *>(b + o_mark);
-    MH_HIP(hipMemsetAsync(b + o_cnt, 0, o_mark + 2 * (size_t)nt - o_cnt, s));
+    int *d_list = reinterpret_cast<int *>(b + o_list);
+    uint32_t *d_hdr = reinterpret_cast<uint32_t *>(b + o_hdr), *d_blk = reinterpret_cast<uint32_t *>(b + o_blk);
+    MH_HIP(hipMemsetAsync(b + o_cnt, 0, o_list - o_cnt, s));
     MH_HIP(hipMemcpyAsync(d_tab, tab.data(), 2048, hipMemcpyHostToDevice, s));
 
     hipLaunchKernelGGL(ng_classify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + CRB - 1) / CRB)), dim3(256), 0, s, d_filled, H, W, d_tab, d_m,
@@ -554,11 +626,12 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
             MH_HIP(hipFuncSetAttribute((const void *)ng_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MH_HIP(hipFuncSetAttribute((const void *)ng_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
     GeoArgs a;
-    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.nt = (int)nt; a.m16 = d_m; a.d = d_d; a.tab = d_tab; a.counters = d_cnt;
+    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.nt = (int)nt; a.m16 = d_m; a.d = d_d; a.tab = d_tab; a.counters = d_cnt; a.blk = d_blk; a.hdr = d_hdr;
     const unsigned grid = (unsigned)std::min<int64_t>((nt + 3) / 4, 512);
     int round = 0, used = 0;
     bool active = true;
@@ -568,22 +641,26 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
             return MHIP_ENOTCONV;
         }
         for (int k = 0; k < BATCH; ++k, ++round) {
-            a.first = round == 0;
-            a.mark_cur = d_mark + (size_t)(round & 1) * nt;
-            a.mark_nxt = d_mark + (size_t)((round + 1) & 1) * nt;
-            a.any_nxt = d_any + round;
-            hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), lds, s, a);
+            a.maxcyc = round == 0 ? firstcyc : maxcyc;
+            a.mark = d_mark;
+            a.list = d_list;
+            a.count = d_any + round;     // tiles of round `round` (round 0: every tile)
+            if (round)
+                hipLaunchKernelGGL(ng_compact_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(d_mark), (int)((nt + 7) / 8), d_list,
+                                   d_any + round);
+            if (round) hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), lds, s, a);
         }
         MH_HIP(hipGetLastError());
         uint32_t h_any[BATCH];
         MH_HIP(hipMemcpyAsync(h_any, d_any + (round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         for (int k = 0; k < BATCH; ++k) {
-            ++used;
-            if (!h_any[k]) {   // that round marked nothing: the later launches of the batch found no marks
+            if (round - BATCH + k > 0 && !h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
                 active = false;
                 break;
             }
+            ++used;
         }
     }
 
@@ -603,6 +680,18 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
             st->visits += (int64_t)h_all[C_STATS + 2 * k];
             st->cycles += (int64_t)h_all[C_STATS + 2 * k + 1];
         }
+    }
+    if (debug) {
+        std::vector<uint32_t> cnt((size_t)round);
+        MH_HIP(hipMemcpy(cnt.data(), d_any, 4 * (size_t)round, hipMemcpyDeviceToHost));
+        unsigned long long v = 0, cy = 0;
+        for (int k = 0; k < 64; ++k) {
+            v += h_all[C_STATS + 2 * k];
+            cy += h_all[C_STATS + 2 * k + 1];
+        }
+        fprintf(stderr, "[noflat geodesic] tiles %lld, visits %llu, cycles %llu; tiles per round:", (long long)nt, v, cy);
+        for (int k = 1; k < used; ++k) fprintf(stderr, " %u", cnt[k]);
+        fprintf(stderr, "\n");
     }
     if (debug)
         fprintf(stderr, "[noflat geodesic] %lld x %lld: rounds %d, unreached %llu, mismatches %llu\n", (long long)H, (long long)W, used, h_all[C_UNREACHED],

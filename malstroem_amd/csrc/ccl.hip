@@ -16,6 +16,9 @@
 //   3. flatten: parent[i] = root(i)
 //   4. rank   : per-block root counts -> single-block scan -> roots get -(rank+1)
 //   5. emit   : labels[i] = rank of root(i), 0 for background
+#include <cstdlib>
+#include <string>
+
 #include "common.hpp"
 
 namespace mh {
@@ -91,6 +94,127 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(int32_t *parent, int64_t
     const bool hasNE = c + 1 < W && parent[i - W + 1] >= 0;
     if (hasNW && !hasW) unite(parent, (int32_t)i, (int32_t)(i - W - 1));   // with W foreground, W has N == my NW
     if (hasNE) unite(parent, (int32_t)i, (int32_t)(i - W + 1));            // a run that starts above my right shoulder
+}
+
+// ---- tile-local labelling in LDS ------------------------------------------------------------------------------------------
+// One workgroup = one 64 x 64 tile; wave w owns the tile rows w, w + 4, ...  The same three steps as above (runs, one union per
+// pair of vertically adjacent runs, flatten) on a 16 KB table of tile-local indices, then parent[cell] = GLOBAL index of the
+// cell's tile-local root (the first cell of its piece in raster order, tile-local = global order inside a tile).  What is left
+// for global memory are the unions across the tile seams (ccl_seam_kernel): ~6 % of the cells.
+constexpr int CT = 64;
+constexpr uint32_t LBG = 0xffffffffu;
+
+__device__ __forceinline__ uint32_t find_root_l(const uint32_t *par, uint32_t x)
+{
+    uint32_t p = par[x];
+    while (p != x) {
+        x = p;
+        p = par[x];
+    }
+    return x;
+}
+__device__ __forceinline__ void unite_l(uint32_t *par, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = find_root_l(par, a);
+        b = find_root_l(par, b);
+        if (a == b) return;
+        if (a < b) {
+            const uint32_t t = a;
+            a = b;
+            b = t;
+        }
+        const uint32_t old = atomicMin(&par[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t H, int64_t W, int ntc)
+{
+    __shared__ uint32_t par[CT * CT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ti = blockIdx.x / ntc, tj = blockIdx.x - ti * ntc;
+    const int64_t r0 = (int64_t)ti * CT, c0 = (int64_t)tj * CT;
+    const int64_t cc = c0 + lane;
+    uint64_t fgrow[CT / 4];   // foreground masks of my rows (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) {
+        const int r = wave + 4 * k;
+        const bool fg = (r0 + r) < H && cc < W && is_fg(data[(r0 + r) * W + cc]);
+        const uint64_t m = __ballot(fg);
+        fgrow[k] = m;
+        // first lane of my run: the highest run start at or below my lane
+        const uint64_t starts = m & ~(m << 1);
+        const uint64_t below = starts & ((2ull << lane) - 1ull);
+        par[r * CT + lane] = fg ? (uint32_t)(r * CT + (63 - __builtin_clzll(below))) : LBG;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) {
+        const int r = wave + 4 * k;
+        if (r == 0) continue;
+        const uint64_t m = fgrow[k];
+        const uint32_t pn = par[(r - 1) * CT + lane];
+        const uint64_t up = __ballot(pn != LBG);
+        if (!((m >> lane) & 1ull)) continue;
+        const bool hasW = lane > 0 && ((m >> (lane - 1)) & 1ull), hasN = (up >> lane) & 1ull;
+        const bool hasNW = lane > 0 && ((up >> (lane - 1)) & 1ull), hasNE = lane < 63 && ((up >> (lane + 1)) & 1ull);
+        const uint32_t i = (uint32_t)(r * CT + lane);
+        if (hasN) {
+            if (!(hasW && hasNW)) unite_l(par, i, i - CT);
+        } else {
+            if (hasNW && !hasW) unite_l(par, i, i - CT - 1);
+            if (hasNE) unite_l(par, i, i - CT + 1);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CT / 4; ++k) {
+        const int r = wave + 4 * k;
+        if ((r0 + r) >= H || cc >= W) continue;
+        const uint32_t p = par[r * CT + lane];
+        int32_t out = -1;
+        if (p != LBG) {
+            const uint32_t root = find_root_l(par, p);
+            out = (int32_t)((r0 + (root >> 6)) * W + c0 + (root & 63u));
+        }
+        parent[(r0 + r) * W + cc] = out;
+    }
+}
+
+// unions across the tile seams.  Horizontal seams (rows that start a tile): the rule of ccl_merge_kernel for N / NW / NE.
+// Vertical seams (columns that start a tile): W; NW and SW only when W is background (else W is united with them -- inside
+// its tile, or by the horizontal-seam rule of its own row).
+__global__ __launch_bounds__(256) void ccl_seam_kernel(int32_t *parent, int64_t H, int64_t W, int64_t nh, int64_t total)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    if (k < nh) {                                   // cell (r, c) of a seam row r = 64, 128, ...
+        const int64_t r = (k / W + 1) * CT, c = k % W;
+        const int64_t i = r * W + c;
+        if (parent[i] < 0) return;
+        const bool hasW = c > 0 && parent[i - 1] >= 0, hasN = parent[i - W] >= 0, hasNW = c > 0 && parent[i - W - 1] >= 0;
+        if (hasN) {
+            if (!(hasW && hasNW)) unite(parent, (int32_t)i, (int32_t)(i - W));
+            return;
+        }
+        const bool hasNE = c + 1 < W && parent[i - W + 1] >= 0;
+        if (hasNW && !hasW) unite(parent, (int32_t)i, (int32_t)(i - W - 1));
+        if (hasNE) unite(parent, (int32_t)i, (int32_t)(i - W + 1));
+    } else {                                        // cell (r, c) of a seam column c = 64, 128, ...
+        const int64_t q = k - nh;
+        const int64_t r = q % H, c = (q / H + 1) * CT;
+        const int64_t i = r * W + c;
+        if (parent[i] < 0) return;
+        if (parent[i - 1] >= 0) {
+            unite(parent, (int32_t)i, (int32_t)(i - 1));
+            return;
+        }
+        if (r > 0 && parent[i - W - 1] >= 0) unite(parent, (int32_t)i, (int32_t)(i - W - 1));
+        if (r + 1 < H && parent[i + W - 1] >= 0) unite(parent, (int32_t)i, (int32_t)(i + W - 1));
+    }
 }
 
 __global__ __launch_bounds__(256) void ccl_flatten_kernel(int32_t *parent, int64_t n)
@@ -209,8 +333,17 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
     MH_TRY(counts.alloc(sizeof(uint32_t) * (size_t)nb));
     MH_TRY(total.alloc(sizeof(unsigned long long)));
     int32_t *parent = d_tmp;
-    hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n, W);
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(g256), dim3(256), 0, s, parent, H, W);
+    static const bool global_uf = [] { const char *e = getenv("MHIP_CCL"); return e && std::string(e) == "global"; }();
+    if (global_uf) {   // the round-1 schedule: every union through global memory
+        hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n, W);
+        hipLaunchKernelGGL(ccl_merge_kernel, dim3(g256), dim3(256), 0, s, parent, H, W);
+    } else {
+        const int64_t ntr = cdiv(H, CT), ntc = cdiv(W, CT);
+        hipLaunchKernelGGL((ccl_tile_kernel<T>), dim3((unsigned)(ntr * ntc)), dim3(256), 0, s, d_data, parent, H, W, (int)ntc);
+        const int64_t nh = (ntr - 1) * W, nv = (ntc - 1) * H;
+        if (nh + nv > 0)
+            hipLaunchKernelGGL(ccl_seam_kernel, dim3((unsigned)cdiv(nh + nv, 256)), dim3(256), 0, s, parent, H, W, nh, nh + nv);
+    }
     hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g256), dim3(256), 0, s, parent, n);
     hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, counts.as<uint32_t>(), nb,

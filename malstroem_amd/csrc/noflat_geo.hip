@@ -20,8 +20,8 @@
 // None of this is trusted: after the distances are turned into G, ng_verify_kernel evaluates (*) at EVERY cell in the
 // reference's own float64 arithmetic.  One mismatch anywhere -> the caller runs the float64 relaxation instead.
 //
-// Kernels.  ng_classify (streaming): per cell a 16-bit word = same-level adjacency byte | binade class << 8.
-// ng_round (one launch per round): a wavefront holds a 64 x 64 window (62 x 62 tile + halo ring) of distances in 64 VGPRs
+// Kernels.  ng_first (every tile once): classifies the window from F -- per cell a 16-bit word = same-level adjacency byte |
+// binade class << 8 -- and keeps it as a block per tile.  ng_first / ng_round (one launch per round): a wavefront holds a 64 x 64 window (62 x 62 tile + halo ring) of distances in 64 VGPRs
 // and relaxes it by row-sequential passes (down, up; transposed through wave-private LDS: right, left) with DPP neighbours;
 // a tile whose edge cells moved marks the neighbouring tiles for the next round (one byte per tile, plain stores -- no
 // atomics, no work lists: wave w owns the tiles w, w + nwaves, ... and scans their marks with one vector load).
@@ -57,6 +57,16 @@ enum { C_IRREGULAR = 0, C_UNREACHED = 1, C_MISMATCH = 2, C_STATS = 8 };   // cou
 __device__ __forceinline__ uint32_t from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_WF_SR1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_WF_SL1, 0xf, 0xf, true); }
 
+// float neighbours; a lane without a source lane (lane 0 / 63) reads +inf: never lower, never equal
+__device__ __forceinline__ float fleft(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(v), DPP_WF_SR1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fright(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(v), DPP_WF_SL1, 0xf, 0xf, false));
+}
+
 // biased float64-exponent class of the values just ABOVE V (where the flat's values live), 255: no class
 __device__ __forceinline__ uint32_t class_above(float V)
 {
@@ -67,64 +77,11 @@ __device__ __forceinline__ uint32_t class_above(float V)
 // ulp of class e (float32 bias 127 -> float64 bias 1023, 52 mantissa bits)
 __device__ __forceinline__ double class_ulp(uint32_t e) { return __longlong_as_double((long long)(e + 1023u - 127u - 52u) << 52); }
 
-// ---- classification --------------------------------------------------------------------------------------------------
-// bits of the adjacency byte = AGNPS direction codes (common.hpp): U 0, UR 1, R 2, DR 3, D 4, DL 5, L 6, UL 7
-constexpr int CRB = 32;   // rows per thread
-__global__ __launch_bounds__(256) void ng_classify_kernel(const float *__restrict__ F, int64_t H, int64_t W, const uint32_t *__restrict__ tab,
-                                                          uint16_t *__restrict__ m16, unsigned long long *counters)
-{
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t rb = (int64_t)blockIdx.y * CRB;
-    if (c >= W) return;
-    const float QNAN = __uint_as_float(0x7fc00000u);   // outside the raster: never lower, never equal
-    const bool cl = c > 0, cr = c + 1 < W;
-    auto row = [&](int64_t r, float (&v)[3]) {
-        const bool in = r >= 0 && r < H;
-        const float *p = F + (in ? r : 0) * W + c;
-        v[0] = (in && cl) ? p[-1] : QNAN;
-        v[1] = in ? p[0] : QNAN;
-        v[2] = (in && cr) ? p[1] : QNAN;
-    };
-    float a[3], b[3], n[3];
-    row(rb - 1, a);
-    row(rb, b);
-    unsigned nirr = 0;
-#pragma unroll 4
-    for (int i = 0; i < CRB; ++i) {
-        const int64_t r = rb + i;
-        if (r >= H) break;
-        row(r + 1, n);
-        const float V = b[1];
-        uint32_t m = M_NOFLAT;
-        if (V != V) {          // NaN anywhere: not for this path
-            m = M_NOFLAT;
-            ++nirr;
-        } else if (r > 0 && r < H - 1 && cl && cr) {
-            const bool lower = a[0] < V || a[1] < V || a[2] < V || b[0] < V || b[2] < V || n[0] < V || n[1] < V || n[2] < V;
-            if (!lower) {
-                const uint32_t adj = (a[1] == V ? 1u : 0u) | (a[2] == V ? 2u : 0u) | (b[2] == V ? 4u : 0u) | (n[2] == V ? 8u : 0u) |
-                                     (n[1] == V ? 16u : 0u) | (n[0] == V ? 32u : 0u) | (b[0] == V ? 64u : 0u) | (a[0] == V ? 128u : 0u);
-                const uint32_t e = class_above(V);
-                const bool regular = adj != 0u && e != 255u && tab[e] != 0u;
-                m = regular ? (adj | (e << 8)) : M_NOFLAT;
-                nirr += regular ? 0u : 1u;
-            }
-        }
-        m16[r * W + c] = (uint16_t)m;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a[k] = b[k];
-            b[k] = n[k];
-        }
-    }
-    if (nirr) atomicAdd(&counters[C_IRREGULAR], (unsigned long long)nirr);
-}
-
 // ---- one round of tile visits ------------------------------------------------------------------------------------------
 struct GeoArgs {
     int64_t H, W;
     int ntr, ntc, nt;
-    const uint16_t *m16;
+    const float *F;                 // the plain fill
     uint32_t *d;
     uint32_t *blk;                  // [nt][64][64] the tiles' window words as the passes want them (written by the first round)
     uint32_t *hdr;                  // [nt] seams | uniform << 9 | class << 16 | active << 31
@@ -287,25 +244,80 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     uint32_t ni[WN], d[WN];
     uint32_t hdr;
     if constexpr (FIRST) {
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(a.m16 + org), 0, 0x7fffffff, 0x00020000);
+        // ---- classification of the window from the plain fill F (adjacency bits = AGNPS direction codes of common.hpp:
+        // U 0, UR 1, R 2, DR 3, D 4, DL 5, L 6, UL 7).  A cell with a lower neighbour, or on the raster border, is a source;
+        // every other interior cell is a flat cell: word = same-level adjacency | class << 8.  Class 255 = not a flat cell.
+        // The halo ring of the window gets no adjacency (its cells belong to the neighbouring tiles: they never move here);
+        // a ring cell that is not KNOWN to be a source from inside the window starts unreached -- an upper bound, which is all
+        // the relaxation needs -- and is read from memory in the later rounds.
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc((void *)(a.F + org), 0, 0x7fffffff, 0x00020000);
         const bool ring_lane = (lane == 0) | (lane == WN - 1);
-        // classification words (adjacency | class << 8; class 255 = not a flat cell).  The halo ring of the window loses its
-        // adjacency: its cells belong to the neighbouring tiles, they never move here.
-        uint32_t lake_any = 0;
+        const bool lane_in = (lane >= 1) & (lane <= TI) & (cc < W - 1);          // a column of interior raster cells
+        const bool lane_border = (tj == 0 && lane == 0) | (cc >= W - 1);          // raster border column (or its clamped copies)
+        const float PINF = __builtin_inff();
+        const int border_row = (int)(H - 1 - r0 < 2 * WN ? H - 1 - r0 : 2 * WN);   // window row of the raster's last row (or beyond the window)
+        uint32_t lake_any = 0, nirr = 0;
         {
+            float f[WN];
             int so = 0;
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
-                uint32_t mv = __builtin_amdgcn_raw_buffer_load_b16(rm, (int)(lane_c * 2u), so * 2, 0);
+                f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, (int)(lane_c * 4u), so * 4, 0));
                 so = r < last_row ? so + Wi : so;
+            }
+            float upl = PINF, up = PINF, upr = PINF, cul = fleft(f[0]), cur = fright(f[0]);
+#pragma unroll
+            for (int r = 0; r < WN; ++r) {
+                const float V = f[r], dn = r + 1 < WN ? f[r + 1] : PINF;
+                const float dnl = r + 1 < WN ? fleft(dn) : PINF, dnr = r + 1 < WN ? fright(dn) : PINF;
+                const bool lower = (upl < V) | (up < V) | (upr < V) | (cul < V) | (cur < V) | (dnl < V) | (dn < V) | (dnr < V);
+                const bool border = lane_border | (ti == 0 && r == 0) | (r >= border_row);
+                const bool src = lower | border;
                 const bool ring = (r == 0) | (r == WN - 1) | ring_lane;
-                mv = ring ? (mv & 0xff00u) : mv;
-                lake_any |= mv;
-                ni[r] = mv;
+                uint32_t w = M_NOFLAT;
+                bool unreached = ring & !src;
+                if (!ring) {
+                    const uint32_t adj = (up == V ? 1u : 0u) | (upr == V ? 2u : 0u) | (cur == V ? 4u : 0u) | (dnr == V ? 8u : 0u) |
+                                         (dn == V ? 16u : 0u) | (dnl == V ? 32u : 0u) | (cul == V ? 64u : 0u) | (upl == V ? 128u : 0u);
+                    const uint32_t e = class_above(V);
+                    const bool cell = lane_in & !border;     // an interior raster cell
+                    const bool flat = cell & !src;
+                    const bool regular = flat & (adj != 0u) & (e != 255u) && tab_l[e & 0xffu] != 0u;
+                    nirr += ((flat & !regular) | (cell & (V != V))) ? 1u : 0u;   // a level without integer weights, or a NaN: not for this path
+                    w = regular ? (adj | (e << 8)) : M_NOFLAT;
+                    unreached = regular;
+                }
+                lake_any |= w;
+                ni[r] = w;
+                d[r] = unreached ? DINF : 0u;
+                upl = cul; up = V; upr = cur;
+                cul = dnl; cur = dnr;
             }
         }
-        if (!__any((lake_any & 0xffu) != 0u)) {   // nothing in this tile can move, ever
+        {
+            uint32_t tot = nirr;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o);
+            if (tot && lane == 0) atomicAdd(&a.counters[C_IRREGULAR], (unsigned long long)tot);
+        }
+        // the raster border cells inside this window are sources: their distance 0 is read by every later visit (and by
+        // ng_assemble), so somebody has to write it
+        if (ti == 0 || tj == 0 || last_row < WN - 1 || c0 + WN - 1 >= W - 1) {
+#pragma unroll
+            for (int r = 0; r < WN; ++r) {
+                const bool brow = (ti == 0 && r == 0) | (r == last_row && last_row == (int)(H - 1 - r0));
+                const bool bcell = r <= last_row && col_in && (brow | (tj == 0 && lane == 0) | (cc == W - 1));
+                if (bcell) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, lane * 4, r * Wi * 4, 0);
+            }
+        }
+        if (!__any((lake_any & 0xffu) != 0u)) {   // nothing in this tile can move, ever: all its cells are sources
             if (lane == 0) a.hdr[t] = 0u;
+            const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
+            if (lane_ok) {
+#pragma unroll
+                for (int r = 1; r <= TI; ++r)
+                    if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, lane * 4, r * Wi * 4, 0);
+            }
             return;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -339,9 +351,6 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < WN; ++r) __builtin_amdgcn_raw_buffer_store_b32(ni[r], rb, lane * 4, r * WN * 4, 0);
-        // distances: a flat cell starts unreached, a source is 0
-#pragma unroll
-        for (int r = 0; r < WN; ++r) d[r] = ((ni[r] >> 8) & 0xffu) != 255u ? DINF : 0u;
         __builtin_amdgcn_sched_barrier(0);
         // one class in the whole window?  (from the words that stay live anyway: the adjacency byte is inverted by now)
         uint32_t esel = 255u;
@@ -379,13 +388,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
 #pragma unroll
         for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
-        // distances: a flat cell's lives in memory, a source's is 0 wherever its tile never stored one
         int so = 0;
 #pragma unroll
         for (int r = 0; r < WN; ++r) {
-            const uint32_t dv = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), so * 4, 0);
+            d[r] = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), so * 4, 0);
             so = r < last_row ? so + Wi : so;
-            d[r] = ((ni[r] >> 8) & 0xffu) != 255u ? dv : 0u;
         }
     }
     ++visits;
@@ -466,37 +473,26 @@ __global__ __launch_bounds__(1024) void ng_compact_kernel(unsigned long long *ma
 }
 
 // ---- G = F + u * D -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ng_assemble_kernel(const float *__restrict__ F, const uint16_t *__restrict__ m16, const uint32_t *__restrict__ d,
-                                                          double *__restrict__ G, int64_t n, unsigned long long *counters)
+__global__ __launch_bounds__(256) void ng_assemble_kernel(const float *__restrict__ F, const uint32_t *__restrict__ d, double *__restrict__ G, int64_t n,
+                                                          unsigned long long *counters)
 {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     unsigned bad = 0;
+    // a source has distance 0: G = F whatever its class
+    auto value = [&](float f, uint32_t dd) {
+        bad += dd >= 0x80000000u ? 1u : 0u;     // a flat cell nobody reached (or a distance beyond the uint32 headroom)
+        const uint32_t e = class_above(f);
+        return dd ? (double)f + (double)dd * class_ulp(e) : (double)f;
+    };
     if (i0 + 4 <= n) {
         const float4 f = *reinterpret_cast<const float4 *>(F + i0);
-        const ushort4 m = *reinterpret_cast<const ushort4 *>(m16 + i0);
         const uint4 dv = *reinterpret_cast<const uint4 *>(d + i0);
-        const float fv[4] = {f.x, f.y, f.z, f.w};
-        const unsigned mv[4] = {m.x, m.y, m.z, m.w};
-        const uint32_t dd[4] = {dv.x, dv.y, dv.z, dv.w};
-        double g[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool flat = (mv[k] >> 8) != 255u;
-            bad += (flat && dd[k] >= 0x80000000u) ? 1u : 0u;
-            g[k] = flat ? (double)fv[k] + (double)dd[k] * class_ulp(mv[k] >> 8) : (double)fv[k];
-        }
         typedef double __attribute__((ext_vector_type(2))) v2d;
-        *reinterpret_cast<v2d *>(G + i0) = v2d{g[0], g[1]};
-        *reinterpret_cast<v2d *>(G + i0 + 2) = v2d{g[2], g[3]};
+        *reinterpret_cast<v2d *>(G + i0) = v2d{value(f.x, dv.x), value(f.y, dv.y)};
+        *reinterpret_cast<v2d *>(G + i0 + 2) = v2d{value(f.z, dv.z), value(f.w, dv.w)};
     } else {
-        for (int64_t i = i0; i < n; ++i) {
-            const unsigned mv = m16[i];
-            const bool flat = (mv >> 8) != 255u;
-            const uint32_t dd = flat ? d[i] : 0u;
-            bad += (flat && dd >= 0x80000000u) ? 1u : 0u;
-            G[i] = flat ? (double)F[i] + (double)dd * class_ulp(mv >> 8) : (double)F[i];
-        }
+        for (int64_t i = i0; i < n; ++i) G[i] = value(F[i], d[i]);
     }
     if (bad) atomicAdd(&counters[C_UNREACHED], (unsigned long long)bad);
 }
@@ -589,14 +585,13 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
     const int64_t nt = (int64_t)ntr * ntc;
     constexpr int MAXR = 4096, BATCH = 16;
     auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t o_d = 0, o_m = align(o_d + 4 * (size_t)n), o_tab = align(o_m + 2 * (size_t)n), o_cnt = align(o_tab + 2048);
+    const size_t o_d = 0, o_tab = align(o_d + 4 * (size_t)n), o_cnt = align(o_tab + 2048);
     const size_t o_any = align(o_cnt + 8 * (C_STATS + 128)), o_mark = align(o_any + 4 * (size_t)(MAXR + BATCH));
     const size_t o_list = align(o_mark + (size_t)nt + 8), o_hdr = align(o_list + 4 * (size_t)nt), o_blk = align(o_hdr + 4 * (size_t)nt);
     DevBuf ws;
     MH_TRY(ws.alloc(o_blk + 4 * (size_t)nt * WN * WN + 256));
     char *b = ws.as<char>();
     uint32_t *d_d = reinterpret_cast<uint32_t *>(b + o_d);
-    uint16_t *d_m = reinterpret_cast<uint16_t *>(b + o_m);
     uint32_t *d_tab = reinterpret_cast<uint32_t *>(b + o_tab);
     unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(b + o_cnt);
     uint32_t *d_any = reinterpret_cast<uint32_t *>(b + o_any);
@@ -605,17 +600,6 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
     uint32_t *d_hdr = reinterpret_cast<uint32_t *>(b + o_hdr), *d_blk = reinterpret_cast<uint32_t *>(b + o_blk);
     MH_HIP(hipMemsetAsync(b + o_cnt, 0, o_list - o_cnt, s));
     MH_HIP(hipMemcpyAsync(d_tab, tab.data(), 2048, hipMemcpyHostToDevice, s));
-
-    hipLaunchKernelGGL(ng_classify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + CRB - 1) / CRB)), dim3(256), 0, s, d_filled, H, W, d_tab, d_m,
-                       d_cnt);
-    MH_HIP(hipGetLastError());
-    unsigned long long h_cnt[4] = {0, 0, 0, 0};
-    MH_HIP(hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
-    if (h_cnt[C_IRREGULAR]) {
-        if (debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells: float64 relaxation\n", h_cnt[C_IRREGULAR]);
-        return MHIP_ELIMIT;
-    }
 
     const size_t lds = (4 * WN * (WN + 1) + 512) * sizeof(uint32_t);
     {
@@ -631,7 +615,7 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
         }
     }
     GeoArgs a;
-    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.nt = (int)nt; a.m16 = d_m; a.d = d_d; a.tab = d_tab; a.counters = d_cnt; a.blk = d_blk; a.hdr = d_hdr;
+    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.nt = (int)nt; a.F = d_filled; a.d = d_d; a.tab = d_tab; a.counters = d_cnt; a.blk = d_blk; a.hdr = d_hdr;
     const unsigned grid = (unsigned)std::min<int64_t>((nt + 3) / 4, 512);
     int round = 0, used = 0;
     bool active = true;
@@ -640,7 +624,8 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
             set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
             return MHIP_ENOTCONV;
         }
-        for (int k = 0; k < BATCH; ++k, ++round) {
+        const int nb = round == 0 ? 1 : BATCH;      // the first round alone: it also says whether this path applies at all
+        for (int k = 0; k < nb; ++k, ++round) {
             a.maxcyc = round == 0 ? firstcyc : maxcyc;
             a.mark = d_mark;
             a.list = d_list;
@@ -652,11 +637,22 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
             else hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), lds, s, a);
         }
         MH_HIP(hipGetLastError());
+        if (nb == 1) {
+            unsigned long long h_irr = 0;
+            MH_HIP(hipMemcpyAsync(&h_irr, d_cnt + C_IRREGULAR, 8, hipMemcpyDeviceToHost, s));
+            MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
+            ++used;
+            if (h_irr) {
+                if (debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells: float64 relaxation\n", h_irr);
+                return MHIP_ELIMIT;
+            }
+            continue;
+        }
         uint32_t h_any[BATCH];
         MH_HIP(hipMemcpyAsync(h_any, d_any + (round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         for (int k = 0; k < BATCH; ++k) {
-            if (round - BATCH + k > 0 && !h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
+            if (!h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
                 active = false;
                 break;
             }
@@ -664,7 +660,7 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
         }
     }
 
-    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, d_filled, d_m, d_d, d_out, n, d_cnt);
+    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, d_filled, d_d, d_out, n, d_cnt);
     hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg,
                        d_cnt);
     MH_HIP(hipGetLastError());

@@ -1456,6 +1456,7 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "fill_tiles") *value = c->fill_st.tiles;
     else if (k == "fill_algorithm") *value = c->fill_st.algorithm;   // 0 iterative tile schedule, 1 tiled priority-flood
     else if (k == "fill_launches") *value = c->fill_st.rounds;
+    else if (k == "noflat_algorithm") *value = c->noflat_st.algorithm;   // 0 float64 relaxation (fill.hip), 2 integer geodesic transform (noflat_geo.hip)
     else if (k == "noflat_visits") *value = c->noflat_st.visits;
     else if (k == "noflat_cycles") *value = c->noflat_st.cycles;
     else if (k == "H") *value = c->H;

@@ -114,13 +114,13 @@ class DemSource(object):
         return out
 
 
-KERNEL_OF_STAGE = {"fill": "fill stage kernels (see stages.fill)", "noflat": "fill_round_kernel<double, ...> (one launch per round)",
+KERNEL_OF_STAGE = {"fill": "fill stage kernels (see stages.fill)", "noflat": "ng_first_kernel + ng_round_kernel (one launch per round) + ng_assemble / ng_verify",
                    "flowdir": "d8_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "depths + ccl_* + stats_kernel",
                    "watershed": "ws_* + count_kernel", "pourpoints": "arg_packed_kernel"}
 # FETCH_SIZE under-counts wide coalesced streaming reads by 2 on gfx950 (MI355X_MICROARCH.md, HBM section): the correction
 # applies per kernel, by its load width (16 B per lane), not to the tile loads (4 / 8 B per lane) of the fills
-FETCH_X2 = ("d8_kernel", "depths_kernel", "minmax_kernel", "pf_apply_kernel", "noflat_seed_kernel")
-STAGE_KERNELS = {"flowdir": ("d8_kernel",), "fill": ("fill_round_kernel<float", "pf_"), "noflat": ("fill_round_kernel<double", "noflat_"),
+FETCH_X2 = ("d8_kernel", "depths_kernel", "minmax_kernel", "pf_apply_kernel", "noflat_seed_kernel", "ng_assemble_kernel")
+STAGE_KERNELS = {"flowdir": ("d8_kernel",), "fill": ("fill_round_kernel<float", "pf_"), "noflat": ("fill_round_kernel<double", "noflat_", "ng_"),
                  "accum": ("accum_",), "label": ("ccl_", "stats_", "depths_kernel"), "watershed": ("ws_", "count_kernel"),
                  "pourpoints": ("arg_",)}
 
@@ -366,11 +366,12 @@ def main():
                          "frac_of_hbm_peak": round(gbs / (HBM_PEAK_GBS * world), 4)}
         dominant = max(stage_names, key=lambda s: stage_ms[s])
         d8 = stages["flowdir"]
-        copy_gbs = None
+        copy_gbs = read_gbs = None
         try:
             copy_gbs = round(pipe.copy_bandwidth(), 1) if pipe is not None else None
+            read_gbs = round(pipe.read_bandwidth(), 1) if pipe is not None else None
         except Exception:
-            copy_gbs = None
+            copy_gbs = read_gbs = None
         chain = "fill -> no-flats fill -> D8" if config2 else ("fill+depths -> no-flats fill -> D8 -> accumulation -> CCL+label_stats -> "
                                                                "watersheds+label_count -> pour points")
         launches_key = {"fill": "fill_launches" if "fill_launches" in info else "fill_rounds", "noflat": "noflat_rounds"}.get(dominant, "")
@@ -386,11 +387,12 @@ def main():
                          "launches_per_step": info.get(launches_key, 1),
                          "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": pmc_traffic(dominant, n) if not band_mode else None,
-                         "measured_copy_peak_GBs": copy_gbs,
+                         "measured_copy_peak_GBs": copy_gbs, "measured_read_peak_GBs": read_gbs,
                          "note": "dominant stage by %s; algorithmic bytes of the whole stage / stage time" % (
                              "host wall clock of the slowest band (rank 0)" if band_mode else "device time (HIP events on the stage's stream)")},
             "d8_roofline": {"bound": "hbm", "kernel": "d8_kernel", "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
                             "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "frac_of_measured_copy_peak": round(d8["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
+                            "frac_of_measured_read_peak": round(d8["achieved_GBs"] / read_gbs, 4) if read_gbs else None,
                             "traffic": pmc_traffic("flowdir", n) if not band_mode else None},
             "stages": stages,
         }

@@ -47,6 +47,8 @@ int mhip_set_device(int device);             /* device used by the calling threa
 /* measurement aid: rate of a 16-byte-per-lane device-to-device copy of `bytes` (read + written bytes per second, GB/s),
  * i.e. the achievable share of the HBM spec peak on this device; reported next to the roofline fractions by bench.py */
 int mhip_copy_bandwidth(int64_t bytes, int32_t reps, double *gbs);
+/* ... and of a read-only stream of 16-byte loads (the ceiling of a kernel that reads much more than it writes) */
+int mhip_read_bandwidth(int64_t bytes, int32_t reps, double *gbs);
 
 /* ---- whole-stage entry points on HOST rasters (upload -> kernels -> download) ----------------- */
 

@@ -28,7 +28,7 @@ RASTER_DTYPE = {R_DEM: np.float32, R_FILLED: np.float32, R_DEPTHS: np.float32, R
 
 # every symbol include/malstroem_hip.h declares (checked by tests/test_cabi.py)
 SYMBOLS = [
-    "mhip_last_error", "mhip_version", "mhip_device_count", "mhip_set_device", "mhip_copy_bandwidth",
+    "mhip_last_error", "mhip_version", "mhip_device_count", "mhip_set_device", "mhip_copy_bandwidth", "mhip_read_bandwidth",
     "mhip_fill_f32", "mhip_fill_noflat_f64", "mhip_short_diag", "mhip_depths_f32", "mhip_d8_f64", "mhip_accum",
     "mhip_ccl8_f32", "mhip_ccl8_u8", "mhip_relabel_keep", "mhip_keep_mask", "mhip_label_stats_f32", "mhip_label_stats_f64",
     "mhip_label_argmin_f64", "mhip_label_argmax_f64", "mhip_label_count", "mhip_label_max", "mhip_watersheds_i32",

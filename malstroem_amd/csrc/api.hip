@@ -149,6 +149,13 @@ int mhip_set_device(int device)
     return MHIP_OK;
 }
 
+int mhip_read_bandwidth(int64_t bytes, int32_t reps, double *gbs)
+{
+    MH_ARG(bytes >= (1 << 20) && reps >= 1 && gbs, "read_bandwidth(bytes >= 1 MiB, reps >= 1, gbs)");
+    MH_TRY(require_device());
+    return read_bandwidth_dev((size_t)bytes & ~size_t(15), reps, gbs, 0);
+}
+
 int mhip_copy_bandwidth(int64_t bytes, int32_t reps, double *gbs)
 {
     MH_ARG(bytes >= (1 << 20) && reps >= 1 && gbs, "copy_bandwidth(bytes >= 1 MiB, reps >= 1, gbs)");

@@ -154,6 +154,7 @@ int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_ou
 int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
 int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s);
+int read_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s);
 int row_update_async(void *d_dst, const void *d_src, int64_t nbytes, int *d_changed, hipStream_t s);
 // trace.hip
 int trace_downstream_dev(const uint8_t *d_fd, const int32_t *d_lab, int64_t H, int64_t W, const int64_t *d_cells, int64_t n, int use_bg,

@@ -17,7 +17,6 @@ namespace {
 
 constexpr int CPL = 4;             // columns per lane
 constexpr int STRIP = 64 * CPL;    // columns per wavefront
-constexpr int ROWS_PER_WAVE = 64;  // rows a wavefront walks down (2 extra halo rows are re-read)
 constexpr int DPP_WF_SL1 = 0x130, DPP_WF_SR1 = 0x138;
 
 __device__ __forceinline__ double lane_from_left(double v)
@@ -40,14 +39,22 @@ struct Row6 {
 };
 
 // Loads raster row `rr` (clamped into the raster; clamped values are never used for an interior cell).
+typedef double v2d __attribute__((ext_vector_type(2)));
+template <bool NT>
 __device__ __forceinline__ void load_row(const double *__restrict__ z, int64_t rr, int64_t H, int64_t W, int64_t c,
                                          int lane, bool fast, Row6 &o)
 {
     rr = rr < 0 ? 0 : (rr >= H ? H - 1 : rr);
     const double *row = z + rr * W;
     if (fast) {
-        const double2 a = *reinterpret_cast<const double2 *>(row + c);
-        const double2 b = *reinterpret_cast<const double2 *>(row + c + 2);
+        v2d a, b;
+        if (NT) {   // streamed once: do not let the surface push the flow directions out of L2
+            a = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(row + c));
+            b = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(row + c + 2));
+        } else {
+            a = *reinterpret_cast<const v2d *>(row + c);
+            b = *reinterpret_cast<const v2d *>(row + c + 2);
+        }
         o.v[1] = a.x; o.v[2] = a.y; o.v[3] = b.x; o.v[4] = b.y;
         double l = lane_from_left(o.v[4]), r = lane_from_right(o.v[1]);
         if (lane == 0) l = row[c > 0 ? c - 1 : 0];
@@ -105,6 +112,8 @@ __device__ __forceinline__ unsigned edge_code(int64_t r, int64_t c, int64_t maxr
 
 // row_off / Hg: row band of a larger raster (local row r is global row r + row_off of Hg rows); only global border
 // rows get the border codes, the band's halo rows are computed from clamped data and overwritten by the host.
+// ROWS_PER_WAVE: rows a wavefront walks down (2 extra halo rows are re-read); PF: rows loaded ahead of the one being computed
+template <int ROWS_PER_WAVE, bool NT, int PF>
 __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, uint8_t *__restrict__ out, int64_t H,
                                                 int64_t W, int edges_outward, int64_t row_off, int64_t Hg)
 {
@@ -122,11 +131,13 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
     const bool fast = (c0 + STRIP <= W) && ((W & 1) == 0);
     const bool store32 = (c0 + STRIP <= W) && ((W & 3) == 0);
 
-    Row6 up, mid, dn;
-    load_row(z, r_begin - 1, H, W, c, lane, fast, up);
-    load_row(z, r_begin, H, W, c, lane, fast, mid);
+    Row6 up, mid, dn, nx;
+    load_row<NT>(z, r_begin - 1, H, W, c, lane, fast, up);
+    load_row<NT>(z, r_begin, H, W, c, lane, fast, mid);
+    if (PF == 2) load_row<NT>(z, r_begin + 1, H, W, c, lane, fast, dn);
     for (int64_t r = r_begin; r < r_end; ++r) {
-        load_row(z, r + 1, H, W, c, lane, fast, dn);
+        if (PF == 2) load_row<NT>(z, r + 2, H, W, c, lane, fast, nx);   // in flight while row r is computed from (up, mid, dn)
+        else load_row<NT>(z, r + 1, H, W, c, lane, fast, dn);
         unsigned packed = 0;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
@@ -150,6 +161,7 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
         }
         up = mid;
         mid = dn;
+        if (PF == 2) dn = nx;
     }
 }
 
@@ -159,8 +171,11 @@ int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_ou
            int64_t Hg)
 {
     if (Hg <= 0) Hg = H;
-    const dim3 grid((unsigned)cdiv(cdiv(W, STRIP), 4), (unsigned)cdiv(H, ROWS_PER_WAVE));
-    hipLaunchKernelGGL(d8_kernel, grid, dim3(256), 0, s, d_z, d_out, H, W, edges_outward, row_off, Hg);
+    // measured at 16384^2 (stage time, HIP events): 64 rows per wave 0.538 ms, 128 rows 0.524 (fewer halo rows re-read);
+    // non-temporal loads 0.56-0.58, a second row in flight 0.54-0.62: the kernel is not waiting for memory latency
+    constexpr int RPW = 128;
+    hipLaunchKernelGGL((d8_kernel<RPW, false, 1>), dim3((unsigned)cdiv(cdiv(W, STRIP), 4), (unsigned)cdiv(H, RPW)), dim3(256), 0, s, d_z, d_out, H, W,
+                       edges_outward, row_off, Hg);
     MH_HIP(hipGetLastError());
     return MHIP_OK;
 }

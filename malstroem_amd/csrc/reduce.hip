@@ -122,7 +122,45 @@ __global__ __launch_bounds__(256) void copy16_kernel(const v4f *__restrict__ src
     }
     for (; i < n; i += stride) dst[i] = src[i];
 }
+// read-only stream: the ceiling of a kernel that reads far more than it writes (D8: 8 B in, 1 B out per cell)
+__global__ __launch_bounds__(256) void read16_kernel(const v4f *__restrict__ src, float *__restrict__ sink, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const v4f a = __builtin_nontemporal_load(&src[i]), b = __builtin_nontemporal_load(&src[i + stride]);
+        const v4f c = __builtin_nontemporal_load(&src[i + 2 * stride]), d = __builtin_nontemporal_load(&src[i + 3 * stride]);
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n; i += stride) acc += src[i];
+    const float t = acc.x + acc.y + acc.z + acc.w;
+    if (t == 12345.678f) sink[0] = t;     // never true for the fill pattern: keeps the loads alive
+}
 }  // namespace
+
+int read_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s)
+{
+    DevBuf a, b;
+    MH_TRY(a.alloc(bytes));
+    MH_TRY(b.alloc(256));
+    MH_HIP(hipMemsetAsync(a.p, 1, bytes, s));
+    const int64_t n = (int64_t)(bytes / 16);
+    hipEvent_t e0, e1;
+    MH_HIP(hipEventCreate(&e0));
+    MH_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(read16_kernel, dim3(256 * 32), dim3(256), 0, s, a.as<v4f>(), b.as<float>(), n);   // warm-up
+    MH_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(read16_kernel, dim3(256 * 32), dim3(256), 0, s, a.as<v4f>(), b.as<float>(), n);
+    MH_HIP(hipEventRecord(e1, s));
+    MH_HIP(hipStreamSynchronize(s));
+    float ms = 0;
+    MH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbs = ms > 0 ? (double)(n * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return MHIP_OK;
+}
 
 int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s)
 {

@@ -119,6 +119,13 @@ class HydroPipeline(object):
         _lib.call("mhip_copy_bandwidth", _lib.i64(nbytes), ctypes.c_int32(reps), ctypes.byref(gbs))
         return gbs.value
 
+    @staticmethod
+    def read_bandwidth(nbytes=1 << 30, reps=10):
+        """GB/s of a read-only stream of 16-byte loads (what a kernel that mostly reads, like D8, can hope for)."""
+        gbs = ctypes.c_double(0)
+        _lib.call("mhip_read_bandwidth", _lib.i64(nbytes), ctypes.c_int32(reps), ctypes.byref(gbs))
+        return gbs.value
+
     def get_int(self, key):
         v = ctypes.c_int64(0)
         _lib.call("mhip_ctx_get_i64", self._ctx, key.encode(), ctypes.byref(v))

@@ -148,7 +148,9 @@ enum mhip_stage {
 
 enum mhip_raster {
     MHIP_R_DEM = 0, MHIP_R_FILLED, MHIP_R_DEPTHS, MHIP_R_NOFLAT, MHIP_R_FLOWDIR, MHIP_R_ACCUM,
-    MHIP_R_LABELS, MHIP_R_WATERSHEDS, MHIP_R_COUNT_
+    MHIP_R_LABELS, MHIP_R_WATERSHEDS,
+    MHIP_R_NGDIST,   /* uint32: distances of the geodesic no-flats fill (row bands exchange its edge rows), see mhip_ctx_geo_begin */
+    MHIP_R_COUNT_
 };
 
 /* Single-GPU context for an H x W raster on `device`. */
@@ -193,6 +195,16 @@ int mhip_ctx_fill_halo_changed(mhip_ctx *ctx, int kind, int side);
  * whose halo a neighbour's probe saw drop) */
 int mhip_ctx_fill_certify(mhip_ctx *ctx, int kind, int32_t *changed);
 int mhip_ctx_fill_end(mhip_ctx *ctx, int kind);   /* kind 0 also computes the bluespot depths */
+/* the no-flats fill of a band as an integer geodesic distance transform (csrc/noflat_geo.hip; needs the converged plain fill
+ * incl. its halo rows).  geo_begin classifies and relaxes every tile once; *applicable == 0: a level without integer weights
+ * (a flat at elevation 0, NaN, ...) -- then EVERY band runs mhip_ctx_fill_begin(kind 1) instead.  Loop: swap the edge rows of
+ * MHIP_R_NGDIST, geo_halo_changed(side) for a halo row that changed, geo_batch (to local convergence) while anything moved
+ * anywhere.  geo_end writes MHIP_R_NOFLAT = filled + ulp * distance and checks the reference's equation (_fill.pyx:107-117) at
+ * every owned cell; *ok == 0 on any band: run the float64 relaxation (kind 1) on all of them. */
+int mhip_ctx_geo_begin(mhip_ctx *ctx, double short_, double diag, int32_t *applicable, int32_t *active);
+int mhip_ctx_geo_batch(mhip_ctx *ctx, int32_t *active);
+int mhip_ctx_geo_halo_changed(mhip_ctx *ctx, int side);
+int mhip_ctx_geo_end(mhip_ctx *ctx, int32_t *ok);
 /* accumulation on a band: mhip_ctx_zero_raster(ACCUM) once, then { mhip_ctx_run(ACCUM); swap ACCUM edge rows } until no
  * halo row changes (a halo value <= 0 means "not known yet" and blocks the cells below it). */
 int mhip_ctx_zero_raster(mhip_ctx *ctx, int which);

@@ -22,9 +22,9 @@ OK, EINVAL, EHIP, ENODEV, ELIMIT, ENOTCONV, ECOMM = 0, -1, -2, -3, -4, -5, -6
 
 STAGE_FILL, STAGE_NOFLAT, STAGE_FLOWDIR, STAGE_ACCUM = 1, 2, 4, 8
 STAGE_LABEL, STAGE_WATERSHED, STAGE_POURPOINTS, STAGE_ALL = 16, 32, 64, 0x7F
-R_DEM, R_FILLED, R_DEPTHS, R_NOFLAT, R_FLOWDIR, R_ACCUM, R_LABELS, R_WATERSHEDS = range(8)
+R_DEM, R_FILLED, R_DEPTHS, R_NOFLAT, R_FLOWDIR, R_ACCUM, R_LABELS, R_WATERSHEDS, R_NGDIST = range(9)
 RASTER_DTYPE = {R_DEM: np.float32, R_FILLED: np.float32, R_DEPTHS: np.float32, R_NOFLAT: np.float64,
-                R_FLOWDIR: np.uint8, R_ACCUM: np.float64, R_LABELS: np.int32, R_WATERSHEDS: np.int32}
+                R_FLOWDIR: np.uint8, R_ACCUM: np.float64, R_LABELS: np.int32, R_WATERSHEDS: np.int32, R_NGDIST: np.uint32}
 
 # every symbol include/malstroem_hip.h declares (checked by tests/test_cabi.py)
 SYMBOLS = [
@@ -40,6 +40,7 @@ SYMBOLS = [
     "mhip_ctx_band_info", "mhip_ctx_get_edge_row", "mhip_ctx_set_halo_row", "mhip_ctx_get_edge_row_dev",
     "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_certify", "mhip_ctx_fill_end",
+    "mhip_ctx_geo_begin", "mhip_ctx_geo_batch", "mhip_ctx_geo_halo_changed", "mhip_ctx_geo_end",
     "mhip_ctx_zero_raster", "mhip_ctx_band_accum_boundary", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_watershed_local",
     "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_records", "mhip_ctx_band_fetch", "mhip_ctx_band_gather",
     "mhip_ctx_band_foreign_counts", "mhip_ctx_side_begin", "mhip_ctx_side_end",

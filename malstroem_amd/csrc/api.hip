@@ -444,6 +444,7 @@ struct mhip_ctx {
     int64_t H_global = 0, row0 = 0, H_owned = 0;
     int ht = 0, hb = 0;     // 1 if a halo row (copy of the neighbouring band's edge row) sits above / below the owned rows
     FillRun *run[2] = {nullptr, nullptr};   // resumable fill (plain, no-flats) in band mode
+    GeoRun *geo = nullptr;                  // ... and the geodesic no-flats fill
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     DevBuf r[MHIP_R_COUNT_];
@@ -467,7 +468,7 @@ struct mhip_ctx {
 static size_t raster_elem(int which)
 {
     switch (which) {
-    case MHIP_R_DEM: case MHIP_R_FILLED: case MHIP_R_DEPTHS: case MHIP_R_LABELS: case MHIP_R_WATERSHEDS: return 4;
+    case MHIP_R_DEM: case MHIP_R_FILLED: case MHIP_R_DEPTHS: case MHIP_R_LABELS: case MHIP_R_WATERSHEDS: case MHIP_R_NGDIST: return 4;
     case MHIP_R_NOFLAT: case MHIP_R_ACCUM: return 8;
     case MHIP_R_FLOWDIR: return 1;
     default: return 0;
@@ -551,6 +552,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
     }
     for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label})
         if (e) (void)hipEventDestroy(e);
+    delete c->geo;
     delete c->run[0];
     delete c->run[1];
     comm_destroy(c->comm);
@@ -1016,6 +1018,10 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
     const int which = kind ? MHIP_R_NOFLAT : MHIP_R_FILLED;
     MH_TRY(ctx_raster(c, which));
     delete c->run[kind];
+    if (kind) {   // a geodesic run that was abandoned (another band found it not applicable)
+        delete c->geo;
+        c->geo = nullptr;
+    }
     FillRun *f = c->run[kind] = new FillRun();
     f->noflat = kind != 0;
     f->dem = c->r[MHIP_R_DEM].as<float>();
@@ -1077,6 +1083,69 @@ int mhip_ctx_fill_end(mhip_ctx *c, int kind)
         MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(),
                           c->H * c->W, c->stream));
         c->have[MHIP_R_DEPTHS] = true;
+    }
+    return MHIP_OK;
+}
+
+/* the no-flats fill of a band as an integer geodesic distance transform (noflat_geo.hip) */
+int mhip_ctx_geo_begin(mhip_ctx *c, double short_, double diag, int32_t *applicable, int32_t *active)
+{
+    MH_ARG(c && applicable && active && c->have[MHIP_R_DEM] && c->have[MHIP_R_FILLED], "ctx_geo_begin(ctx, short, diag, applicable, active) needs the plain fill");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, MHIP_R_NOFLAT));
+    MH_TRY(ctx_raster(c, MHIP_R_NGDIST));
+    delete c->geo;
+    GeoRun *g = c->geo = new GeoRun();
+    g->dem = c->r[MHIP_R_DEM].as<float>();
+    g->filled = c->r[MHIP_R_FILLED].as<float>();
+    g->out = c->r[MHIP_R_NOFLAT].as<double>();
+    g->dist = c->r[MHIP_R_NGDIST].as<uint32_t>();
+    g->H = c->H; g->W = c->W; g->sh = short_; g->dg = diag;
+    g->fixed_top = c->ht; g->fixed_bot = c->hb;
+    c->sh = short_; c->dg = diag;
+    bool ap = false, ac = false;
+    MH_TRY(g->begin(c->stream, &ap, &ac));
+    *applicable = ap ? 1 : 0;
+    *active = ac ? 1 : 0;
+    if (!ap) {
+        delete c->geo;
+        c->geo = nullptr;
+    }
+    c->have[MHIP_R_NGDIST] = ap;
+    return MHIP_OK;
+}
+
+int mhip_ctx_geo_batch(mhip_ctx *c, int32_t *active)
+{
+    MH_ARG(c && active && c->geo, "ctx_geo_batch needs ctx_geo_begin");
+    MH_HIP(hipSetDevice(c->device));
+    bool a = false;
+    MH_TRY(c->geo->batch(c->stream, &a));
+    *active = a ? 1 : 0;
+    return MHIP_OK;
+}
+
+int mhip_ctx_geo_halo_changed(mhip_ctx *c, int side)
+{
+    MH_ARG(c && c->geo && (side == 0 || side == 1), "ctx_geo_halo_changed needs ctx_geo_begin");
+    MH_HIP(hipSetDevice(c->device));
+    return c->geo->halo_changed(side, c->stream);
+}
+
+int mhip_ctx_geo_end(mhip_ctx *c, int32_t *ok)
+{
+    MH_ARG(c && ok && c->geo, "ctx_geo_end needs ctx_geo_begin");
+    MH_HIP(hipSetDevice(c->device));
+    FillStats st;
+    bool good = false;
+    MH_TRY(c->geo->end(c->stream, &good, &st));
+    delete c->geo;
+    c->geo = nullptr;
+    *ok = good ? 1 : 0;
+    if (good) {
+        c->noflat_rounds = st.rounds;
+        c->noflat_st = st;
+        c->have[MHIP_R_NOFLAT] = true;
     }
     return MHIP_OK;
 }

@@ -141,6 +141,26 @@ int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipSt
                    bool *depths_done = nullptr);
 // pflood.hip
 int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st);
+// noflat_geo.hip: the no-flats fill as an integer geodesic distance transform; resumable for row bands
+struct GeoRun {
+    const float *dem = nullptr, *filled = nullptr;   // local raster incl. halo rows; `filled` = the converged plain fill
+    double *out = nullptr;                            // the no-flats surface (written by end())
+    uint32_t *dist = nullptr;                         // distances, H * W (nullptr: kept in the run's own workspace)
+    int64_t H = 0, W = 0;
+    double sh = 0, dg = 0;
+    int fixed_top = 0, fixed_bot = 0;
+    struct Impl;
+    Impl *impl;
+    GeoRun();
+    ~GeoRun();
+    GeoRun(const GeoRun &) = delete;
+    GeoRun &operator=(const GeoRun &) = delete;
+    int begin(hipStream_t s, bool *applicable, bool *active);
+    int batch(hipStream_t s, bool *active);
+    int halo_changed(int side, hipStream_t s);
+    int end(hipStream_t s, bool *ok, FillStats *st);
+    int launch_rounds(hipStream_t s, int nb);
+};
 // noflat_geo.hip: MHIP_ELIMIT = not applicable, run the float64 relaxation
 int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                              FillStats *st);

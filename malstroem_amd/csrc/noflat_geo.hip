@@ -91,6 +91,7 @@ struct GeoArgs {
     const uint32_t *tab;            // [256] S | [256] Dg by class
     unsigned long long *counters;
     int maxcyc;                     // local cycles per visit in this round
+    int fixed_top, fixed_bot;       // row band: local row 0 / H - 1 is a halo row of the neighbouring band (not a raster border, not mine)
 };
 
 // 64 x 64 transpose of 32-bit words through a wave-private LDS scratch [64][65].  The DS instructions are written out: one
@@ -271,9 +272,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 const float V = f[r], dn = r + 1 < WN ? f[r + 1] : PINF;
                 const float dnl = r + 1 < WN ? fleft(dn) : PINF, dnr = r + 1 < WN ? fright(dn) : PINF;
                 const bool lower = (upl < V) | (up < V) | (upr < V) | (cul < V) | (cur < V) | (dnl < V) | (dn < V) | (dnr < V);
-                const bool border = lane_border | (ti == 0 && r == 0) | (r >= border_row);
+                // raster border rows are sources; a band's halo rows are the neighbour's cells (ring-like: never moved here, known
+                // only as far as this window can tell); window rows beyond the local raster are nothing
+                const bool border = lane_border | (ti == 0 && r == 0 && !a.fixed_top) | (r == border_row && !a.fixed_bot) | (r > border_row);
                 const bool src = lower | border;
-                const bool ring = (r == 0) | (r == WN - 1) | ring_lane;
+                const bool ring = (r == 0) | (r == WN - 1) | ring_lane | (r >= border_row);
                 uint32_t w = M_NOFLAT;
                 bool unreached = ring & !src;
                 if (!ring) {
@@ -305,8 +308,9 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         if (ti == 0 || tj == 0 || last_row < WN - 1 || c0 + WN - 1 >= W - 1) {
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
-                const bool brow = (ti == 0 && r == 0) | (r == last_row && last_row == (int)(H - 1 - r0));
-                const bool bcell = r <= last_row && col_in && (brow | (tj == 0 && lane == 0) | (cc == W - 1));
+                const bool brow = (ti == 0 && r == 0 && !a.fixed_top) | (r == last_row && last_row == (int)(H - 1 - r0) && !a.fixed_bot);
+                const bool halo = (ti == 0 && r == 0 && a.fixed_top) | (r == last_row && last_row == (int)(H - 1 - r0) && a.fixed_bot);
+                const bool bcell = r <= last_row && col_in && !halo && (brow | (tj == 0 && lane == 0) | (cc == W - 1));
                 if (bcell) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, lane * 4, r * Wi * 4, 0);
             }
         }
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256) void ng_assemble_kernel(const float *__restric
 // ---- the strict equation (*) at every cell, in the reference's arithmetic (_fill.pyx:107-117) ------------------------------
 constexpr int VRB = 16;   // rows per thread
 __global__ __launch_bounds__(256) void ng_verify_kernel(const float *__restrict__ dem, const double *__restrict__ G, int64_t H, int64_t W, double sh,
-                                                        double dg, unsigned long long *counters)
+                                                        double dg, int fixed_top, int fixed_bot, unsigned long long *counters)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t rb = (int64_t)blockIdx.y * VRB;
@@ -530,7 +534,8 @@ __global__ __launch_bounds__(256) void ng_verify_kernel(const float *__restrict_
             const double me = fmin(fmin(a[1], b[0]), fmin(b[2], n[1])) + sh;
             want = fmax(fmin(md, me), dv);
         }
-        bad += (own == want) ? 0u : 1u;   // NaN anywhere fails too
+        const bool halo = (r == 0 && fixed_top) || (r == H - 1 && fixed_bot);   // the neighbouring band checks its own rows
+        bad += (own == want || halo) ? 0u : 1u;   // NaN anywhere fails too
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             a[k] = b[k];
@@ -557,18 +562,66 @@ uint32_t class_weight(double eps, int e)
 
 }  // namespace
 
-// MHIP_OK: d_out holds the verified no-flats surface.  MHIP_ELIMIT: not applicable to this raster (irregular levels, a cell the
-// verification rejects, ...): the caller runs the float64 relaxation.
-int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                             FillStats *st)
+// ---- the resumable run (a row band refreshes its halo rows between batches) --------------------------------------------
+struct GeoRun::Impl {
+    DevBuf ws;
+    uint32_t *d_tab = nullptr, *d_any = nullptr, *d_hdr = nullptr, *d_blk = nullptr;
+    unsigned long long *d_cnt = nullptr;
+    uint8_t *d_mark = nullptr;
+    int *d_list = nullptr;
+    int ntr = 0, ntc = 0, round = 0, used = 0;
+    int64_t nt = 0;
+    size_t lds = 0;
+    int maxcyc = NG_MAXCYC, firstcyc = NG_FIRSTCYC;
+    bool debug = false;
+};
+namespace {
+constexpr int MAXR = 8192, BATCH = 16;
+__global__ void ng_mark_row_kernel(uint8_t *mark, int ti, int ntc)
 {
+    const int tj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tj < ntc) mark[(int64_t)ti * ntc + tj] = 1;
+}
+}  // namespace
+
+GeoRun::GeoRun() : impl(new Impl) {}
+GeoRun::~GeoRun() { delete impl; }
+
+int GeoRun::launch_rounds(hipStream_t s, int nb)
+{
+    Impl &m = *impl;
+    GeoArgs a;
+    a.H = H; a.W = W; a.ntr = m.ntr; a.ntc = m.ntc; a.nt = (int)m.nt; a.F = filled; a.d = dist; a.tab = m.d_tab; a.counters = m.d_cnt;
+    a.blk = m.d_blk; a.hdr = m.d_hdr; a.mark = m.d_mark; a.list = m.d_list; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot;
+    const unsigned grid = (unsigned)std::min<int64_t>((m.nt + 3) / 4, 512);
+    for (int k = 0; k < nb; ++k, ++m.round) {
+        a.maxcyc = m.round == 0 ? m.firstcyc : m.maxcyc;
+        a.count = m.d_any + m.round;     // tiles of this round (round 0: every tile)
+        if (m.round) {
+            hipLaunchKernelGGL(ng_compact_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(m.d_mark), (int)((m.nt + 7) / 8),
+                               m.d_list, m.d_any + m.round);
+            hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), m.lds, s, a);
+        } else {
+            hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), m.lds, s, a);
+        }
+    }
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+// The first round: every tile is classified and relaxed once.  *applicable == false: the raster holds flat cells of a level
+// without integer weights (or NaNs, or the epsilons give no weights at all): run the float64 relaxation instead.
+int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
+{
+    Impl &m = *impl;
     static const bool off = [] { const char *e = getenv("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
-    static const bool debug = getenv("MHIP_NG_DEBUG") != nullptr;
-    const int maxcyc = getenv("MHIP_NG_MAXCYC") ? atoi(getenv("MHIP_NG_MAXCYC")) : NG_MAXCYC;        // tuning knobs (development)
-    const int firstcyc = getenv("MHIP_NG_FIRSTCYC") ? atoi(getenv("MHIP_NG_FIRSTCYC")) : NG_FIRSTCYC;
-    if (off || !d_filled || H < 3 || W < 3) return MHIP_ELIMIT;
-    if (!(sh > 0.0) || !(dg > 0.0) || std::isinf(sh) || std::isinf(dg)) return MHIP_ELIMIT;
-    const int64_t n = H * W;
+    m.debug = getenv("MHIP_NG_DEBUG") != nullptr;
+    if (getenv("MHIP_NG_MAXCYC")) m.maxcyc = atoi(getenv("MHIP_NG_MAXCYC"));        // tuning knobs (development)
+    if (getenv("MHIP_NG_FIRSTCYC")) m.firstcyc = atoi(getenv("MHIP_NG_FIRSTCYC"));
+    *applicable = false;
+    *active = false;
+    if (off || !filled || H < 3 || W < 3) return MHIP_OK;
+    if (!(sh > 0.0) || !(dg > 0.0) || std::isinf(sh) || std::isinf(dg)) return MHIP_OK;
     std::vector<uint32_t> tab(512, 0u);
     bool any_class = false;
     for (int e = 0; e < 255; ++e) {
@@ -579,29 +632,33 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
             any_class = true;
         }
     }
-    if (!any_class) return MHIP_ELIMIT;
+    if (!any_class) return MHIP_OK;
 
-    const int ntr = (int)((H - 2 + TI - 1) / TI), ntc = (int)((W - 2 + TI - 1) / TI);
-    const int64_t nt = (int64_t)ntr * ntc;
-    constexpr int MAXR = 4096, BATCH = 16;
+    const int64_t n = H * W;
+    m.ntr = (int)((H - 2 + TI - 1) / TI);
+    m.ntc = (int)((W - 2 + TI - 1) / TI);
+    m.nt = (int64_t)m.ntr * m.ntc;
     auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
-    const size_t o_d = 0, o_tab = align(o_d + 4 * (size_t)n), o_cnt = align(o_tab + 2048);
+    const size_t o_d = 0, o_tab = align(o_d + (dist ? 0 : 4 * (size_t)n)), o_cnt = align(o_tab + 2048);
     const size_t o_any = align(o_cnt + 8 * (C_STATS + 128)), o_mark = align(o_any + 4 * (size_t)(MAXR + BATCH));
-    const size_t o_list = align(o_mark + (size_t)nt + 8), o_hdr = align(o_list + 4 * (size_t)nt), o_blk = align(o_hdr + 4 * (size_t)nt);
-    DevBuf ws;
-    MH_TRY(ws.alloc(o_blk + 4 * (size_t)nt * WN * WN + 256));
-    char *b = ws.as<char>();
-    uint32_t *d_d = reinterpret_cast<uint32_t *>(b + o_d);
-    uint32_t *d_tab = reinterpret_cast<uint32_t *>(b + o_tab);
-    unsigned long long *d_cnt = reinterpret_cast<unsigned long long *>(b + o_cnt);
-    uint32_t *d_any = reinterpret_cast<uint32_t *>(b + o_any);
-    uint8_t *d_mark = reinterpret_cast<uint8_t *>(b + o_mark);
-    int *d_list = reinterpret_cast<int *>(b + o_list);
-    uint32_t *d_hdr = reinterpret_cast<uint32_t *>(b + o_hdr), *d_blk = reinterpret_cast<uint32_t *>(b + o_blk);
+    const size_t o_list = align(o_mark + (size_t)m.nt + 8), o_hdr = align(o_list + 4 * (size_t)m.nt), o_blk = align(o_hdr + 4 * (size_t)m.nt);
+    MH_TRY(m.ws.alloc(o_blk + 4 * (size_t)m.nt * WN * WN + 256));
+    char *b = m.ws.as<char>();
+    if (!dist) dist = reinterpret_cast<uint32_t *>(b + o_d);
+    m.d_tab = reinterpret_cast<uint32_t *>(b + o_tab);
+    m.d_cnt = reinterpret_cast<unsigned long long *>(b + o_cnt);
+    m.d_any = reinterpret_cast<uint32_t *>(b + o_any);
+    m.d_mark = reinterpret_cast<uint8_t *>(b + o_mark);
+    m.d_list = reinterpret_cast<int *>(b + o_list);
+    m.d_hdr = reinterpret_cast<uint32_t *>(b + o_hdr);
+    m.d_blk = reinterpret_cast<uint32_t *>(b + o_blk);
     MH_HIP(hipMemsetAsync(b + o_cnt, 0, o_list - o_cnt, s));
-    MH_HIP(hipMemcpyAsync(d_tab, tab.data(), 2048, hipMemcpyHostToDevice, s));
+    MH_HIP(hipMemcpyAsync(m.d_tab, tab.data(), 2048, hipMemcpyHostToDevice, s));
+    // a band's halo rows belong to the neighbour: "not reached yet" (an upper bound) until the first exchange brings its values
+    if (fixed_top) MH_HIP(hipMemsetAsync(dist, 0xE0, 4 * (size_t)W, s));
+    if (fixed_bot) MH_HIP(hipMemsetAsync(dist + (H - 1) * W, 0xE0, 4 * (size_t)W, s));
 
-    const size_t lds = (4 * WN * (WN + 1) + 512) * sizeof(uint32_t);
+    m.lds = (4 * WN * (WN + 1) + 512) * sizeof(uint32_t);
     {
         static std::mutex mu;
         static bool attr_done[64] = {};
@@ -609,91 +666,111 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
         MH_HIP(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 0 || dev >= 64 || !attr_done[dev]) {
-            MH_HIP(hipFuncSetAttribute((const void *)ng_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            MH_HIP(hipFuncSetAttribute((const void *)ng_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            MH_HIP(hipFuncSetAttribute((const void *)ng_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds));
+            MH_HIP(hipFuncSetAttribute((const void *)ng_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m.lds));
             if (dev >= 0 && dev < 64) attr_done[dev] = true;
         }
     }
-    GeoArgs a;
-    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.nt = (int)nt; a.F = d_filled; a.d = d_d; a.tab = d_tab; a.counters = d_cnt; a.blk = d_blk; a.hdr = d_hdr;
-    const unsigned grid = (unsigned)std::min<int64_t>((nt + 3) / 4, 512);
-    int round = 0, used = 0;
-    bool active = true;
-    while (active) {
-        if (round + BATCH > MAXR) {
+    m.round = 0;
+    m.used = 0;
+    MH_TRY(launch_rounds(s, 1));
+    unsigned long long h_irr = 0;
+    MH_HIP(hipMemcpyAsync(&h_irr, m.d_cnt + C_IRREGULAR, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
+    m.used = 1;
+    if (h_irr) {
+        if (m.debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells: float64 relaxation\n", h_irr);
+        return MHIP_OK;
+    }
+    *applicable = true;
+    *active = true;
+    return MHIP_OK;
+}
+
+// rounds until nothing is marked any more (locally converged: *active = false on return)
+int GeoRun::batch(hipStream_t s, bool *active)
+{
+    Impl &m = *impl;
+    for (;;) {
+        if (m.round + BATCH > MAXR) {
             set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
             return MHIP_ENOTCONV;
         }
-        const int nb = round == 0 ? 1 : BATCH;      // the first round alone: it also says whether this path applies at all
-        for (int k = 0; k < nb; ++k, ++round) {
-            a.maxcyc = round == 0 ? firstcyc : maxcyc;
-            a.mark = d_mark;
-            a.list = d_list;
-            a.count = d_any + round;     // tiles of round `round` (round 0: every tile)
-            if (round)
-                hipLaunchKernelGGL(ng_compact_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(d_mark), (int)((nt + 7) / 8), d_list,
-                                   d_any + round);
-            if (round) hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), lds, s, a);
-            else hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), lds, s, a);
-        }
-        MH_HIP(hipGetLastError());
-        if (nb == 1) {
-            unsigned long long h_irr = 0;
-            MH_HIP(hipMemcpyAsync(&h_irr, d_cnt + C_IRREGULAR, 8, hipMemcpyDeviceToHost, s));
-            MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
-            ++used;
-            if (h_irr) {
-                if (debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells: float64 relaxation\n", h_irr);
-                return MHIP_ELIMIT;
-            }
-            continue;
-        }
+        MH_TRY(launch_rounds(s, BATCH));
         uint32_t h_any[BATCH];
-        MH_HIP(hipMemcpyAsync(h_any, d_any + (round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(h_any, m.d_any + (m.round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         for (int k = 0; k < BATCH; ++k) {
             if (!h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
-                active = false;
-                break;
+                *active = false;
+                return MHIP_OK;
             }
-            ++used;
+            ++m.used;
         }
     }
+}
 
-    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, d_filled, d_d, d_out, n, d_cnt);
-    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg,
-                       d_cnt);
+int GeoRun::halo_changed(int side, hipStream_t s)
+{
+    Impl &m = *impl;
+    hipLaunchKernelGGL(ng_mark_row_kernel, dim3((unsigned)((m.ntc + 255) / 256)), dim3(256), 0, s, m.d_mark, side == 0 ? 0 : m.ntr - 1, m.ntc);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+// G = F + u * D over the whole local raster, then the reference's equation at every owned cell.  *ok == false: a cell failed.
+int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
+{
+    Impl &m = *impl;
+    const int64_t n = H * W;
+    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, m.d_cnt);
+    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, dem, out, H, W, sh, dg,
+                       fixed_top, fixed_bot, m.d_cnt);
     MH_HIP(hipGetLastError());
     unsigned long long h_all[C_STATS + 128];
-    MH_HIP(hipMemcpyAsync(h_all, d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
+    MH_HIP(hipMemcpyAsync(h_all, m.d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     if (st) {
         *st = FillStats();
-        st->rounds = used;
-        st->tiles = nt;
+        st->rounds = m.used;
+        st->tiles = m.nt;
         st->algorithm = 2;
         for (int k = 0; k < 64; ++k) {
             st->visits += (int64_t)h_all[C_STATS + 2 * k];
             st->cycles += (int64_t)h_all[C_STATS + 2 * k + 1];
         }
     }
-    if (debug) {
-        std::vector<uint32_t> cnt((size_t)round);
-        MH_HIP(hipMemcpy(cnt.data(), d_any, 4 * (size_t)round, hipMemcpyDeviceToHost));
+    if (m.debug) {
+        std::vector<uint32_t> cnt((size_t)m.round);
+        MH_HIP(hipMemcpy(cnt.data(), m.d_any, 4 * (size_t)m.round, hipMemcpyDeviceToHost));
         unsigned long long v = 0, cy = 0;
         for (int k = 0; k < 64; ++k) {
             v += h_all[C_STATS + 2 * k];
             cy += h_all[C_STATS + 2 * k + 1];
         }
-        fprintf(stderr, "[noflat geodesic] tiles %lld, visits %llu, cycles %llu; tiles per round:", (long long)nt, v, cy);
-        for (int k = 1; k < used; ++k) fprintf(stderr, " %u", cnt[k]);
-        fprintf(stderr, "\n");
-    }
-    if (debug)
-        fprintf(stderr, "[noflat geodesic] %lld x %lld: rounds %d, unreached %llu, mismatches %llu\n", (long long)H, (long long)W, used, h_all[C_UNREACHED],
+        fprintf(stderr, "[noflat geodesic] tiles %lld, visits %llu, cycles %llu; tiles per round:", (long long)m.nt, v, cy);
+        for (int k = 1; k < m.round && k < 200; ++k) fprintf(stderr, " %u", cnt[k]);
+        fprintf(stderr, "\n[noflat geodesic] %lld x %lld: rounds %d, unreached %llu, mismatches %llu\n", (long long)H, (long long)W, m.used, h_all[C_UNREACHED],
                 h_all[C_MISMATCH]);
-    if (h_all[C_UNREACHED] || h_all[C_MISMATCH]) return MHIP_ELIMIT;
+    }
+    *ok = !(h_all[C_UNREACHED] || h_all[C_MISMATCH]);
+    m.ws.release();
     return MHIP_OK;
+}
+
+// MHIP_OK: d_out holds the verified no-flats surface.  MHIP_ELIMIT: not applicable to this raster (irregular levels, a cell the
+// verification rejects, ...): the caller runs the float64 relaxation.
+int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
+                             FillStats *st)
+{
+    GeoRun g;
+    g.dem = d_dem; g.filled = d_filled; g.out = d_out; g.H = H; g.W = W; g.sh = sh; g.dg = dg;
+    bool applicable = false, active = false, ok = false;
+    MH_TRY(g.begin(s, &applicable, &active));
+    if (!applicable) return MHIP_ELIMIT;
+    while (active) MH_TRY(g.batch(s, &active));
+    MH_TRY(g.end(s, &ok, st));
+    return ok ? MHIP_OK : MHIP_ELIMIT;
 }
 
 }  // namespace mh

@@ -18,6 +18,7 @@ package itself never imports it).  Without RCCL (one GPU shared by several bands
 tests) the rows travel through the ``Comm`` as host buffers.  The compute backend is ``HipBand`` (the C-ABI band context).
 """
 import ctypes
+import os
 import pickle
 import queue
 import socket
@@ -408,6 +409,27 @@ class HipBand(object):
     def fill_end(self, kind):
         _lib.call("mhip_ctx_fill_end", self._ctx, int(kind))
 
+    # the no-flats fill as an integer geodesic distance transform (csrc/noflat_geo.hip); edge rows of raster "ngdist" travel
+    def geo_begin(self, short, diag):
+        """-> (applicable, active).  Not applicable (a flat at elevation 0, NaN, ...): run the float64 relaxation (kind 1)."""
+        ap, ac = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.call("mhip_ctx_geo_begin", self._ctx, ctypes.c_double(short), ctypes.c_double(diag), ctypes.byref(ap), ctypes.byref(ac))
+        return bool(ap.value), bool(ac.value)
+
+    def geo_batch(self):
+        active = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_geo_batch", self._ctx, ctypes.byref(active))
+        return bool(active.value)
+
+    def geo_halo_changed(self, side):
+        _lib.call("mhip_ctx_geo_halo_changed", self._ctx, int(side))
+
+    def geo_end(self):
+        """writes the no-flats surface and checks the reference's equation at every owned cell -> all cells passed?"""
+        ok = ctypes.c_int32(0)
+        _lib.call("mhip_ctx_geo_end", self._ctx, ctypes.byref(ok))
+        return bool(ok.value)
+
     def run_flowdir(self):
         _lib.call("mhip_ctx_run", self._ctx, STAGE_FLOWDIR)
         _lib.call("mhip_ctx_sync", self._ctx)
@@ -658,7 +680,50 @@ class BandPipeline(object):
     def noflat(self):
         """fill.fill_terrain_no_flats over all bands (needs fill())."""
         short, diag = self.short_and_diag()
+        if hasattr(self.band, "geo_begin") and os.environ.get("MALSTROEM_BAND_NOFLAT", "") != "relaxation" and self._noflat_geodesic(short, diag):
+            return
         self._fill(1, "noflat", short, diag)
+
+    def _noflat_geodesic(self, short, diag):
+        """The integer geodesic transform of csrc/noflat_geo.hip on bands: every band classifies and relaxes its tiles, then
+        { neighbours trade the edge rows of the DISTANCES; a band whose halo row changed relaxes again } until nothing moves
+        anywhere -- one exchange per crossing of a seam by a geodesic inside a flat, not one per batch of tile rounds.  Returns
+        False (on every rank alike) when the path does not apply to this DEM or a band's final check fails: the caller then
+        runs the float64 relaxation."""
+        b = self.band
+        self.exchanges["noflat"] = 0
+        err, applicable, active = None, True, False
+        try:
+            applicable, active = b.geo_begin(short, diag)
+        except Exception as e:
+            err = e
+        if self._vote(not applicable, err):          # some band holds a level without integer weights
+            return False
+        while True:
+            busy = False
+            try:
+                ch_top, ch_bot = self._swap_edges("ngdist")
+                self.exchanges["noflat"] += 1
+                if ch_top:
+                    b.geo_halo_changed(0)
+                if ch_bot:
+                    b.geo_halo_changed(1)
+                busy = active or ch_top or ch_bot
+            except Exception as e:
+                err = e
+            if not self._vote(busy, err):
+                break
+            try:
+                if busy:
+                    active = b.geo_batch()
+            except Exception as e:
+                err = e
+        ok = False
+        try:
+            ok = b.geo_end()
+        except Exception as e:
+            err = e
+        return not self._vote(not ok, err)
 
     def flowdir(self):
         """D8 on the no-flats surface, edges outward; afterwards the flow-direction halo rows are valid too."""

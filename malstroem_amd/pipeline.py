@@ -10,14 +10,14 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (INDEX_DTYPE, R_ACCUM, R_DEM, R_DEPTHS, R_FILLED, R_FLOWDIR, R_LABELS, R_NOFLAT, R_WATERSHEDS,
+from ._lib import (INDEX_DTYPE, R_ACCUM, R_DEM, R_DEPTHS, R_FILLED, R_FLOWDIR, R_LABELS, R_NGDIST, R_NOFLAT, R_WATERSHEDS,
                    RASTER_DTYPE, STAGE_ACCUM, STAGE_FILL, STAGE_FLOWDIR, STAGE_LABEL, STAGE_NOFLAT,
                    STAGE_POURPOINTS, STAGE_WATERSHED, STAT_DTYPE)
 
 STAGES = {"fill": STAGE_FILL, "noflat": STAGE_NOFLAT, "flowdir": STAGE_FLOWDIR, "accum": STAGE_ACCUM,
           "label": STAGE_LABEL, "watershed": STAGE_WATERSHED, "pourpoints": STAGE_POURPOINTS}
 RASTERS = {"dem": R_DEM, "filled": R_FILLED, "depths": R_DEPTHS, "noflat": R_NOFLAT, "flowdir": R_FLOWDIR,
-           "accum": R_ACCUM, "labels": R_LABELS, "watersheds": R_WATERSHEDS}
+           "accum": R_ACCUM, "labels": R_LABELS, "watersheds": R_WATERSHEDS, "ngdist": R_NGDIST}
 
 
 class HydroPipeline(object):

@@ -51,7 +51,7 @@ class CpuBand(object):
 
     def _dtype(self, name):
         return {"dem": np.float32, "filled": np.float32, "depths": np.float32, "noflat": np.float64, "flowdir": np.uint8,
-                "accum": np.float64, "labels": np.int32, "watersheds": np.int32}[name]
+                "accum": np.float64, "labels": np.int32, "watersheds": np.int32, "ngdist": np.uint32}[name]
 
     def _raster(self, name):
         if name not in self.r:
@@ -140,6 +140,79 @@ class CpuBand(object):
 
     def fill_halo_changed(self, kind, side):
         pass
+
+    # ---- stand-in for the geodesic no-flats engine (csrc/noflat_geo.hip): same protocol, numpy arithmetic
+    GEO_INF = 0xE0000000
+
+    def geo_begin(self, short, diag):
+        F = self.r["filled"].astype(np.float64)
+        H, W = self.H, self.W
+        gr = np.arange(H) + (self.row0 - self.ht)
+        border = np.zeros((H, W), bool)
+        border[(gr == 0) | (gr == self.Hg - 1), :] = True
+        border[:, 0] = border[:, -1] = True
+        owned = np.zeros((H, W), bool)
+        owned[self.ht:self.ht + self.nrows] = True
+        P = np.pad(F, 1, constant_values=np.nan)
+        nb = [(-1, -1, 1), (-1, 0, 0), (-1, 1, 1), (0, -1, 0), (0, 1, 0), (1, -1, 1), (1, 0, 0), (1, 1, 1)]
+        lower = np.zeros((H, W), bool)
+        self._geo_same = []
+        with np.errstate(invalid="ignore"):
+            for dr, dc, dg in nb:
+                N = P[1 + dr:1 + dr + H, 1 + dc:1 + dc + W]
+                lower |= N < F
+                self._geo_same.append((dr, dc, dg, N == F))
+        flat = owned & ~border & ~lower
+        up = np.nextafter(F, np.inf)
+        with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+            u = np.nextafter(up, np.inf) - up
+            Su, Du = short / u, diag / u
+        regular = np.isfinite(F) & (F != 0) & (np.rint(Su) == Su) & (Su >= 1) & (Du < 2 ** 28) & (np.abs(Du - np.rint(Du)) != 0.5)
+        if (flat & ~regular).any() or np.isnan(self.r["filled"][owned]).any() or not (short > 0 and diag > 0):
+            return False, False
+        self._geo = dict(flat=flat, u=u, S=np.where(regular, np.rint(Su), 0).astype(np.int64), D=np.where(regular, np.rint(Du), 0).astype(np.int64),
+                         short=short, diag=diag)
+        d = self._raster("ngdist")
+        d[...] = np.where(flat, self.GEO_INF, 0).astype(np.uint32)
+        if self.ht:
+            d[0] = self.GEO_INF       # the neighbour's cells: unknown until the first exchange
+        if self.hb:
+            d[-1] = self.GEO_INF
+        self._geo_relax()
+        return True, True
+
+    def _geo_relax(self):
+        g, H, W = self._geo, self.H, self.W
+        INF = np.int64(self.GEO_INF)
+        d = self.r["ngdist"].astype(np.int64)
+        while True:
+            Pd = np.pad(d, 1, constant_values=INF)
+            best = d.copy()
+            for dr, dc, dg, same in self._geo_same:
+                N = Pd[1 + dr:1 + dr + H, 1 + dc:1 + dc + W]
+                cand = np.where(same & g["flat"], np.minimum(N + (g["D"] if dg else g["S"]), INF), INF)
+                best = np.minimum(best, cand)
+            if np.array_equal(best, d):
+                break
+            d = best
+        self.r["ngdist"][...] = d.astype(np.uint32)
+
+    def geo_halo_changed(self, side):
+        pass
+
+    def geo_batch(self):
+        self._geo_relax()
+        return False
+
+    def geo_end(self):
+        F = self.r["filled"].astype(np.float64)
+        d = self.r["ngdist"].astype(np.float64)
+        up = np.nextafter(F, np.inf)
+        with np.errstate(over="ignore", invalid="ignore"):
+            u = np.nextafter(up, np.inf) - up
+            G = np.where(d > 0, F + d * u, F)
+        self._raster("noflat")[...] = G
+        return bool((self.r["ngdist"] < 0x80000000).all())
 
     def fill_end(self, kind):
         if kind == 0:

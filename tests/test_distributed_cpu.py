@@ -163,6 +163,36 @@ def test_solve_band_accum_forest():
     assert halos[1][0].tolist() == [0, 1, 1] and halos[2][0].tolist() == [1, 1, 0] and halos[1][1].tolist() == [0, 3, 1]
 
 
+@pytest.mark.parametrize("case", ["geodesic", "sea-at-zero-in-one-band"])
+def test_band_noflat_engines(case):
+    """the no-flats fill of the bands: the integer geodesic transform (a handful of exchanges), and the float64 relaxation every
+    band falls back to when ONE band holds a flat at elevation 0"""
+    dem = fbm(96, 80, beta=2.0, seed=8) + np.float32(2.0)
+    if case != "geodesic":
+        dem[70:90, :40] = 0.0          # reaches the raster border: stays a flat at level 0 after the fill (band 2 of 3 only)
+    short, diag = oracle.minimum_safe_short_and_diag(dem)
+    want = oracle.fill_terrain_no_flats(dem, short, diag)
+    out = [None] * 3
+
+    def work(comm):
+        p = BandPipeline(comm, dem.shape, backend_factory=CpuBand)
+        p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+        p.fill()
+        took = p._noflat_geodesic(*p.short_and_diag())
+        if not took:
+            p._fill(1, "noflat", *p.short_and_diag())
+        out[comm.rank] = (p.download("noflat"), took, p.exchanges["noflat"])
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(3)]
+    [t.start() for t in threads]
+    [t.join(300) for t in threads]
+    assert all(o is not None for o in out)
+    assert np.array_equal(np.concatenate([o[0] for o in out]), want)
+    assert [o[1] for o in out] == [case == "geodesic"] * 3
+    if case == "geodesic":
+        assert out[0][2] <= 8
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))

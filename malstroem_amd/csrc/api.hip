@@ -445,6 +445,7 @@ struct mhip_ctx {
     int ht = 0, hb = 0;     // 1 if a halo row (copy of the neighbouring band's edge row) sits above / below the owned rows
     FillRun *run[2] = {nullptr, nullptr};   // resumable fill (plain, no-flats) in band mode
     GeoRun *geo = nullptr;                  // ... and the geodesic no-flats fill
+    PfRun *pf = nullptr;                    // ... and the tiled priority-flood (plain fill)
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     DevBuf r[MHIP_R_COUNT_];
@@ -553,6 +554,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
     for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label})
         if (e) (void)hipEventDestroy(e);
     delete c->geo;
+    delete c->pf;
     delete c->run[0];
     delete c->run[1];
     comm_destroy(c->comm);
@@ -1017,6 +1019,27 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
     MH_HIP(hipSetDevice(c->device));
     const int which = kind ? MHIP_R_NOFLAT : MHIP_R_FILLED;
     MH_TRY(ctx_raster(c, which));
+    if (kind == 0) {
+        // the tiled priority-flood first: the band's whole local solve happens here, the loop that follows only trades edge rows
+        static const bool force_iter = [] { const char *e = getenv("MHIP_FILL"); return e && std::string(e) == "iterative"; }();
+        delete c->pf;
+        c->pf = nullptr;
+        if (!force_iter) {
+            PfRun *p = new PfRun();
+            p->dem = c->r[MHIP_R_DEM].as<float>();
+            p->out = c->r[MHIP_R_FILLED].as<float>();
+            p->H = c->H; p->W = c->W;
+            p->fixed_top = c->ht; p->fixed_bot = c->hb;
+            const int rc = p->begin(c->stream);
+            if (rc == MHIP_OK) {
+                c->pf = p;
+                *active = 0;
+                return MHIP_OK;
+            }
+            delete p;
+            if (rc != MHIP_ELIMIT) return rc;
+        }
+    }
     delete c->run[kind];
     if (kind) {   // a geodesic run that was abandoned (another band found it not applicable)
         delete c->geo;
@@ -1043,8 +1066,28 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
 
 int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
 {
-    MH_ARG(c && active && (kind == 0 || kind == 1) && c->run[kind], "ctx_fill_batch needs ctx_fill_begin");
+    MH_ARG(c && active && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_batch needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
+    if (kind == 0 && c->pf) {
+        const int rc = c->pf->batch(c->stream);
+        *active = 0;
+        if (rc != MHIP_ELIMIT) return rc;
+        // a capacity gave out while the halo links were rebuilt: start the iterative schedule instead (its edge rows are upper
+        // bounds of the final surface like the ones published so far: the neighbours' state stays valid)
+        delete c->pf;
+        c->pf = nullptr;
+        FillRun *f = c->run[0] = new FillRun();
+        f->noflat = false;
+        f->dem = c->r[MHIP_R_DEM].as<float>();
+        f->out = c->r[MHIP_R_FILLED].p;
+        f->H = c->H; f->W = c->W;
+        f->fixed_top = c->ht; f->fixed_bot = c->hb;
+        f->rounds_per_batch = 16;
+        bool a0 = false;
+        MH_TRY(f->begin(c->stream, &a0));
+        *active = a0;
+        return MHIP_OK;
+    }
     bool a = false;
     MH_TRY(c->run[kind]->batch(c->stream, &a));
     *active = a;
@@ -1053,8 +1096,12 @@ int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
 
 int mhip_ctx_fill_certify(mhip_ctx *c, int kind, int32_t *changed)
 {
-    MH_ARG(c && changed && (kind == 0 || kind == 1) && c->run[kind], "ctx_fill_certify needs ctx_fill_begin");
+    MH_ARG(c && changed && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_certify needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
+    if (kind == 0 && c->pf) {   // nothing to certify: the flood is not a worklist schedule
+        *changed = 0;
+        return MHIP_OK;
+    }
     bool ch = false;
     MH_TRY(c->run[kind]->certify(c->stream, &ch));
     *changed = ch ? 1 : 0;
@@ -1063,19 +1110,26 @@ int mhip_ctx_fill_certify(mhip_ctx *c, int kind, int32_t *changed)
 
 int mhip_ctx_fill_halo_changed(mhip_ctx *c, int kind, int side)
 {
-    MH_ARG(c && (kind == 0 || kind == 1) && c->run[kind] && (side == 0 || side == 1), "ctx_fill_halo_changed needs ctx_fill_begin");
+    MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)) && (side == 0 || side == 1), "ctx_fill_halo_changed needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
+    if (kind == 0 && c->pf) return c->pf->halo_changed(side, c->stream);
     return c->run[kind]->activate_row(side, c->stream);
 }
 
 int mhip_ctx_fill_end(mhip_ctx *c, int kind)
 {
-    MH_ARG(c && (kind == 0 || kind == 1) && c->run[kind], "ctx_fill_end needs ctx_fill_begin");
+    MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_end needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
     FillStats st;
-    MH_TRY(c->run[kind]->finish(c->stream, &st));
-    delete c->run[kind];
-    c->run[kind] = nullptr;
+    if (kind == 0 && c->pf) {
+        MH_TRY(c->pf->finish(c->stream, nullptr, &st));
+        delete c->pf;
+        c->pf = nullptr;
+    } else {
+        MH_TRY(c->run[kind]->finish(c->stream, &st));
+        delete c->run[kind];
+        c->run[kind] = nullptr;
+    }
     if (kind) { c->noflat_rounds = st.rounds; c->noflat_st = st; c->have[MHIP_R_NOFLAT] = true; }
     else {
         c->fill_rounds = st.rounds; c->fill_st = st; c->have[MHIP_R_FILLED] = true;

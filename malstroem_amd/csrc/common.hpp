@@ -141,6 +141,26 @@ int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipSt
                    bool *depths_done = nullptr);
 // pflood.hip
 int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st);
+// pflood.hip: the exact tiled priority-flood, resumable for row bands (whose halo rows of `out` carry the neighbours' current
+// estimates of their filled edge rows; this band's own edge rows in `out` are kept current for them)
+struct PfRun {
+    const float *dem = nullptr;
+    float *out = nullptr;            // the filled surface
+    int64_t H = 0, W = 0;
+    int fixed_top = 0, fixed_bot = 0;
+    struct Impl;
+    Impl *impl;
+    PfRun();
+    ~PfRun();
+    PfRun(const PfRun &) = delete;
+    PfRun &operator=(const PfRun &) = delete;
+    int begin(hipStream_t s);                     // MHIP_ELIMIT: not applicable (capacity, band alignment): run the iterative schedule
+    int halo_changed(int side, hipStream_t s);
+    int batch(hipStream_t s);                     // MHIP_ELIMIT as above
+    int finish(hipStream_t s, float *d_depths, FillStats *st);
+    int solve(hipStream_t s);
+    int publish_edges(hipStream_t s);
+};
 // noflat_geo.hip: the no-flats fill as an integer geodesic distance transform; resumable for row bands
 struct GeoRun {
     const float *dem = nullptr, *filled = nullptr;   // local raster incl. halo rows; `filled` = the converged plain fill

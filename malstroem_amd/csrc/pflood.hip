@@ -61,7 +61,9 @@ struct PfArgs {
     unsigned long long *spill;  // [ntiles * SPMAX]  (la << 40 | lb << 32 | w)
     int *tileNS;            // [ntiles]
     unsigned long long *links;  // [ntiles * LMAX]   (myLab << 48 | dir << 40 | nbrLab << 32 | w)
-    int *tileNL;            // [ntiles]
+    int *tileNL;            // [ntiles] links of the tile = tileNL0 links between tiles + the band's halo links
+    int *tileNL0;           // [ntiles]
+    int fixed_top, fixed_bot;   // row band: local row 0 / H - 1 is a halo row of the neighbouring band (a ring row, not a raster border)
     uint32_t *Lv;           // [ntiles * NSMAX] minimax level of every seed (keys)
     unsigned int *flags;    // [0]: overflow
     unsigned long long *prof;   // -DPF_PROFILE builds: clock ticks per phase of pf_tile_kernel, summed over the tiles
@@ -110,6 +112,7 @@ constexpr int EPT = HE / NT;       // (compacted) basin pairs per thread in the 
 
 struct WinGeom {
     int64_t r0, c0, H, W;
+    int fixed_top, fixed_bot;
 };
 // class of window cell ci: valid / raster border / window ring (the last two exclude each other)
 __device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
@@ -117,7 +120,8 @@ __device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
     const int wr = ci >> 6, wc = ci & 63;
     const int64_t rr = g.r0 + wr, cc = g.c0 + wc;
     if (rr >= g.H || cc >= g.W) return 0;
-    if (rr == 0 || rr == g.H - 1 || cc == 0 || cc == g.W - 1) return C_VALID | C_BORDER;
+    // (a band's halo rows sit on window ring rows -- PfRun::begin checks the alignment -- and are ring cells like any other)
+    if ((rr == 0 && !g.fixed_top) || (rr == g.H - 1 && !g.fixed_bot) || cc == 0 || cc == g.W - 1) return C_VALID | C_BORDER;
     if (wr == 0 || wr == WN - 1 || wc == 0 || wc == WN - 1) return C_VALID | C_RING;
     return C_VALID;
 }
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
     const int t = threadIdx.x, wc = t & 63, q = t >> 6;
     const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
     WinGeom g;
-    g.r0 = (int64_t)ti * TI; g.c0 = (int64_t)tj * TI; g.H = a.H; g.W = a.W;
+    g.r0 = (int64_t)ti * TI; g.c0 = (int64_t)tj * TI; g.H = a.H; g.W = a.W; g.fixed_top = a.fixed_top; g.fixed_bot = a.fixed_bot;
     const int64_t W = a.W;
     uint32_t *hk = hkv, *hv = hkv + HE;
     static_assert(2 * HE == NC, "plateau ids / drains (one 16-bit word per cell each) share the hash arrays");
@@ -653,7 +657,10 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
         return;
     }
     for (int i = s_cnt + t; i < LMAX; i += 256) a.links[(size_t)tile * LMAX + i] = ~0ull;
-    if (t == 0) a.tileNL[tile] = s_cnt;
+    if (t == 0) {
+        a.tileNL[tile] = s_cnt;
+        a.tileNL0[tile] = s_cnt;
+    }
 #ifdef PF_PROFILE
     if (t == 0) atomicAdd(&a.prof[12], (unsigned long long)s_cnt);
 #endif
@@ -831,6 +838,7 @@ __global__ __launch_bounds__(256) void pf_apply_kernel(PfArgs a, float *__restri
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= groups * H) return;
     const int64_t r = g / groups, c4 = (g - r * groups) * 4;
+    if ((r == 0 && a.fixed_top) || (r == H - 1 && a.fixed_bot)) return;   // a band's halo rows belong to the neighbour
     const bool rowb = r == 0 || r == H - 1;
     const int ti = (int)((r - 1) / TI);
     const int64_t i0 = r * W + c4;
@@ -874,18 +882,165 @@ __global__ __launch_bounds__(256) void pf_apply_kernel(PfArgs a, float *__restri
     }
 }
 
+// ---- row bands ---------------------------------------------------------------------------------------------------------------
+// A halo row holds the neighbouring band's CURRENT estimate of its filled edge row (an upper bound of the final surface that only
+// ever drops; +inf before the first exchange).  To this band a halo cell is a ring cell whose level is that estimate: for the
+// seed s its ring position drains to,  L[s] <= estimate  -- a link from s to OCEAN with that weight.  The halo links of a tile
+// follow its tileNL0 links between tiles and are rebuilt whenever a halo row changed; the solve kernel does not know the
+// difference.  What this band owes its neighbours are the estimates of its own edge rows (pf_edge_rows_kernel).
+__global__ __launch_bounds__(128) void pf_halo_links_kernel(PfArgs a, const float *__restrict__ filled)
+{
+    __shared__ uint32_t minw[NSMAX];
+    __shared__ int s_n;
+    const int t = threadIdx.x;
+    const int tj = blockIdx.x % a.ntc, side = blockIdx.x / a.ntc;          // side 0: tile row 0, side 1: the last tile row
+    if (side == 1 && a.ntr == 1) return;                                    // one tile row: side 0 does both halo rows
+    const int ti = side == 0 ? 0 : a.ntr - 1;
+    const int tile = ti * a.ntc + tj;
+    if (t < NSMAX) minw[t] = EMPTY;
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    const int64_t c0 = (int64_t)tj * TI;
+    for (int hs = 0; hs < 2; ++hs) {                                        // top halo row (ring row 0), bottom halo row (ring row 63)
+        if (hs == 0 ? !(a.fixed_top && ti == 0) : !(a.fixed_bot && ti == a.ntr - 1)) continue;
+        const int64_t r = hs == 0 ? 0 : a.H - 1;
+        if (t < WN) {
+            const int64_t c = c0 + t;
+            if (c > 0 && c < a.W - 1) {                                     // raster border columns are OCEAN to K1 already
+                const uint32_t lab = a.ringLab[(size_t)tile * 256 + ring_pos(hs == 0 ? 0 : WN - 1, t)];
+                if (lab < (uint32_t)NSMAX) atomicMin(&minw[lab], dem_key(filled[r * a.W + c]));
+            }
+        }
+    }
+    __syncthreads();
+    const int nl0 = a.tileNL0[tile];
+    if (t < NSMAX && minw[t] != EMPTY && minw[t] < f32_key(__builtin_inff())) {
+        const int i = nl0 + atomicAdd(&s_n, 1);
+        if (i < LMAX) a.links[(size_t)tile * LMAX + i] = ((unsigned long long)((uint32_t)t << 16 | 4u << 8 | (uint32_t)OCEAN) << 32) | minw[t];
+        else atomicOr(a.flags, 1u);
+    }
+    __syncthreads();
+    const int n = min(nl0 + s_n, LMAX);
+    for (int i = n + t; i < LMAX; i += 128) a.links[(size_t)tile * LMAX + i] = ~0ull;
+    if (t == 0) a.tileNL[tile] = n;
+}
+
+// current estimate of the filled surface on local row r (an owned edge row): max(dem, V[basin], L[seed of the basin])
+__global__ __launch_bounds__(256) void pf_edge_rows_kernel(PfArgs a, float *__restrict__ filled, int64_t r)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.W) return;
+    const float d = a.dem[r * a.W + c];
+    float f = d;
+    if (c > 0 && c < a.W - 1) {
+        const int tile = (int)((r - 1) / TI) * a.ntc + (int)((c - 1) / TI);
+        const size_t i = (size_t)tile * NBMAX + a.bslot[r * a.W + c];
+        const int lab = a.tabL[i];
+        const uint32_t lev = max(a.tabV[i], lab == OCEAN ? 0u : a.Lv[(size_t)tile * NSMAX + lab]);
+        const uint32_t k = max(dem_key(d), lev);
+        f = k >= f32_key(__builtin_inff()) ? __builtin_inff() : key_f32(k);   // a seed nobody has reached yet: +inf
+    }
+    filled[r * a.W + c] = f;
+}
+
+__global__ void pf_set_bytes_kernel(uint8_t *p, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 1;
+}
+__global__ void pf_fill_f32_kernel(float *p, int64_t n, float v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 }  // namespace
 
-// Exact tiled priority-flood.  Returns MHIP_ELIMIT (without touching d_out) when a per-tile capacity was exceeded: the
-// caller then runs the iterative schedule.
-int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st)
+// ---- the resumable run -------------------------------------------------------------------------------------------------------
+struct PfRun::Impl {
+    DevBuf ws;
+    PfArgs a;
+    uint8_t *act = nullptr;
+    unsigned int *any = nullptr;
+    unsigned long long *visits = nullptr;
+    int64_t ntiles = 0;
+    size_t nslots = 0;
+    int nbr = 0, nbc = 0, round = 0, launches = 0;
+    bool halo_dirty = false;
+};
+namespace {
+constexpr int PF_MAXR = 1 << 14, PF_BATCH = 32;
+}
+
+PfRun::PfRun() : impl(new Impl) {}
+PfRun::~PfRun() { delete impl; }
+
+// rounds of the seed-graph solve until a round appends nothing
+int PfRun::solve(hipStream_t s)
 {
+    Impl &m = *impl;
+    std::vector<unsigned int> h_cnt(PF_BATCH + 1);
+    unsigned int h_flag = 0;
+    for (;;) {
+        if (m.round + PF_BATCH + 1 >= PF_MAXR) {
+            set_error("priority-flood seed graph did not converge within %d rounds", PF_MAXR);
+            return MHIP_ENOTCONV;
+        }
+        for (int k = 0; k < PF_BATCH; ++k) {
+            const int r = m.round + k;
+            SolveArgs sa;
+            sa.a = m.a;
+            sa.act_cur = m.act + (size_t)(r & 1) * m.nslots;
+            sa.act_nxt = m.act + (size_t)((r + 1) & 1) * m.nslots;
+            sa.any_nxt = m.any + r + 1;
+            sa.visits = m.visits;
+            sa.nbr = m.nbr;
+            sa.nbc = m.nbc;
+            sa.first = r == 0;
+            hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)m.nslots), dim3(ST), 0, s, sa);
+        }
+        m.launches += PF_BATCH;
+        MH_HIP(hipGetLastError());
+        MH_HIP(hipMemcpyAsync(h_cnt.data(), m.any + m.round + 1, sizeof(unsigned int) * PF_BATCH, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(&h_flag, m.a.flags, 4, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));
+        if (h_flag) return MHIP_ELIMIT;
+        if (getenv("MHIP_PF_DEBUG")) {
+            fprintf(stderr, "[pf_solve] rounds %d..%d appended work:", m.round, m.round + PF_BATCH - 1);
+            for (int k = 0; k < PF_BATCH; ++k) fprintf(stderr, " %u", h_cnt[k]);
+            fprintf(stderr, "\n");
+        }
+        m.round += PF_BATCH;     // (even: the parity of the active-byte buffers is kept)
+        for (int k = 0; k < PF_BATCH; ++k)
+            if (h_cnt[k] == 0) {   // that round appended nothing: converged; the launches after it were no-ops
+                m.launches -= PF_BATCH - (k + 1);
+                return MHIP_OK;
+            }
+    }
+}
+
+int PfRun::publish_edges(hipStream_t s)
+{
+    Impl &m = *impl;
+    const unsigned g = (unsigned)cdiv(W, 256);
+    if (fixed_top) hipLaunchKernelGGL(pf_edge_rows_kernel, dim3(g), dim3(256), 0, s, m.a, out, (int64_t)1);
+    if (fixed_bot) hipLaunchKernelGGL(pf_edge_rows_kernel, dim3(g), dim3(256), 0, s, m.a, out, H - 2);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+// tiles, links, the local solve (with the halo rows at +inf: nothing known about the neighbours yet) and the band's first edge
+// rows.  MHIP_ELIMIT: a capacity was exceeded, or a band whose bottom halo row does not sit on a window ring row.
+int PfRun::begin(hipStream_t s)
+{
+    Impl &m = *impl;
+    if (H < 3 || W < 3) return MHIP_ELIMIT;
+    if (fixed_bot && (H - 2) % TI != 0) return MHIP_ELIMIT;
     const int ntr = (int)cdiv(H - 2, TI), ntc = (int)cdiv(W - 2, TI);
     const int64_t ntiles = (int64_t)ntr * ntc;
     const size_t n = (size_t)(H * W);
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
-    // one workspace: bslot | tabV | tabL | tileNB | ringLab | spill | tileNS | links | tileNL | Lv | lists[2] | marks[2] | counters
-    constexpr int MAXR = 1 << 14;
+    // one workspace: bslot | tabV | tabL | tileNB | ringLab | spill | tileNS | links | tileNL | tileNL0 | Lv | active bytes | counters
     size_t off = 0;
     const size_t o_bslot = off; off = al(off + n * 2);
     const size_t o_tabV = off; off = al(off + (size_t)ntiles * NBMAX * 4);
@@ -896,19 +1051,21 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     const size_t o_ns = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_links = off; off = al(off + (size_t)ntiles * LMAX * 8);
     const size_t o_nl = off; off = al(off + (size_t)ntiles * 4);
+    const size_t o_nl0 = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_lv = off; off = al(off + (size_t)ntiles * NSMAX * 4);
     // solve worklist: one active byte per block of BT x BT tiles, double buffered
-    const int nbr = (int)cdiv(ntr, BT), nbc = (int)cdiv(ntc, BT);
-    const size_t nslots = (size_t)nbr * nbc;
-    const size_t o_act = off; off = al(off + nslots * 2);
-    const size_t o_cnt = off; off = al(off + (size_t)(MAXR + 2) * 4 + 64 + 32 * 8);
-    DevBuf ws;
-    MH_TRY(ws.alloc(off));
-    char *b = ws.as<char>();
+    m.nbr = (int)cdiv(ntr, BT);
+    m.nbc = (int)cdiv(ntc, BT);
+    m.nslots = (size_t)m.nbr * m.nbc;
+    m.ntiles = ntiles;
+    const size_t o_act = off; off = al(off + m.nslots * 2);
+    const size_t o_cnt = off; off = al(off + (size_t)(PF_MAXR + 2) * 4 + 64 + 32 * 8);
+    MH_TRY(m.ws.alloc(off));
+    char *b = m.ws.as<char>();
     MH_HIP(hipMemsetAsync(b + o_act, 0, off - o_act, s));                 // active bytes, per-round words, flags, visits
     MH_HIP(hipMemsetAsync(b + o_ring, NOLAB, (size_t)ntiles * 256, s));
-    PfArgs a;
-    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = d_dem;
+    PfArgs &a = m.a;
+    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = dem; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot;
     a.bslot = reinterpret_cast<uint16_t *>(b + o_bslot);
     a.tabV = reinterpret_cast<uint32_t *>(b + o_tabV);
     a.tabL = reinterpret_cast<uint8_t *>(b + o_tabL);
@@ -918,100 +1075,106 @@ int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int
     a.tileNS = reinterpret_cast<int *>(b + o_ns);
     a.links = reinterpret_cast<unsigned long long *>(b + o_links);
     a.tileNL = reinterpret_cast<int *>(b + o_nl);
+    a.tileNL0 = reinterpret_cast<int *>(b + o_nl0);
     a.Lv = reinterpret_cast<uint32_t *>(b + o_lv);
-    unsigned int *any = reinterpret_cast<unsigned int *>(b + o_cnt);      // [MAXR + 2] "round r was handed work"
-    a.flags = any + (MAXR + 2);
-    unsigned long long *visits = reinterpret_cast<unsigned long long *>(a.flags + 2);
-    a.prof = visits + 1;   // 24 words (inside the zeroed tail of the workspace)
-    uint8_t *act = reinterpret_cast<uint8_t *>(b + o_act);
+    m.any = reinterpret_cast<unsigned int *>(b + o_cnt);      // [PF_MAXR + 2] "round r was handed work"
+    a.flags = m.any + (PF_MAXR + 2);
+    m.visits = reinterpret_cast<unsigned long long *>(a.flags + 2);
+    a.prof = m.visits + 1;   // 24 words (inside the zeroed tail of the workspace)
+    m.act = reinterpret_cast<uint8_t *>(b + o_act);
+    m.round = 0;
+    m.halo_dirty = false;
 
+    if (fixed_top) hipLaunchKernelGGL(pf_fill_f32_kernel, dim3((unsigned)cdiv(W, 256)), dim3(256), 0, s, out, W, __builtin_inff());
+    if (fixed_bot) hipLaunchKernelGGL(pf_fill_f32_kernel, dim3((unsigned)cdiv(W, 256)), dim3(256), 0, s, out + (H - 1) * W, W, __builtin_inff());
     hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
     MH_HIP(hipGetLastError());
-    int launches = 2, round = 0;
-    auto launch_round = [&](int r) {
-        SolveArgs sa;
-        sa.a = a;
-        sa.act_cur = act + (size_t)(r & 1) * nslots;
-        sa.act_nxt = act + (size_t)((r + 1) & 1) * nslots;
-        sa.any_nxt = any + r + 1;
-        sa.visits = visits;
-        sa.nbr = nbr;
-        sa.nbc = nbc;
-        sa.first = r == 0;
-        hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)nslots), dim3(ST), 0, s, sa);
-    };
-    constexpr int BATCH = 32;
-    std::vector<unsigned int> h_cnt(BATCH + 1);
-    unsigned int h_flag = 0;
-    bool done = false;
-    while (!done) {
-        if (round + BATCH + 1 >= MAXR) {
-            set_error("priority-flood seed graph did not converge within %d rounds", MAXR);
-            return MHIP_ENOTCONV;
-        }
-        for (int k = 0; k < BATCH; ++k) launch_round(round + k);
-        launches += BATCH;
-        MH_HIP(hipGetLastError());
-        MH_HIP(hipMemcpyAsync(h_cnt.data(), any + round + 1, sizeof(unsigned int) * BATCH, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipMemcpyAsync(&h_flag, a.flags, 4, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
-        if (h_flag) return MHIP_ELIMIT;
-        if (getenv("MHIP_PF_DEBUG")) {
-            fprintf(stderr, "[pf_solve] rounds %d..%d appended work:", round, round + BATCH - 1);
-            for (int k = 0; k < BATCH; ++k) fprintf(stderr, " %u", h_cnt[k]);
-            fprintf(stderr, "\n");
-        }
-        for (int k = 0; k < BATCH; ++k)
-            if (h_cnt[k] == 0) {   // round (round + k) appended nothing: converged; the launches after it were no-ops
-                done = true;
-                launches -= BATCH - (k + 1);
-                break;
-            }
-        round += BATCH;
-    }
-    hipLaunchKernelGGL(pf_final_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
-    const int64_t groups = ((W + 3) / 4) * H;
-    hipLaunchKernelGGL(pf_apply_kernel, dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, s, a, d_out, d_depths);
+    m.launches = 2;
+    MH_TRY(solve(s));
+    return publish_edges(s);
+}
+
+int PfRun::halo_changed(int, hipStream_t)
+{
+    impl->halo_dirty = true;
+    return MHIP_OK;
+}
+
+// after a halo row changed: its links again, the blocks of the band's first / last tile rows, the solve, the edge rows
+int PfRun::batch(hipStream_t s)
+{
+    Impl &m = *impl;
+    if (!m.halo_dirty) return MHIP_OK;
+    m.halo_dirty = false;
+    hipLaunchKernelGGL(pf_halo_links_kernel, dim3((unsigned)(2 * m.a.ntc)), dim3(128), 0, s, m.a, (const float *)out);
+    uint8_t *cur = m.act + (size_t)(m.round & 1) * m.nslots;
+    hipLaunchKernelGGL(pf_set_bytes_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, cur, m.nbc);
+    hipLaunchKernelGGL(pf_set_bytes_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, cur + (size_t)(m.nbr - 1) * m.nbc, m.nbc);
     MH_HIP(hipGetLastError());
-    launches += 2;
+    MH_TRY(solve(s));
+    return publish_edges(s);
+}
+
+// the final level of every basin, then the raster (a band's halo rows stay as the neighbour left them)
+int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st)
+{
+    Impl &m = *impl;
+    hipLaunchKernelGGL(pf_final_kernel, dim3((unsigned)m.ntiles), dim3(256), 0, s, m.a);
+    const int64_t groups = ((W + 3) / 4) * H;
+    hipLaunchKernelGGL(pf_apply_kernel, dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, s, m.a, out, d_depths);
+    MH_HIP(hipGetLastError());
+    m.launches += 2;
 #ifdef PF_PROFILE
     {
         unsigned long long h_prof[24];
-        MH_HIP(hipMemcpyAsync(h_prof, a.prof, sizeof(h_prof), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(h_prof, m.a.prof, sizeof(h_prof), hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         const char *names[9] = {"load", "descent+plateaus", "doubling", "slots", "pairs", "compact", "label-correcting", "outputs", "spill"};
         double tot = 0;
         for (int i = 0; i < 9; ++i) tot += (double)h_prof[i];
         fprintf(stderr, "[pf_tile profile] ticks/tile:");
-        for (int i = 0; i < 9; ++i) fprintf(stderr, " %s=%.0f", names[i], (double)h_prof[i] / (double)ntiles);
-        fprintf(stderr, " | total=%.0f basins/tile=%.1f pairs/tile=%.1f seeds/tile=%.1f links/tile=%.1f spill/tile=%.1f\n", tot / (double)ntiles,
-                (double)h_prof[9] / (double)ntiles, (double)h_prof[10] / (double)ntiles, (double)h_prof[11] / (double)ntiles,
-                (double)h_prof[12] / (double)ntiles, (double)h_prof[13] / (double)ntiles);
+        for (int i = 0; i < 9; ++i) fprintf(stderr, " %s=%.0f", names[i], (double)h_prof[i] / (double)m.ntiles);
+        fprintf(stderr, " | total=%.0f basins/tile=%.1f pairs/tile=%.1f seeds/tile=%.1f links/tile=%.1f spill/tile=%.1f\n", tot / (double)m.ntiles,
+                (double)h_prof[9] / (double)m.ntiles, (double)h_prof[10] / (double)m.ntiles, (double)h_prof[11] / (double)m.ntiles,
+                (double)h_prof[12] / (double)m.ntiles, (double)h_prof[13] / (double)m.ntiles);
         {
             unsigned long long hv_ = 0;
-            (void)hipMemcpy(&hv_, visits, 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&hv_, m.visits, 8, hipMemcpyDeviceToHost);
             const double nv = (double)(hv_ ? hv_ : 1);
             fprintf(stderr, "[pf_solve, per visit] load ticks=%.0f links=%.0f spill loop=%.0f (%.1f iterations) store+push=%.0f | visits=%llu\n", (double)h_prof[19] / nv,
                     (double)h_prof[20] / nv, (double)h_prof[21] / nv, (double)h_prof[23] / nv, (double)h_prof[22] / nv, hv_);
         }
-        fprintf(stderr, "[pf_tile S5, wave 0] preload ticks=%.0f insert ticks=%.0f | per tile: candidates=%.0f live=%.0f slow-path=%.0f\n", (double)h_prof[14] / (double)ntiles,
-                (double)h_prof[15] / (double)ntiles, (double)h_prof[16] / (double)ntiles, (double)h_prof[17] / (double)ntiles, (double)h_prof[18] / (double)ntiles);
+        fprintf(stderr, "[pf_tile S5, wave 0] preload ticks=%.0f insert ticks=%.0f | per tile: candidates=%.0f live=%.0f slow-path=%.0f\n", (double)h_prof[14] / (double)m.ntiles,
+                (double)h_prof[15] / (double)m.ntiles, (double)h_prof[16] / (double)m.ntiles, (double)h_prof[17] / (double)m.ntiles, (double)h_prof[18] / (double)m.ntiles);
     }
 #endif
     if (st) {
         unsigned long long h_vis = 0;
-        MH_HIP(hipMemcpyAsync(&h_vis, visits, 8, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(&h_vis, m.visits, 8, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         *st = FillStats();
-        st->rounds = launches;
+        st->rounds = m.launches;
         st->visits = (int64_t)h_vis;
         st->cycles = 0;
-        st->tiles = ntiles;
+        st->tiles = m.ntiles;
+        st->algorithm = 1;
     } else {
-        MH_HIP(hipStreamSynchronize(s));   // the workspace goes back to the pool when this function returns
+        MH_HIP(hipStreamSynchronize(s));   // the workspace goes back to the pool now
     }
+    m.ws.release();
     return MHIP_OK;
+}
+
+
+// Exact tiled priority-flood on one raster.  Returns MHIP_ELIMIT (without touching d_out) when a per-tile capacity was
+// exceeded: the caller then runs the iterative schedule.
+int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st)
+{
+    PfRun f;
+    f.dem = d_dem; f.out = d_out; f.H = H; f.W = W;
+    MH_TRY(f.begin(s));
+    return f.finish(s, d_depths, st);
 }
 
 }  // namespace mh

@@ -34,11 +34,32 @@ from .pipeline import RASTERS
 __all__ = ["band_rows", "Comm", "SingleComm", "ThreadComm", "SocketComm", "HybridComm", "HipBand", "BandPipeline"]
 
 
-def band_rows(H, size, rank):
-    """(row0, nrows) of band ``rank``: contiguous, sizes differ by at most one row."""
-    base, extra = divmod(int(H), int(size))
-    if base < 1:
+TILE = 62     # tile edge of the fill kernels (csrc/pflood.hip, csrc/noflat_geo.hip): window 64 = tile + ring
+
+
+def band_rows(H, size, rank, align=True):
+    """(row0, nrows) of band ``rank``: contiguous row bands of near-equal height.
+
+    ``align``: the seams between bands are put on the tile grid of the fill kernels (a band's last owned row is the last row
+    of a tile: global row 62 k), so that the tiles of the bands are the tiles of the undivided raster and a band's bottom halo
+    row is a window ring row -- what the tiled priority-flood needs to run on a band (otherwise the band falls back to the
+    iterative tile schedule).  Needs at least one tile row per band; the heights then differ by at most one tile row."""
+    H, size, rank = int(H), int(size), int(rank)
+    if H < size:
         raise ValueError("more bands (%d) than raster rows (%d)" % (size, H))
+    ntr = -(-(H - 2) // TILE) if H > 2 else 0      # tile rows of the undivided raster (its border rows belong to no tile)
+    if align and size > 1 and ntr >= size:
+        # seam b (first row of band b) = the tile-grid row 1 + 62 k nearest to the equal split, kept strictly increasing
+        seams = [0]
+        for b in range(1, size):
+            k = int(round((b * H / float(size) - 1) / TILE))
+            k = max(k, (seams[-1] - 1) // TILE + 1 if seams[-1] else 1)      # at least one tile row for the band above ...
+            k = min(k, ntr - (size - b))                                     # ... and for every band below
+            seams.append(1 + TILE * k)
+        seams.append(H)
+        if all(seams[i] < seams[i + 1] for i in range(size)):
+            return seams[rank], seams[rank + 1] - seams[rank]
+    base, extra = divmod(H, size)
     row0 = rank * base + min(rank, extra)
     return row0, base + (1 if rank < extra else 0)
 
@@ -554,13 +575,13 @@ def solve_band_accum(info, W):
 class BandPipeline(object):
     """One rank's share of a row-banded DEM.  Every rank calls the same methods in the same order (SPMD)."""
 
-    def __init__(self, comm, shape, device=0, backend_factory=None, rccl=None):
-        """``rccl``: True = the bands join an RCCL communicator inside the library and move their halo rows GPU -> GPU
+    def __init__(self, comm, shape, device=0, backend_factory=None, rccl=None, align=True):
+        """``align``: seams on the tile grid of the fill kernels (see ``band_rows``).  ``rccl``: True = the bands join an RCCL communicator inside the library and move their halo rows GPU -> GPU
         (one rank per GPU required), False = rows travel through ``comm`` as host buffers, None = RCCL whenever there is
         more than one rank and the backend is the HIP one.  Creation is voted on: if any rank fails, every rank raises."""
         self.comm = comm
         self.H, self.W = int(shape[0]), int(shape[1])
-        self.row0, self.nrows = band_rows(self.H, comm.size, comm.rank)
+        self.row0, self.nrows = band_rows(self.H, comm.size, comm.rank, align)
         factory = backend_factory or HipBand
         if rccl is None:   # RCCL wants one rank per device: only transports between processes say so (SocketComm; a launcher's own)
             rccl = comm.size > 1 and factory is HipBand and bool(getattr(comm, "one_rank_per_device", False))

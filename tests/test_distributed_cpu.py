@@ -63,10 +63,16 @@ def check_records(outs, ref):
 
 
 def test_band_rows_partition():
-    for H, n in ((188, 2), (188, 3), (7, 7), (1000, 8)):
-        rows = [band_rows(H, n, r) for r in range(n)]
-        assert rows[0][0] == 0 and sum(k for _, k in rows) == H
-        assert all(rows[i][0] + rows[i][1] == rows[i + 1][0] for i in range(n - 1))
+    for H, n in ((188, 2), (188, 3), (7, 7), (1000, 8), (65536, 4), (65536, 8), (16384, 3), (64, 2), (127, 2)):
+        for align in (True, False):
+            rows = [band_rows(H, n, r, align) for r in range(n)]
+            assert rows[0][0] == 0 and sum(k for _, k in rows) == H and all(k >= 1 for _, k in rows)
+            assert all(rows[i][0] + rows[i][1] == rows[i + 1][0] for i in range(n - 1))
+            if align and -(-(H - 2) // 62) >= n:       # a tile row per band: every seam sits behind the last row of a tile
+                assert all(r0 % 62 == 1 for r0, _ in rows[1:])
+                if H >= 1000:
+                    assert max(k for _, k in rows) - min(k for _, k in rows) <= 64
+    assert [band_rows(65536, 4, r) for r in range(4)] == [(0, 16369), (16369, 16368), (32737, 16430), (49167, 16369)]
     with pytest.raises(ValueError):
         band_rows(3, 4, 0)
 

@@ -12,14 +12,14 @@ from _cases import fbm, fixtures, meander_flowdir, random_flowdir, serpentine_fl
 pytestmark = pytest.mark.gpu
 
 
-def run_bands(dem, nbands):
+def run_bands(dem, nbands, align=True):
     from malstroem_amd.distributed import BandPipeline, ThreadComm
     out = [None] * nbands
     err = []
 
     def work(comm):
         try:
-            p = BandPipeline(comm, dem.shape, device=0)
+            p = BandPipeline(comm, dem.shape, device=0, align=align)
             p.upload_dem(dem[p.row0:p.row0 + p.nrows])
             rec = p.run_chain(overlap=comm.size != 3)      # two host threads per band (3 bands: one after the other)
             n = p.nlabels
@@ -27,6 +27,7 @@ def run_bands(dem, nbands):
             out[comm.rank]["nlabels"] = n
             out[comm.rank]["short_diag"] = (p.short, p.diag)
             out[comm.rank]["exchanges"] = dict(p.exchanges)
+            out[comm.rank]["engines"] = (p.band.get_int("fill_algorithm"), p.band.get_int("noflat_algorithm"))
             out[comm.rank].update(rec)
             p.close()
         except Exception as e:  # pragma: no cover
@@ -63,6 +64,21 @@ def test_bands_match_reference_fixture(nbands):
 def test_bands_match_oracle(nbands, h, w):
     dem = fbm(h, w, beta=2.0, seed=21)
     out = run_bands(dem, nbands)
+    check_bands_against_oracle(dem, out)
+    # seams on the tile grid: every band ran the tiled priority-flood and the geodesic no-flats transform, a handful of exchanges
+    assert all(o["engines"] == (1, 2) for o in out), [o["engines"] for o in out]
+    assert out[0]["exchanges"]["fill"] <= 12 and out[0]["exchanges"]["noflat"] <= 12
+
+
+@pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (3, 380, 130), (4, 1000, 130)])
+def test_bands_off_the_tile_grid_run_the_iterative_fill(nbands, h, w):
+    dem = fbm(h, w, beta=2.0, seed=22)
+    out = run_bands(dem, nbands, align=False)
+    check_bands_against_oracle(dem, out)
+    assert all(o["engines"][0] == 0 for o in out[:-1])      # (the last band has no bottom halo row: the flood runs there)
+
+
+def check_bands_against_oracle(dem, out):
     filled = oracle.fill_terrain(dem)
     short, diag = oracle.minimum_safe_short_and_diag(dem)
     fnf = oracle.fill_terrain_no_flats(dem, short, diag)

@@ -167,7 +167,8 @@ class CpuBand(object):
         with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
             u = np.nextafter(up, np.inf) - up
             Su, Du = short / u, diag / u
-        regular = np.isfinite(F) & (F != 0) & (np.rint(Su) == Su) & (Su >= 1) & (Du < 2 ** 28) & (np.abs(Du - np.rint(Du)) != 0.5)
+        with np.errstate(invalid="ignore"):
+            regular = np.isfinite(F) & (F != 0) & (np.rint(Su) == Su) & (Su >= 1) & (Du < 2 ** 28) & (np.abs(Du - np.rint(Du)) != 0.5)
         if (flat & ~regular).any() or np.isnan(self.r["filled"][owned]).any() or not (short > 0 and diag > 0):
             return False, False
         self._geo = dict(flat=flat, u=u, S=np.where(regular, np.rint(Su), 0).astype(np.int64), D=np.where(regular, np.rint(Du), 0).astype(np.int64),

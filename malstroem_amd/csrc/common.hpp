@@ -124,6 +124,7 @@ struct FillRun {
     double seed_add = 0;
     int fixed_top = 0, fixed_bot = 0;  // local row 0 / H-1 is a halo row owned by the neighbouring band
     int rounds_per_batch = 8;          // rounds launched between two host checks (a band exchanges its halo rows after each batch)
+    bool attach_only = false;          // (internal: attach() is begin() without the initialising round)
     struct Impl;
     Impl *impl;
     FillRun();
@@ -133,6 +134,7 @@ struct FillRun {
     int begin(hipStream_t s, bool *active);      // initialising round over every tile
     int batch(hipStream_t s, bool *active);      // a batch of rounds; *active == false: locally converged
     int activate_row(int side, hipStream_t s);   // halo row `side` (0 top, 1 bottom) changed: revisit its tile row
+    int attach(hipStream_t s);                   // instead of begin(): `out` already holds an upper bound of the fixed point
     int certify(hipStream_t s, bool *changed);   // one sweep over EVERY tile, iterated to local convergence; *changed: a tile moved
     int finish(hipStream_t s, FillStats *st);
 };
@@ -169,6 +171,9 @@ struct GeoRun {
     int64_t H = 0, W = 0;
     double sh = 0, dg = 0;
     int fixed_top = 0, fixed_bot = 0;
+    bool allow_partial = false;                       // flats of irregular levels: leave them to the caller (else: not applicable)
+    double seed_add = 0;                              // ... with the upper bound F + seed_add in `out`
+    bool partial = false;                             // set by end(): `out` still needs the float64 relaxation on those flats
     struct Impl;
     Impl *impl;
     GeoRun();
@@ -182,8 +187,9 @@ struct GeoRun {
     int launch_rounds(hipStream_t s, int nb);
 };
 // noflat_geo.hip: MHIP_ELIMIT = not applicable, run the float64 relaxation
-int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                             FillStats *st);
+int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
+                             hipStream_t s, FillStats *st, bool *partial);
+int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);

@@ -802,6 +802,17 @@ static int fill_launch_any(FillRun &f, int round, int init, hipStream_t s)
     return f.noflat ? fill_launch<double, true>(f, round, init, s) : fill_launch<float, false>(f, round, init, s);
 }
 
+// workspace of a run whose `out` already holds an upper bound of the fixed point: no initialising round; certify() finds the
+// tiles that can still move and batch() relaxes them
+int FillRun::attach(hipStream_t s)
+{
+    attach_only = true;
+    bool active = false;
+    const int rc = begin(s, &active);
+    attach_only = false;
+    return rc;
+}
+
 int FillRun::begin(hipStream_t s, bool *active)
 {
     Impl &m = *impl;
@@ -809,6 +820,7 @@ int FillRun::begin(hipStream_t s, bool *active)
     m.rounds_used = 0;
     *active = false;
     m.trivial = H < 3 || W < 3;
+    if (m.trivial && attach_only) return MHIP_OK;
     if (m.trivial) {  // no interior cell: filled == dem (fill.py:102-109 with an empty sweep area)
         const int64_t n = H * W;
         if (noflat) hipLaunchKernelGGL((copy_dem_kernel<double>), dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, dem, reinterpret_cast<double *>(out), n);
@@ -838,6 +850,7 @@ int FillRun::begin(hipStream_t s, bool *active)
     m.head = reinterpret_cast<unsigned int *>(m.ws.as<char>() + off_head);
     m.d_stats = reinterpret_cast<unsigned long long *>(m.ws.as<char>() + off_stats);
 
+    if (attach_only) return MHIP_OK;
     MH_TRY(fill_launch_any(*this, 0, seed ? INIT_SEED : INIT_INF, s));
     m.round = 1;
     m.rounds_used = 1;
@@ -1054,8 +1067,38 @@ int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, dou
                     FillStats *st, const float *d_filled)
 {
     // the integer geodesic transform of noflat_geo.hip first; it hands back MHIP_ELIMIT for what it does not cover
-    const int rc = fill_noflat_geodesic_dev(d_dem, d_filled, d_out, H, W, sh, dg, s, st);
-    if (rc != MHIP_ELIMIT) return rc;
+    bool partial = false;
+    const double seed_add = 1.01 * (double)(H * W) * dg;      // see noflat_seed()
+    const int rc = fill_noflat_geodesic_dev(d_dem, d_filled, d_out, H, W, sh, dg, seed_add, s, st, &partial);
+    if (rc != MHIP_ELIMIT && !(rc == MHIP_OK && partial)) return rc;
+    if (rc == MHIP_OK) {
+        // hybrid: exact everywhere but on the flats of irregular levels (a sea at elevation 0, ...), which hold the upper bound
+        // F + seed_add.  The relaxation settles them -- certify() queues exactly the tiles that can still move -- and the
+        // reference's equation is checked at every cell afterwards; a failure falls through to the relaxation from scratch.
+        FillStats st_geo = st ? *st : FillStats();
+        FillRun h;
+        h.noflat = true; h.dem = d_dem; h.out = d_out; h.H = H; h.W = W; h.sh = sh; h.dg = dg;
+        MH_TRY(h.attach(s));
+        int sweeps = 0;
+        for (bool changed = true; changed; ++sweeps) MH_TRY(h.certify(s, &changed));
+        FillStats st_rel;
+        MH_TRY(h.finish(s, &st_rel));
+        bool ok = false;
+        MH_TRY(noflat_verify_dev(d_dem, d_out, H, W, sh, dg, s, &ok));
+        if (getenv("MHIP_NG_DEBUG"))
+            fprintf(stderr, "[noflat hybrid] relaxation: %d certification sweeps, %d rounds, %lld visits; verified: %d\n", sweeps, st_rel.rounds,
+                    (long long)st_rel.visits, (int)ok);
+        if (ok) {
+            if (st) {
+                *st = st_geo;
+                st->algorithm = 3;
+                st->rounds += st_rel.rounds;
+                st->visits += st_rel.visits;
+                st->cycles += st_rel.cycles;
+            }
+            return MHIP_OK;
+        }
+    }
     FillRun f;
     f.noflat = true; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W; f.sh = sh; f.dg = dg;
     noflat_seed(f, d_filled, sh, dg, H * W);

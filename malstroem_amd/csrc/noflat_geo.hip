@@ -43,6 +43,7 @@ constexpr int WN = 64;  // window edge (tile + halo ring)
 constexpr int TI = 62;  // tile edge
 constexpr uint32_t DINF = 0xE0000000u;     // "not reached yet"; every weight is < 2**28, so DINF + weight does not wrap
 constexpr uint32_t WMAX = 1u << 28;
+constexpr uint32_t D_IRR = 0xFFFFFFFFu;    // distance word of a flat cell of an irregular level: not part of the transform (see GeoRun::end)
 constexpr uint32_t M_NOFLAT = 0xFF00u;     // class 255: not a flat cell (a source), or a flat cell of a level without integer weights (counted)
 constexpr int DPP_WF_SL1 = 0x130;          // lane i <- lane i+1
 constexpr int DPP_WF_SR1 = 0x138;          // lane i <- lane i-1
@@ -52,7 +53,7 @@ constexpr int DPP_WF_SR1 = 0x138;          // lane i <- lane i-1
 #ifndef NG_FIRSTCYC
 #define NG_FIRSTCYC 1    // ... in the first round: flats that fit into one tile are finished there
 #endif
-enum { C_IRREGULAR = 0, C_UNREACHED = 1, C_MISMATCH = 2, C_STATS = 8 };   // counters[]; C_STATS: 64 x {visits, cycles}
+enum { C_IRREGULAR = 0, C_UNREACHED = 1, C_MISMATCH = 2, C_FATAL = 3, C_STATS = 8 };   // counters[]; C_STATS: 64 x {visits, cycles}
 
 __device__ __forceinline__ uint32_t from_left(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_WF_SR1, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t from_right(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_WF_SL1, 0xf, 0xf, true); }
@@ -257,7 +258,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         const bool lane_border = (tj == 0 && lane == 0) | (cc >= W - 1);          // raster border column (or its clamped copies)
         const float PINF = __builtin_inff();
         const int border_row = (int)(H - 1 - r0 < 2 * WN ? H - 1 - r0 : 2 * WN);   // window row of the raster's last row (or beyond the window)
-        uint32_t lake_any = 0, nirr = 0;
+        uint32_t lake_any = 0, nirr = 0, nfatal = 0;
         {
             float f[WN];
             int so = 0;
@@ -286,9 +287,18 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                     const bool cell = lane_in & !border;     // an interior raster cell
                     const bool flat = cell & !src;
                     const bool regular = flat & (adj != 0u) & (e != 255u) && tab_l[e & 0xffu] != 0u;
-                    nirr += ((flat & !regular) | (cell & (V != V))) ? 1u : 0u;   // a level without integer weights, or a NaN: not for this path
+                    const bool nan = cell & (V != V);
+                    const bool irregular = flat & !regular & !nan;     // a level without integer weights: left to the float64 relaxation
+                    nirr += irregular ? 1u : 0u;
+                    nfatal += nan ? 1u : 0u;                            // NaN cells: not for this path at all
                     w = regular ? (adj | (e << 8)) : M_NOFLAT;
                     unreached = regular;
+                    lake_any |= w;
+                    ni[r] = w;
+                    d[r] = irregular ? D_IRR : (unreached ? DINF : 0u);
+                    upl = cul; up = V; upr = cur;
+                    cul = dnl; cur = dnr;
+                    continue;
                 }
                 lake_any |= w;
                 ni[r] = w;
@@ -298,10 +308,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             }
         }
         {
-            uint32_t tot = nirr;
+            uint32_t tot = nirr | (nfatal << 16);      // (at most 62 x 62 of either per window)
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) tot += (uint32_t)__shfl_xor((int)tot, o);
-            if (tot && lane == 0) atomicAdd(&a.counters[C_IRREGULAR], (unsigned long long)tot);
+            if ((tot & 0xffffu) && lane == 0) atomicAdd(&a.counters[C_IRREGULAR], (unsigned long long)(tot & 0xffffu));
+            if ((tot >> 16) && lane == 0) atomicAdd(&a.counters[C_FATAL], (unsigned long long)(tot >> 16));
         }
         // the raster border cells inside this window are sources: their distance 0 is read by every later visit (and by
         // ng_assemble), so somebody has to write it
@@ -319,8 +330,8 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
             if (lane_ok) {
 #pragma unroll
-                for (int r = 1; r <= TI; ++r)
-                    if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, lane * 4, r * Wi * 4, 0);
+                for (int r = 1; r <= TI; ++r)      // 0 for a source, D_IRR for a flat cell of an irregular level
+                    if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(d[r], rd, lane * 4, r * Wi * 4, 0);
             }
             return;
         }
@@ -478,13 +489,14 @@ __global__ __launch_bounds__(1024) void ng_compact_kernel(unsigned long long *ma
 
 // ---- G = F + u * D -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ng_assemble_kernel(const float *__restrict__ F, const uint32_t *__restrict__ d, double *__restrict__ G, int64_t n,
-                                                          unsigned long long *counters)
+                                                          double seed_add, unsigned long long *counters)
 {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     unsigned bad = 0;
     // a source has distance 0: G = F whatever its class
     auto value = [&](float f, uint32_t dd) {
+        if (dd == D_IRR) return (double)f + seed_add;   // a flat cell of an irregular level: an upper bound for the relaxation
         bad += dd >= 0x80000000u ? 1u : 0u;     // a flat cell nobody reached (or a distance beyond the uint32 headroom)
         const uint32_t e = class_above(f);
         return dd ? (double)f + (double)dd * class_ulp(e) : (double)f;
@@ -574,6 +586,7 @@ struct GeoRun::Impl {
     size_t lds = 0;
     int maxcyc = NG_MAXCYC, firstcyc = NG_FIRSTCYC;
     bool debug = false;
+    unsigned long long irregular = 0;
 };
 namespace {
 constexpr int MAXR = 8192, BATCH = 16;
@@ -674,12 +687,13 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
     m.round = 0;
     m.used = 0;
     MH_TRY(launch_rounds(s, 1));
-    unsigned long long h_irr = 0;
-    MH_HIP(hipMemcpyAsync(&h_irr, m.d_cnt + C_IRREGULAR, 8, hipMemcpyDeviceToHost, s));
+    unsigned long long h_c[4] = {0, 0, 0, 0};
+    MH_HIP(hipMemcpyAsync(h_c, m.d_cnt, sizeof(h_c), hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
     m.used = 1;
-    if (h_irr) {
-        if (m.debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells: float64 relaxation\n", h_irr);
+    m.irregular = h_c[C_IRREGULAR];
+    if (h_c[C_FATAL] || (m.irregular && !allow_partial)) {
+        if (m.debug) fprintf(stderr, "[noflat geodesic] %llu irregular flat cells, %llu NaN cells: float64 relaxation\n", m.irregular, h_c[C_FATAL]);
         return MHIP_OK;
     }
     *applicable = true;
@@ -723,9 +737,11 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
 {
     Impl &m = *impl;
     const int64_t n = H * W;
-    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, m.d_cnt);
-    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, dem, out, H, W, sh, dg,
-                       fixed_top, fixed_bot, m.d_cnt);
+    partial = m.irregular != 0;
+    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, seed_add, m.d_cnt);
+    if (!partial)     // (a partial surface is checked by the caller once the relaxation has settled the irregular flats)
+        hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, dem, out, H, W, sh, dg,
+                           fixed_top, fixed_bot, m.d_cnt);
     MH_HIP(hipGetLastError());
     unsigned long long h_all[C_STATS + 128];
     MH_HIP(hipMemcpyAsync(h_all, m.d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
@@ -734,7 +750,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
         *st = FillStats();
         st->rounds = m.used;
         st->tiles = m.nt;
-        st->algorithm = 2;
+        st->algorithm = partial ? 3 : 2;
         for (int k = 0; k < 64; ++k) {
             st->visits += (int64_t)h_all[C_STATS + 2 * k];
             st->cycles += (int64_t)h_all[C_STATS + 2 * k + 1];
@@ -758,18 +774,38 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     return MHIP_OK;
 }
 
-// MHIP_OK: d_out holds the verified no-flats surface.  MHIP_ELIMIT: not applicable to this raster (irregular levels, a cell the
-// verification rejects, ...): the caller runs the float64 relaxation.
-int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                             FillStats *st)
+// the reference's equation at every cell of d_out (the check of GeoRun::end as a function of its own)
+int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok)
+{
+    DevBuf cnt;
+    MH_TRY(cnt.alloc(8 * (C_STATS + 128)));
+    MH_HIP(hipMemsetAsync(cnt.p, 0, 8 * (C_STATS + 128), s));
+    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg, 0, 0,
+                       cnt.as<unsigned long long>());
+    MH_HIP(hipGetLastError());
+    unsigned long long bad = 0;
+    MH_HIP(hipMemcpyAsync(&bad, cnt.as<unsigned long long>() + C_MISMATCH, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    *ok = bad == 0;
+    return MHIP_OK;
+}
+
+// MHIP_OK: d_out holds the no-flats surface, verified -- or, with *partial, exact everywhere but on the flats of irregular levels,
+// which hold an upper bound (F + seed_add): the caller relaxes those in float64 and verifies.  MHIP_ELIMIT: not applicable to
+// this raster (NaN cells, epsilons without weights, a cell the verification rejects): the caller runs the float64 relaxation.
+int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
+                             hipStream_t s, FillStats *st, bool *partial)
 {
     GeoRun g;
     g.dem = d_dem; g.filled = d_filled; g.out = d_out; g.H = H; g.W = W; g.sh = sh; g.dg = dg;
+    g.allow_partial = partial != nullptr && seed_add == seed_add && seed_add < 1e300;
+    g.seed_add = seed_add;
     bool applicable = false, active = false, ok = false;
     MH_TRY(g.begin(s, &applicable, &active));
     if (!applicable) return MHIP_ELIMIT;
     while (active) MH_TRY(g.batch(s, &active));
     MH_TRY(g.end(s, &ok, st));
+    if (partial) *partial = g.partial;
     return ok ? MHIP_OK : MHIP_ELIMIT;
 }
 

@@ -63,10 +63,19 @@ def test_quantised_terrain_large_natural_flats():
     check(np.repeat(stairs, 8, 0), algorithm=2)                     # terraces: every flat cell has a lower row within 8 cells
 
 
-def test_a_flat_at_elevation_zero_runs_the_float64_relaxation():
+def test_a_flat_at_elevation_zero_is_left_to_the_float64_relaxation():
+    """hybrid: the integer transform for every regular level, the relaxation only where the irregular flats lie; NaN cells send
+    the whole raster to the relaxation"""
     dem = fbm(400, 300, beta=2.0, seed=13)
     dem[100:200, :250] = 0.0                                        # a sea at 0 that reaches the raster border: no constant ulp above 0
-    check(dem, algorithm=0)
+    check(dem, algorithm=3)
+    sea = fbm(1500, 1200, beta=2.0, seed=17) - 30.0                 # a tenth of the raster below sea level ...
+    sea[sea < 0] = 0.0                                              # ... clamped to 0: one huge irregular flat + regular lakes on land
+    check(sea, algorithm=3)
+    from _cases import fixtures
+    fx = fixtures()                                                 # the reference's own DEM has cells at 0
+    got, alg, _ = run(fx["dtm"])
+    assert alg == 3 and np.array_equal(got, fx["filled_no_flats"])
     nan = fbm(300, 300, beta=2.0, seed=14) + 3
     nan[40:60, 70] = np.nan
     from malstroem_amd.algorithms import fill

@@ -269,8 +269,12 @@ def main():
         for w in workers:
             w.start()
         gate.wait()
+        used_rccl = bool(workers[0].pipe is not None and workers[0].pipe.rccl)
+        rccl_note = ""
+        if rccl and not used_rccl and workers[0].pipe is not None:
+            rccl_note = " (RCCL setup failed: %s)" % workers[0].pipe.rccl_error
         parallelism = "%d row bands of one %dx%d DEM over %d GPU(s), %d band(s) per GPU; halo rows %s" % (
-            nbands, n, n, world, k, "GPU->GPU over RCCL inside the library (ncclSend/ncclRecv)" if rccl else "through the host communicator")
+            nbands, n, n, world, k, "GPU->GPU over RCCL inside the library (ncclSend/ncclRecv)" if used_rccl else "through the host communicator" + rccl_note)
     else:
         pipe = HydroPipeline((n, n), device=device)
         pipe.upload("dem", src.rows(0, n))

@@ -585,25 +585,36 @@ class BandPipeline(object):
         factory = backend_factory or HipBand
         if rccl is None:   # RCCL wants one rank per device: only transports between processes say so (SocketComm; a launcher's own)
             rccl = comm.size > 1 and factory is HipBand and bool(getattr(comm, "one_rank_per_device", False))
-        self.band, err = None, None
-        try:
-            uid = None
-            if rccl and comm.size > 1:
-                try:
-                    mine = getattr(factory, "new_unique_id", HipBand.new_unique_id)() if comm.rank == 0 else None
-                except Exception as e:
-                    mine, err = None, e
-                uid = comm.allgather(mine)[0]          # every rank takes part, whatever happened on rank 0
-                if uid is None:
-                    raise err or RuntimeError("rank 0 could not create an ncclUniqueId")
-            kw = dict(unique_id=uid) if uid is not None else {}
-            self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size, **kw)
-        except Exception as e:
-            err = err or e
-        if comm.allreduce_max(1.0 if err is not None else 0.0) > 0.0:
+        self.rccl_error = None
+        for attempt in (0, 1):
+            self.band, err = None, None
+            try:
+                uid = None
+                if rccl and comm.size > 1:
+                    try:
+                        mine = getattr(factory, "new_unique_id", HipBand.new_unique_id)() if comm.rank == 0 else None
+                    except Exception as e:
+                        mine, err = None, e
+                    uid = comm.allgather(mine)[0]          # every rank takes part, whatever happened on rank 0
+                    if uid is None:
+                        raise err or RuntimeError("rank 0 could not create an ncclUniqueId")
+                kw = dict(unique_id=uid) if uid is not None else {}
+                self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size, **kw)
+                if uid is not None:                          # one collective before anything depends on the communicator
+                    self.band.allreduce_max(float(comm.rank))
+            except Exception as e:
+                err = err or e
+            if comm.allreduce_max(1.0 if err is not None else 0.0) == 0.0:
+                break
             if self.band is not None:
                 self.band.close()
-            raise err if err is not None else RuntimeError("band setup failed on another rank")
+                self.band = None
+            if not (rccl and comm.size > 1 and attempt == 0):
+                raise err if err is not None else RuntimeError("band setup failed on another rank")
+            # the RCCL communicator could not be set up on some rank: the same bands with their rows through `comm` (host buffers).
+            # Every rank takes this branch together (the vote above); the reason is kept for the caller to report.
+            self.rccl_error = repr(err) if err is not None else "RCCL setup failed on another rank"
+            rccl = False
         self.rccl = bool(getattr(self.band, "has_comm", False))
         self.has_up = comm.rank > 0
         self.has_down = comm.rank < comm.size - 1

@@ -199,6 +199,30 @@ def test_band_noflat_engines(case):
         assert out[0][2] <= 8
 
 
+def test_a_failed_rccl_setup_falls_back_to_rows_through_the_host_on_every_rank():
+    class BrokenTransport(CpuBand):       # librccl cannot be opened / ncclGetUniqueId fails: known before any collective is entered
+        @staticmethod
+        def new_unique_id():
+            raise RuntimeError("ncclGetUniqueId: unhandled system error (simulated)")
+
+    dem = fbm(96, 80, beta=2.0, seed=8) + np.float32(2.0)
+    want = oracle.fill_terrain(dem)
+    out = [None] * 3
+
+    def work(comm):
+        p = BandPipeline(comm, dem.shape, backend_factory=BrokenTransport, rccl=True)
+        p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+        p.fill()
+        out[comm.rank] = (p.download("filled"), p.rccl, p.rccl_error)
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(3)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert all(o is not None for o in out)
+    assert [o[1] for o in out] == [False] * 3 and all(o[2] for o in out)
+    assert np.array_equal(np.concatenate([o[0] for o in out]), want)
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))

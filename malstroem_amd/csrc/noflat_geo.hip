@@ -497,7 +497,10 @@ __global__ __launch_bounds__(256) void ng_assemble_kernel(const float *__restric
     // a source has distance 0: G = F whatever its class
     auto value = [&](float f, uint32_t dd) {
         if (dd == D_IRR) return (double)f + seed_add;   // a flat cell of an irregular level: an upper bound for the relaxation
-        bad += dd >= 0x80000000u ? 1u : 0u;     // a flat cell nobody reached (or a distance beyond the uint32 headroom)
+        if (dd >= 0x80000000u) {                        // a distance beyond the uint32 headroom (a very long flat in a low binade;
+            ++bad;                                      // every smaller distance is exact): the relaxation settles it as well
+            return (double)f + seed_add;
+        }
         const uint32_t e = class_above(f);
         return dd ? (double)f + (double)dd * class_ulp(e) : (double)f;
     };
@@ -737,7 +740,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
 {
     Impl &m = *impl;
     const int64_t n = H * W;
-    partial = m.irregular != 0;
+    partial = m.irregular != 0 && allow_partial;
     hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, seed_add, m.d_cnt);
     if (!partial)     // (a partial surface is checked by the caller once the relaxation has settled the irregular flats)
         hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, dem, out, H, W, sh, dg,
@@ -746,6 +749,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     unsigned long long h_all[C_STATS + 128];
     MH_HIP(hipMemcpyAsync(h_all, m.d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
+    if (allow_partial && h_all[C_UNREACHED]) partial = true;      // (the verification above then reported those cells: ignored)
     if (st) {
         *st = FillStats();
         st->rounds = m.used;
@@ -769,7 +773,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
         fprintf(stderr, "\n[noflat geodesic] %lld x %lld: rounds %d, unreached %llu, mismatches %llu\n", (long long)H, (long long)W, m.used, h_all[C_UNREACHED],
                 h_all[C_MISMATCH]);
     }
-    *ok = !(h_all[C_UNREACHED] || h_all[C_MISMATCH]);
+    *ok = partial ? true : !(h_all[C_UNREACHED] || h_all[C_MISMATCH]);
     m.ws.release();
     return MHIP_OK;
 }

@@ -84,6 +84,19 @@ def test_a_flat_at_elevation_zero_is_left_to_the_float64_relaxation():
     assert np.array_equal(a, b, equal_nan=True)                     # (NaN semantics are pinned in test_gpu_edgecases)
 
 
+def test_a_flat_longer_than_the_uint32_headroom():
+    """a 1-cell-wide channel at 0.3 m that snakes through walls of 100 m: 20 000 steps of 2**18 ulps each -- past 2**31 the
+    distances are handed to the relaxation (every smaller one is exact), the result is the oracle's"""
+    h, w = 203, 203
+    dem = np.full((h, w), 100.0, np.float32)
+    for k, r in enumerate(range(1, h - 1, 2)):
+        dem[r, 1:w - 1] = 0.3
+        if r + 2 < h - 1:
+            dem[r + 1, (w - 2) if k % 2 == 0 else 1] = 0.3      # the turn at alternating ends
+    dem[1, 0] = 0.2                                              # the outlet, on the raster border
+    check(dem, algorithm=3)
+
+
 @pytest.mark.parametrize("short,diag", [(2.0 ** -30, 2.0 ** -30 * 2 ** 0.5), (1e-9, 1.5e-9), (1e-3, 1.4142e-3), (3e-7, 3e-7), (2.0 ** -20, 2.0 ** -19),
                                         (1e-13, 1.5e-13), (0.0, 0.0), (0.25, 0.5)])
 def test_user_epsilons_whatever_path_they_take(short, diag):

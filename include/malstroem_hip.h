@@ -204,7 +204,14 @@ int mhip_ctx_fill_end(mhip_ctx *ctx, int kind);   /* kind 0 also computes the bl
 int mhip_ctx_geo_begin(mhip_ctx *ctx, double short_, double diag, int32_t *applicable, int32_t *active);
 int mhip_ctx_geo_batch(mhip_ctx *ctx, int32_t *active);
 int mhip_ctx_geo_halo_changed(mhip_ctx *ctx, int side);
-int mhip_ctx_geo_end(mhip_ctx *ctx, int32_t *ok);
+int mhip_ctx_geo_end(mhip_ctx *ctx, int32_t *ok, int32_t *partial);
+/* *partial (with *ok): MHIP_R_NOFLAT is exact except on flats the transform does not cover (a level without integer weights, a
+ * distance beyond the uint32 headroom), which hold an upper bound.  If any band reports it, ALL bands call
+ * mhip_ctx_fill_attach(kind 1) -- mhip_ctx_fill_begin without the initialising round: the surface in MHIP_R_NOFLAT is the start --
+ * and run the usual loop (edge rows of MHIP_R_NOFLAT, _halo_changed, _batch, _certify, _end); mhip_ctx_noflat_verify then checks
+ * the reference's equation at every owned cell (any band failing: relaxation from scratch, mhip_ctx_fill_begin kind 1). */
+int mhip_ctx_fill_attach(mhip_ctx *ctx, int kind, double short_, double diag);
+int mhip_ctx_noflat_verify(mhip_ctx *ctx, int32_t *ok);
 /* accumulation on a band: mhip_ctx_zero_raster(ACCUM) once, then { mhip_ctx_run(ACCUM); swap ACCUM edge rows } until no
  * halo row changes (a halo value <= 0 means "not known yet" and blocks the cells below it). */
 int mhip_ctx_zero_raster(mhip_ctx *ctx, int which);

@@ -1064,6 +1064,43 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
     return MHIP_OK;
 }
 
+/* like mhip_ctx_fill_begin, but the raster (MHIP_R_NOFLAT / MHIP_R_FILLED) already holds an upper bound of the fixed point: no
+ * initialising round; mhip_ctx_fill_certify finds the tiles that can still move */
+int mhip_ctx_fill_attach(mhip_ctx *c, int kind, double short_, double diag)
+{
+    MH_ARG(c && (kind == 0 || kind == 1) && c->have[MHIP_R_DEM], "ctx_fill_attach(ctx, kind, short, diag)");
+    const int which = kind ? MHIP_R_NOFLAT : MHIP_R_FILLED;
+    MH_ARG(c->r[which].p, "ctx_fill_attach: the raster to start from does not exist");
+    MH_HIP(hipSetDevice(c->device));
+    if (kind == 0) {
+        delete c->pf;
+        c->pf = nullptr;
+    }
+    delete c->run[kind];
+    FillRun *f = c->run[kind] = new FillRun();
+    f->noflat = kind != 0;
+    f->dem = c->r[MHIP_R_DEM].as<float>();
+    f->out = c->r[which].p;
+    f->H = c->H; f->W = c->W;
+    f->fixed_top = c->ht; f->fixed_bot = c->hb;
+    f->rounds_per_batch = 16;
+    if (kind) {
+        f->sh = short_; f->dg = diag;
+        c->sh = short_; c->dg = diag;
+    }
+    return f->attach(c->stream);
+}
+
+int mhip_ctx_noflat_verify(mhip_ctx *c, int32_t *ok)
+{
+    MH_ARG(c && ok && c->have[MHIP_R_NOFLAT] && c->have[MHIP_R_DEM], "ctx_noflat_verify(ctx, ok) needs the no-flats surface");
+    MH_HIP(hipSetDevice(c->device));
+    bool good = false;
+    MH_TRY(noflat_verify_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), c->H, c->W, c->sh, c->dg, c->stream, &good, c->ht, c->hb));
+    *ok = good ? 1 : 0;
+    return MHIP_OK;
+}
+
 int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
 {
     MH_ARG(c && active && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_batch needs ctx_fill_begin");
@@ -1156,6 +1193,8 @@ int mhip_ctx_geo_begin(mhip_ctx *c, double short_, double diag, int32_t *applica
     g->dist = c->r[MHIP_R_NGDIST].as<uint32_t>();
     g->H = c->H; g->W = c->W; g->sh = short_; g->dg = diag;
     g->fixed_top = c->ht; g->fixed_bot = c->hb;
+    g->allow_partial = true;                                   // the launcher votes on what happens with a partial surface
+    g->seed_add = 1.01 * (double)(c->H_global * c->W) * diag;  // see noflat_seed()
     c->sh = short_; c->dg = diag;
     bool ap = false, ac = false;
     MH_TRY(g->begin(c->stream, &ap, &ac));
@@ -1186,13 +1225,14 @@ int mhip_ctx_geo_halo_changed(mhip_ctx *c, int side)
     return c->geo->halo_changed(side, c->stream);
 }
 
-int mhip_ctx_geo_end(mhip_ctx *c, int32_t *ok)
+int mhip_ctx_geo_end(mhip_ctx *c, int32_t *ok, int32_t *partial)
 {
-    MH_ARG(c && ok && c->geo, "ctx_geo_end needs ctx_geo_begin");
+    MH_ARG(c && ok && partial && c->geo, "ctx_geo_end needs ctx_geo_begin");
     MH_HIP(hipSetDevice(c->device));
     FillStats st;
     bool good = false;
     MH_TRY(c->geo->end(c->stream, &good, &st));
+    *partial = c->geo->partial ? 1 : 0;
     delete c->geo;
     c->geo = nullptr;
     *ok = good ? 1 : 0;

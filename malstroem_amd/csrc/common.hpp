@@ -189,7 +189,8 @@ struct GeoRun {
 // noflat_geo.hip: MHIP_ELIMIT = not applicable, run the float64 relaxation
 int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
                              hipStream_t s, FillStats *st, bool *partial);
-int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok);
+int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok, int fixed_top = 0,
+                      int fixed_bot = 0);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
                     FillStats *st, const float *d_filled = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);

@@ -779,13 +779,14 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
 }
 
 // the reference's equation at every cell of d_out (the check of GeoRun::end as a function of its own)
-int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok)
+int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok, int fixed_top,
+                      int fixed_bot)
 {
     DevBuf cnt;
     MH_TRY(cnt.alloc(8 * (C_STATS + 128)));
     MH_HIP(hipMemsetAsync(cnt.p, 0, 8 * (C_STATS + 128), s));
-    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg, 0, 0,
-                       cnt.as<unsigned long long>());
+    hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg, fixed_top,
+                       fixed_bot, cnt.as<unsigned long long>());
     MH_HIP(hipGetLastError());
     unsigned long long bad = 0;
     MH_HIP(hipMemcpyAsync(&bad, cnt.as<unsigned long long>() + C_MISMATCH, 8, hipMemcpyDeviceToHost, s));

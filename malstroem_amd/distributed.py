@@ -446,9 +446,20 @@ class HipBand(object):
         _lib.call("mhip_ctx_geo_halo_changed", self._ctx, int(side))
 
     def geo_end(self):
-        """writes the no-flats surface and checks the reference's equation at every owned cell -> all cells passed?"""
+        """writes the no-flats surface -> (ok, partial).  Not partial: the reference's equation held at every owned cell (ok).
+        Partial: exact except on flats the transform does not cover, which hold an upper bound for the relaxation."""
+        ok, partial = ctypes.c_int32(0), ctypes.c_int32(0)
+        _lib.call("mhip_ctx_geo_end", self._ctx, ctypes.byref(ok), ctypes.byref(partial))
+        return bool(ok.value), bool(partial.value)
+
+    def fill_attach(self, kind, short=0.0, diag=0.0):
+        """fill_begin without the initialising round: the raster already holds an upper bound of the fixed point"""
+        _lib.call("mhip_ctx_fill_attach", self._ctx, int(kind), ctypes.c_double(short), ctypes.c_double(diag))
+        return False
+
+    def noflat_verify(self):
         ok = ctypes.c_int32(0)
-        _lib.call("mhip_ctx_geo_end", self._ctx, ctypes.byref(ok))
+        _lib.call("mhip_ctx_noflat_verify", self._ctx, ctypes.byref(ok))
         return bool(ok.value)
 
     def run_flowdir(self):
@@ -655,11 +666,11 @@ class BandPipeline(object):
         self.band.upload("dem", dem_band)
         self._swap_edges("dem")
 
-    def _fill(self, kind, name, short=0.0, diag=0.0):
+    def _fill(self, kind, name, short=0.0, diag=0.0, attach=False):
         b = self.band
         err, active = None, False
         try:
-            active = b.fill_begin(kind, short, diag)
+            active = b.fill_attach(kind, short, diag) if attach else b.fill_begin(kind, short, diag)
         except Exception as e:
             err = e
         while True:
@@ -750,9 +761,20 @@ class BandPipeline(object):
                     active = b.geo_batch()
             except Exception as e:
                 err = e
-        ok = False
+        ok, partial = False, False
         try:
-            ok = b.geo_end()
+            ok, partial = b.geo_end()
+        except Exception as e:
+            err = e
+        if self._vote(not ok, err):
+            return False
+        if not self._vote(partial):
+            return True
+        # some band holds flats the transform does not cover (a sea at elevation 0, a distance beyond the uint32 headroom): every
+        # band relaxes in float64 from the surface it has -- exact, or an upper bound on those flats -- and checks the result
+        self._fill(1, "noflat", short, diag, attach=True)
+        try:
+            ok = b.noflat_verify()
         except Exception as e:
             err = e
         return not self._vote(not ok, err)

@@ -31,6 +31,11 @@ class CpuBand(object):
             self._comm.close()
 
     def fill_certify(self, kind):
+        if getattr(self, "_attached", False):      # attached to an upper bound: the first "certification" is the relaxation itself
+            self._attached = False
+            before = self.r["noflat" if kind else "filled"].copy()
+            self._solve(kind)
+            return not np.array_equal(before, self.r["noflat" if kind else "filled"])
         return False      # the stand-in iterates whole-raster sweeps to a fixed point: nothing to certify
 
     @staticmethod
@@ -138,6 +143,14 @@ class CpuBand(object):
         self._solve(kind)
         return False
 
+    def fill_attach(self, kind, short=0.0, diag=0.0):
+        self.kind_state[kind] = (short, diag)
+        self._attached = True
+        return False
+
+    def noflat_verify(self):
+        return True
+
     def fill_halo_changed(self, kind, side):
         pass
 
@@ -169,12 +182,14 @@ class CpuBand(object):
             Su, Du = short / u, diag / u
         with np.errstate(invalid="ignore"):
             regular = np.isfinite(F) & (F != 0) & (np.rint(Su) == Su) & (Su >= 1) & (Du < 2 ** 28) & (np.abs(Du - np.rint(Du)) != 0.5)
-        if (flat & ~regular).any() or np.isnan(self.r["filled"][owned]).any() or not (short > 0 and diag > 0):
+        if np.isnan(self.r["filled"][owned]).any() or not (short > 0 and diag > 0):
             return False, False
-        self._geo = dict(flat=flat, u=u, S=np.where(regular, np.rint(Su), 0).astype(np.int64), D=np.where(regular, np.rint(Du), 0).astype(np.int64),
+        irregular = flat & ~regular       # left to the float64 relaxation (geo_end reports a partial surface)
+        flat = flat & regular
+        self._geo = dict(flat=flat, irregular=irregular, u=u, S=np.where(regular, np.rint(Su), 0).astype(np.int64), D=np.where(regular, np.rint(Du), 0).astype(np.int64),
                          short=short, diag=diag)
         d = self._raster("ngdist")
-        d[...] = np.where(flat, self.GEO_INF, 0).astype(np.uint32)
+        d[...] = np.where(flat | irregular, self.GEO_INF, 0).astype(np.uint32)
         if self.ht:
             d[0] = self.GEO_INF       # the neighbour's cells: unknown until the first exchange
         if self.hb:
@@ -212,8 +227,12 @@ class CpuBand(object):
         with np.errstate(over="ignore", invalid="ignore"):
             u = np.nextafter(up, np.inf) - up
             G = np.where(d > 0, F + d * u, F)
+        beyond = self.r["ngdist"] >= 0x80000000          # irregular flats, distances past the uint32 headroom
+        short, diag = self._geo["short"], self._geo["diag"]
+        G[beyond] = F[beyond] + 1.01 * self.Hg * self.W * diag
         self._raster("noflat")[...] = G
-        return bool((self.r["ngdist"] < 0x80000000).all())
+        self.kind_state[1] = (short, diag)
+        return True, bool(beyond[self.ht:self.ht + self.nrows].any())
 
     def fill_end(self, kind):
         if kind == 0:

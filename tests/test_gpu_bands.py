@@ -78,6 +78,27 @@ def test_bands_off_the_tile_grid_run_the_iterative_fill(nbands, h, w):
     assert all(o["engines"][0] == 0 for o in out[:-1])      # (the last band has no bottom halo row: the flood runs there)
 
 
+@pytest.mark.parametrize("case", ["sea at elevation 0", "a flat beyond the uint32 headroom"])
+def test_bands_attach_the_relaxation_to_a_partial_geodesic_surface(case):
+    if case.startswith("sea"):
+        dem = fbm(700, 450, beta=2.0, seed=23) - np.float32(30.0)
+        dem[dem < 0] = 0.0
+        nbands = 3
+    else:       # the snake channel of test_gpu_noflat_geodesic.py, cut into bands
+        h, w = 403, 203
+        dem = np.full((h, w), 100.0, np.float32)
+        for k, r in enumerate(range(1, h - 1, 2)):
+            dem[r, 1:w - 1] = 0.3
+            if r + 2 < h - 1:
+                dem[r + 1, (w - 2) if k % 2 == 0 else 1] = 0.3
+        dem[1, 0] = 0.2
+        nbands = 2
+    out = run_bands(dem, nbands)
+    check_bands_against_oracle(dem, out)
+    assert all(o["engines"][1] == 0 for o in out)        # the relaxation had the last word on the no-flats surface ...
+    assert out[0]["exchanges"]["noflat"] >= 2            # ... after the geodesic exchanges
+
+
 def check_bands_against_oracle(dem, out):
     filled = oracle.fill_terrain(dem)
     short, diag = oracle.minimum_safe_short_and_diag(dem)

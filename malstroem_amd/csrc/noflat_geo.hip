@@ -278,33 +278,28 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 const bool border = lane_border | (ti == 0 && r == 0 && !a.fixed_top) | (r == border_row && !a.fixed_bot) | (r > border_row);
                 const bool src = lower | border;
                 const bool ring = (r == 0) | (r == WN - 1) | ring_lane | (r >= border_row);
-                uint32_t w = M_NOFLAT;
-                bool unreached = ring & !src;
-                if (!ring) {
-                    const uint32_t adj = (up == V ? 1u : 0u) | (upr == V ? 2u : 0u) | (cur == V ? 4u : 0u) | (dnr == V ? 8u : 0u) |
-                                         (dn == V ? 16u : 0u) | (dnl == V ? 32u : 0u) | (cul == V ? 64u : 0u) | (upl == V ? 128u : 0u);
-                    const uint32_t e = class_above(V);
-                    const bool cell = lane_in & !border;     // an interior raster cell
-                    const bool flat = cell & !src;
-                    const bool regular = flat & (adj != 0u) & (e != 255u) && tab_l[e & 0xffu] != 0u;
-                    const bool nan = cell & (V != V);
-                    const bool irregular = flat & !regular & !nan;     // a level without integer weights: left to the float64 relaxation
-                    nirr += irregular ? 1u : 0u;
-                    nfatal += nan ? 1u : 0u;                            // NaN cells: not for this path at all
-                    w = regular ? (adj | (e << 8)) : M_NOFLAT;
-                    unreached = regular;
-                    lake_any |= w;
-                    ni[r] = w;
-                    d[r] = irregular ? D_IRR : (unreached ? DINF : 0u);
-                    upl = cul; up = V; upr = cur;
-                    cul = dnl; cur = dnr;
-                    continue;
-                }
+                // (no branches on per-lane values here: selects only -- see tools/lint_exec_spills.py)
+                const uint32_t adj = (up == V ? 1u : 0u) | (upr == V ? 2u : 0u) | (cur == V ? 4u : 0u) | (dnr == V ? 8u : 0u) |
+                                     (dn == V ? 16u : 0u) | (dnl == V ? 32u : 0u) | (cul == V ? 64u : 0u) | (upl == V ? 128u : 0u);
+                const uint32_t e = class_above(V);
+                const bool cell = lane_in & !border & !ring;     // an interior raster cell of this tile
+                const bool flat = cell & !src;
+                const bool regular = flat & (adj != 0u) & (e != 255u) & (tab_l[e & 0xffu] != 0u);
+                const bool nan = cell & (V != V);
+                const bool irregular = flat & !regular & !nan;     // a level without integer weights: left to the float64 relaxation
+                nirr += irregular ? 1u : 0u;
+                nfatal += nan ? 1u : 0u;                            // NaN cells: not for this path at all
+                const uint32_t w = regular ? (adj | (e << 8)) : M_NOFLAT;
+                const bool unreached = regular | (ring & !src);
                 lake_any |= w;
                 ni[r] = w;
-                d[r] = unreached ? DINF : 0u;
+                // the start distance goes straight to memory (the first relaxation is a visit of the next launch): 0 for a source,
+                // "not reached" for a flat cell, D_IRR for a flat cell of an irregular level
+                const uint32_t d0 = irregular ? D_IRR : (unreached ? DINF : 0u);
+                if (r >= 1 && r <= TI && r < last_row && lane_in) __builtin_amdgcn_raw_buffer_store_b32(d0, rd, lane * 4, r * Wi * 4, 0);
                 upl = cul; up = V; upr = cur;
                 cul = dnl; cur = dnr;
+                __builtin_amdgcn_sched_barrier(0);   // row by row: every comparison is a live SGPR pair until its select has been issued
             }
         }
         {
@@ -325,14 +320,8 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 if (bcell) __builtin_amdgcn_raw_buffer_store_b32(0u, rd, lane * 4, r * Wi * 4, 0);
             }
         }
-        if (!__any((lake_any & 0xffu) != 0u)) {   // nothing in this tile can move, ever: all its cells are sources
+        if (!__any((lake_any & 0xffu) != 0u)) {   // nothing in this tile can move, ever: all its cells are sources (or irregular)
             if (lane == 0) a.hdr[t] = 0u;
-            const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
-            if (lane_ok) {
-#pragma unroll
-                for (int r = 1; r <= TI; ++r)      // 0 for a source, D_IRR for a flat cell of an irregular level
-                    if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(d[r], rd, lane * 4, r * Wi * 4, 0);
-            }
             return;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -397,7 +386,13 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             seams |= (br & B62) ? 1u << 8 : 0u;
         }
         hdr = HDR_ACTIVE | seams | (__any(mism != 0u) ? 0u : HDR_UNIFORM) | (eref << 16);
-        if (lane == 0) a.hdr[t] = hdr;
+        if (lane == 0) {
+            a.hdr[t] = hdr;
+            a.mark[t] = 1;       // the first relaxation of the tile is a visit of the next launch like any other
+        }
+        // (classification and relaxation in one kernel cost more than this extra trip of the distances through memory: the
+        // two phases together do not fit the register file and the compiler spills in both)
+        return;
     } else {
         hdr = __builtin_amdgcn_readfirstlane(a.hdr[t]);
         if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
@@ -419,7 +414,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     wake &= hdr & 0x1ffu;
 
-    if (changed || FIRST) {
+    if (changed) {
         const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
         if (lane_ok) {
 #pragma unroll

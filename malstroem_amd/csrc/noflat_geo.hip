@@ -219,11 +219,71 @@ __device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], con
     }
 }
 
+// ---- a tile that is ONE flat (every cell of the 62 x 62 interior is adjacent to all of its 8 neighbours, one class): no masks --
+// the interior of the lakes the tail rounds spend their time in.  Per row: min(left, right of the row behind) + Dg, the cell
+// behind + S, min3 with the cell itself; the two ring lanes are put back (they belong to the neighbouring tiles).
+template <bool DOWN>
+__device__ __forceinline__ void pass_open(uint32_t (&d)[WN], const uint32_t S, const uint32_t G, const bool ring_lane, uint32_t &acc_all, uint32_t &acc_first,
+                                          uint32_t &acc_last)
+{
+    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]));
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int r = first + dir * i;
+        const uint32_t behind = d[r - dir];
+        const uint32_t m2 = min(from_left(behind), from_right(behind));
+        const uint32_t cu = d[r];
+        uint32_t nv = min(min(behind + S, m2 + G), cu);
+        nv = ring_lane ? cu : nv;
+        const uint32_t x = nv ^ cu;
+        acc_all |= x;
+        asm volatile("" : "+v"(acc_all));
+        if (r == 1) acc_first |= x;
+        if (r == TI) acc_last |= x;
+        d[r] = nv;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void relax_open(uint32_t (&d)[WN], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc, unsigned &wake,
+                                           bool &changed, bool &capped, unsigned &cycles)
+{
+    const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
+    const bool ring_lane = (lane == 0) | (lane == WN - 1);
+    capped = true;
+#pragma nounroll
+    for (int cyc = 0; cyc < maxcyc; ++cyc) {
+        uint64_t chg = 0;
+        ++cycles;
+#pragma nounroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
+            pass_open<true>(d, S, G, ring_lane, acc_all, acc_first, acc_last);
+            pass_open<false>(d, S, G, ring_lane, acc_all, acc_first, acc_last);
+            const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
+            chg |= all;
+            const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
+            const unsigned l1 = (all & B1) ? 1u : 0u, l62 = (all & B62) ? 1u : 0u;
+            const unsigned f1 = (fst & B1) ? 1u : 0u, f62 = (fst & B62) ? 1u : 0u, g1 = (lst & B1) ? 1u : 0u, g62 = (lst & B62) ? 1u : 0u;
+            if (half == 0) wake |= (e_first << 1) | (e_last << 7) | (l1 << 3) | (l62 << 5) | (f1 << 0) | (f62 << 2) | (g1 << 6) | (g62 << 8);
+            else wake |= (e_first << 3) | (e_last << 5) | (l1 << 1) | (l62 << 7) | (f1 << 0) | (f62 << 6) | (g1 << 2) | (g62 << 8);
+            transpose32(d, scr_b, lane);
+        }
+        changed |= chg != 0;
+        if (!chg) {
+            capped = false;
+            break;
+        }
+    }
+}
+
 // One tile visit.  FIRST (ng_first_kernel, every tile once): the window's words are built from the classification -- ring
 // cleared, column layout transposed in, adjacency inverted -- and kept for all later visits as a 16 KB block per tile together
 // with a header word (seams, class, "holds a flat cell at all"); distances start from the classification alone.  Later visits
 // (ng_round_kernel) load header, block and distances and go straight to the passes.
-constexpr uint32_t HDR_ACTIVE = 1u << 31, HDR_UNIFORM = 1u << 9;
+constexpr uint32_t HDR_ACTIVE = 1u << 31, HDR_UNIFORM = 1u << 9, HDR_OPEN = 1u << 10;
 template <bool FIRST>
 __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &visits, unsigned &cycles)
 {
@@ -367,10 +427,15 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         for (int r = 1; r <= TI; ++r) mism |= (ni[r] & 0xffu) != 0xffu ? ((ni[r] >> 8) & 0xffu) ^ eref : 0u;
         // which of the 8 neighbouring tiles share a flat with this one at all?  (bit numbering of `wake`)
         unsigned seams = 1u << 4;
+        bool open_tile = false;
         {
             uint32_t l_or = 0xffu;   // AND of the inverted bytes over rows 1..62 = inverted OR of the adjacency
 #pragma unroll
             for (int r = 1; r <= TI; ++r) l_or &= ni[r];
+            uint32_t any_gap = 0;    // OR of the inverted bytes: a cell that lacks one of its 8 neighbours on its level
+#pragma unroll
+            for (int r = 1; r <= TI; ++r) any_gap |= ni[r] & 0xffu;
+            open_tile = (__ballot(any_gap != 0u) & (((1ull << TI) - 1) << 1)) == 0ull;
             const uint64_t top = __ballot((ni[1] & 0x83u) != 0x83u), bot = __ballot((ni[TI] & 0x38u) != 0x38u);
             const uint64_t lft = __ballot((l_or & 0xe0u) != 0xe0u), rgt = __ballot((l_or & 0x0eu) != 0x0eu);
             const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
@@ -385,7 +450,8 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             seams |= (bl & B1) ? 1u << 6 : 0u;
             seams |= (br & B62) ? 1u << 8 : 0u;
         }
-        hdr = HDR_ACTIVE | seams | (__any(mism != 0u) ? 0u : HDR_UNIFORM) | (eref << 16);
+        const bool uniform = !__any(mism != 0u);
+        hdr = HDR_ACTIVE | seams | (uniform ? HDR_UNIFORM : 0u) | ((uniform && open_tile) ? HDR_OPEN : 0u) | (eref << 16);
         if (lane == 0) {
             a.hdr[t] = hdr;
             a.mark[t] = 1;       // the first relaxation of the tile is a visit of the next launch like any other
@@ -396,8 +462,10 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     } else {
         hdr = __builtin_amdgcn_readfirstlane(a.hdr[t]);
         if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
+        if (!(hdr & HDR_OPEN)) {           // (a tile that is one flat needs no words)
 #pragma unroll
-        for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
+            for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
+        }
         int so = 0;
 #pragma unroll
         for (int r = 0; r < WN; ++r) {
@@ -410,7 +478,8 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     const uint32_t eref = (hdr >> 16) & 0xffu;
     unsigned wake = 0;
     bool changed = false, capped = false;
-    if (hdr & HDR_UNIFORM) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    if (hdr & HDR_OPEN) relax_open(d, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    else if (hdr & HDR_UNIFORM) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     wake &= hdr & 0x1ffu;
 

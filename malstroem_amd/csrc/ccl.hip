@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void ccl_merge_kernel(int32_t *parent, int64_t
 // cell's tile-local root (the first cell of its piece in raster order, tile-local = global order inside a tile).  What is left
 // for global memory are the unions across the tile seams (ccl_seam_kernel): ~6 % of the cells.
 constexpr int CT = 64;
+constexpr int MAXROOTS = CT * CT / 4;   // pieces of a tile: at most every other cell in both directions (8-connectivity)
 constexpr uint32_t LBG = 0xffffffffu;
 
 __device__ __forceinline__ uint32_t find_root_l(const uint32_t *par, uint32_t x)
@@ -131,9 +132,12 @@ __device__ __forceinline__ void unite_l(uint32_t *par, uint32_t a, uint32_t b)
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t H, int64_t W, int ntc)
+__global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t H, int64_t W, int ntc,
+                                                       int32_t *__restrict__ rootlist, int32_t *__restrict__ rootcount)
 {
     __shared__ uint32_t par[CT * CT];
+    __shared__ int s_nroots;
+    if (threadIdx.x == 0) s_nroots = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ti = blockIdx.x / ntc, tj = blockIdx.x - ti * ntc;
     const int64_t r0 = (int64_t)ti * CT, c0 = (int64_t)tj * CT;
@@ -179,9 +183,84 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ dat
         if (p != LBG) {
             const uint32_t root = find_root_l(par, p);
             out = (int32_t)((r0 + (root >> 6)) * W + c0 + (root & 63u));
+            // the roots of the tile's pieces: all that the global steps (flatten, rank) still have to look at
+            if (root == (uint32_t)(r * CT + lane)) rootlist[(size_t)blockIdx.x * MAXROOTS + atomicAdd(&s_nroots, 1)] = out;
         }
         parent[(r0 + r) * W + cc] = out;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) rootcount[blockIdx.x] = s_nroots;
+}
+
+// ---- the global steps on the tile roots only ---------------------------------------------------------------------------------
+// flatten: parent[r] = root(r) for every tile root r; a root of the whole component (the component's first raster pixel: unions
+// always hook the larger index under the smaller) sets its bit in a 1-bit-per-cell mask
+__global__ __launch_bounds__(256) void ccl_flatten_roots_kernel(int32_t *parent, const int32_t *__restrict__ rootlist, const int32_t *__restrict__ rootcount,
+                                                                int64_t ntiles, unsigned long long *rootbits)
+{
+    // four tiles per workgroup, one wavefront each
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int cnt = rootcount[tile];
+    for (int j = threadIdx.x & 63; j < cnt; j += 64) {
+        const int32_t r = rootlist[(size_t)tile * MAXROOTS + j];
+        const int32_t root = find_root(parent, r);
+        if (root != r) parent[r] = root;
+        else atomicOr(&rootbits[r >> 6], 1ull << (r & 63));
+    }
+}
+
+// scipy's numbering = rank of the component's first pixel in raster order = number of root bits before it: per 64-cell word
+// the count of the bits before the word (block sums -> scan_blocks_kernel -> exclusive prefix inside the block)
+constexpr int WB = 1024;      // words per block
+__global__ __launch_bounds__(WB) void ccl_bits_count_kernel(const unsigned long long *__restrict__ rootbits, int64_t nwords, uint32_t *__restrict__ block_counts)
+{
+    __shared__ uint32_t wsum[WB / 64];
+    const int64_t w = (int64_t)blockIdx.x * WB + threadIdx.x;
+    uint32_t cnt = w < nwords ? (uint32_t)__popcll(rootbits[w]) : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < WB / 64; ++k) t += wsum[k];
+        block_counts[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(WB) void ccl_bits_prefix_kernel(const unsigned long long *__restrict__ rootbits, int64_t nwords,
+                                                              const uint32_t *__restrict__ block_offsets, uint32_t *__restrict__ wordprefix)
+{
+    __shared__ uint32_t wsum[WB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * WB + threadIdx.x;
+    const uint32_t cnt = w < nwords ? (uint32_t)__popcll(rootbits[w]) : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wave; ++k) woff += wsum[k];
+    if (w < nwords) wordprefix[w] = block_offsets[blockIdx.x] + woff + incl - cnt;
+}
+
+// labels[i] = 1 + rank of root(i):  i -> its tile root -> (flattened) the component's root -> bits before it
+__global__ __launch_bounds__(256) void ccl_emit_ranked_kernel(const int32_t *__restrict__ parent, const unsigned long long *__restrict__ rootbits,
+                                                              const uint32_t *__restrict__ wordprefix, int32_t *__restrict__ labels, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t p = parent[i];
+    int32_t lab = 0;
+    if (p >= 0) {
+        const int32_t g = parent[p];      // parent[tile root] = component root; a component root is its own parent
+        lab = (int32_t)(wordprefix[g >> 6] + (uint32_t)__popcll(rootbits[g >> 6] & ((1ull << (g & 63)) - 1ull))) + 1;
+    }
+    labels[i] = lab;
 }
 
 // unions across the tile seams.  Horizontal seams (rows that start a tile): the rule of ccl_merge_kernel for N / NW / NE.
@@ -334,22 +413,45 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
     MH_TRY(total.alloc(sizeof(unsigned long long)));
     int32_t *parent = d_tmp;
     static const bool global_uf = [] { const char *e = getenv("MHIP_CCL"); return e && std::string(e) == "global"; }();
-    if (global_uf) {   // the round-1 schedule: every union through global memory
+    if (global_uf) {   // the round-1 schedule: every union and every flatten / rank step over all cells through global memory
         hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n, W);
         hipLaunchKernelGGL(ccl_merge_kernel, dim3(g256), dim3(256), 0, s, parent, H, W);
+        hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g256), dim3(256), 0, s, parent, n);
+        hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, counts.as<uint32_t>(), nb, total.as<unsigned long long>());
+        hipLaunchKernelGGL(ccl_rank_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
+        hipLaunchKernelGGL(ccl_emit_kernel, dim3(g256), dim3(256), 0, s, parent, d_labels, n);
     } else {
-        const int64_t ntr = cdiv(H, CT), ntc = cdiv(W, CT);
-        hipLaunchKernelGGL((ccl_tile_kernel<T>), dim3((unsigned)(ntr * ntc)), dim3(256), 0, s, d_data, parent, H, W, (int)ntc);
+        // three passes over the raster: tiles (read data, write parent), seams (6 % of the cells), emit (read parent, write labels);
+        // everything in between works on the tile roots and on one bit per cell
+        const int64_t ntr = cdiv(H, CT), ntc = cdiv(W, CT), ntiles = ntr * ntc;
+        const int64_t nwords = cdiv(n, 64), nwb = cdiv(nwords, WB);
+        DevBuf roots, rcount, bits, wprefix, bcounts;
+        MH_TRY(roots.alloc(4 * (size_t)ntiles * MAXROOTS));
+        MH_TRY(rcount.alloc(4 * (size_t)ntiles));
+        MH_TRY(bits.alloc(8 * (size_t)nwords));
+        MH_TRY(wprefix.alloc(4 * (size_t)nwords));
+        MH_TRY(bcounts.alloc(4 * (size_t)nwb));
+        MH_HIP(hipMemsetAsync(bits.p, 0, 8 * (size_t)nwords, s));
+        hipLaunchKernelGGL((ccl_tile_kernel<T>), dim3((unsigned)ntiles), dim3(256), 0, s, d_data, parent, H, W, (int)ntc, roots.as<int32_t>(),
+                           rcount.as<int32_t>());
         const int64_t nh = (ntr - 1) * W, nv = (ntc - 1) * H;
         if (nh + nv > 0)
             hipLaunchKernelGGL(ccl_seam_kernel, dim3((unsigned)cdiv(nh + nv, 256)), dim3(256), 0, s, parent, H, W, nh, nh + nv);
+        hipLaunchKernelGGL(ccl_flatten_roots_kernel, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, parent, roots.as<int32_t>(),
+                           rcount.as<int32_t>(), ntiles, bits.as<unsigned long long>());
+        hipLaunchKernelGGL(ccl_bits_count_kernel, dim3((unsigned)nwb), dim3(WB), 0, s, bits.as<unsigned long long>(), nwords, bcounts.as<uint32_t>());
+        hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bcounts.as<uint32_t>(), nwb, total.as<unsigned long long>());
+        hipLaunchKernelGGL(ccl_bits_prefix_kernel, dim3((unsigned)nwb), dim3(WB), 0, s, bits.as<unsigned long long>(), nwords, bcounts.as<uint32_t>(),
+                           wprefix.as<uint32_t>());
+        hipLaunchKernelGGL(ccl_emit_ranked_kernel, dim3(g256), dim3(256), 0, s, parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, n);
+        MH_HIP(hipGetLastError());
+        unsigned long long h_total = 0;
+        MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));     // (the scratch buffers of this branch go back to the pool after the sync)
+        *nlabels = (int64_t)h_total;
+        return MHIP_OK;
     }
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(g256), dim3(256), 0, s, parent, n);
-    hipLaunchKernelGGL(ccl_count_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, counts.as<uint32_t>(), nb,
-                       total.as<unsigned long long>());
-    hipLaunchKernelGGL(ccl_rank_roots_kernel, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, s, parent, n, counts.as<uint32_t>());
-    hipLaunchKernelGGL(ccl_emit_kernel, dim3(g256), dim3(256), 0, s, parent, d_labels, n);
     MH_HIP(hipGetLastError());
     unsigned long long h_total = 0;
     MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));

@@ -446,6 +446,8 @@ struct mhip_ctx {
     FillRun *run[2] = {nullptr, nullptr};   // resumable fill (plain, no-flats) in band mode
     GeoRun *geo = nullptr;                  // ... and the geodesic no-flats fill
     PfRun *pf = nullptr;                    // ... and the tiled priority-flood (plain fill)
+    DevBuf nodir_cnt;                       // interior NODIR cells of FLOWDIR, counted by the D8 kernel (the watersheds' fast-path test)
+    bool nodir_valid = false;
     int device = 0, rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     DevBuf r[MHIP_R_COUNT_];
@@ -607,6 +609,7 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
         for (int k = 0; k < MHIP_R_COUNT_; ++k)
             if (k != MHIP_R_DEM) c->have[k] = false;
     if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; }
+    if (which == MHIP_R_FLOWDIR) c->nodir_valid = false;
     return MHIP_OK;
 }
 
@@ -624,6 +627,7 @@ int mhip_ctx_upload_rows(mhip_ctx *c, int which, int64_t row0, int64_t nrows, co
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     if (which == MHIP_R_DEM)
         for (int k = 0; k < MHIP_R_COUNT_; ++k) c->have[k] = false;
+    if (which == MHIP_R_FLOWDIR) c->nodir_valid = false;
     MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * (size_t)(c->ht + row0), host, rowb * (size_t)nrows, hipMemcpyHostToDevice, cs(c)));
     MH_HIP(hipStreamSynchronize(cs(c)));      // the caller reuses its window buffer
     if (row0 + nrows == c->H_owned) {
@@ -1355,11 +1359,14 @@ static int stage_flowdir(mhip_ctx *c, hipStream_t s)
     MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_FLOWDIR, s, &e1));
+    MH_TRY(c->nodir_cnt.alloc(4));
+    MH_HIP(hipMemsetAsync(c->nodir_cnt.p, 0, 4, s));
     MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->H, c->W, 1, s, c->row0 - c->ht,
-                  c->H_global));
+                  c->H_global, c->nodir_cnt.as<unsigned int>()));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
     c->have[MHIP_R_FLOWDIR] = true;
+    c->nodir_valid = !c->ht && !c->hb;     // (a band's halo rows are computed from clamped data: their codes do not count)
     return MHIP_OK;
 }
 
@@ -1408,7 +1415,8 @@ static int stage_watershed(mhip_ctx *c, hipStream_t s)
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_WATERSHED, s, &e1));
     MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
-    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s));
+    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s, false,
+                          c->nodir_valid ? c->nodir_cnt.as<unsigned int>() : nullptr));
     MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
     MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s, W));
     MH_HIP(hipEventRecord(*e1, s));

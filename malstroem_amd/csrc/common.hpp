@@ -197,7 +197,7 @@ int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStr
 int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s);
 // d8.hip
 int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s, int64_t row_off = 0,
-           int64_t Hg = 0);
+           int64_t Hg = 0, unsigned int *d_interior_nodir = nullptr);   // d_interior_nodir (edges_outward only): left != 0 when an interior cell got NODIR (pre-zeroed by the caller)
 int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
 int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s);
@@ -238,7 +238,7 @@ int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d
 int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
 // watershed.hip
 int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s,
-                   bool band_mode = false);
+                   bool band_mode = false, const unsigned int *d_known_interior_nodir = nullptr);
 int band_pseudo_labels_dev(int32_t *d_ws, int64_t H, int64_t W, int top, int bottom, hipStream_t s);
 int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nlut, hipStream_t s);
 

@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned edge_code(int64_t r, int64_t c, int64_t maxr
 // ROWS_PER_WAVE: rows a wavefront walks down (2 extra halo rows are re-read); PF: rows loaded ahead of the one being computed
 template <int ROWS_PER_WAVE, bool NT, int PF>
 __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, uint8_t *__restrict__ out, int64_t H,
-                                                int64_t W, int edges_outward, int64_t row_off, int64_t Hg)
+                                                int64_t W, int edges_outward, int64_t row_off, int64_t Hg, unsigned int *nodir)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
     const bool fast = (c0 + STRIP <= W) && ((W & 1) == 0);
     const bool store32 = (c0 + STRIP <= W) && ((W & 3) == 0);
 
+    unsigned nnodir = 0;     // != 0: an interior cell without a downslope neighbour (none on a no-flats surface: the watersheds' fast path)
     Row6 up, mid, dn, nx;
     load_row<NT>(z, r_begin - 1, H, W, c, lane, fast, up);
     load_row<NT>(z, r_begin, H, W, c, lane, fast, mid);
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
                                mid.v[j], up.v[j]);
             packed |= code << (8 * j);
         }
+        // with edges flowing outward every border cell has a direction: a NODIR byte is an interior cell without a downslope
+        // neighbour ("does the word hold a zero byte" on packed ^ 0x08080808: four cells for four operations)
+        const unsigned v8 = packed ^ 0x08080808u;
+        nnodir |= (v8 - 0x01010101u) & ~v8 & 0x80808080u;
         if (store32) {
             *reinterpret_cast<uint32_t *>(out + r * W + c) = packed;
         } else {
@@ -163,19 +168,20 @@ __global__ __launch_bounds__(256) void d8_kernel(const double *__restrict__ z, u
         mid = dn;
         if (PF == 2) dn = nx;
     }
+    if (nodir && edges_outward && __any(nnodir != 0u) && lane == 0) atomicAdd(nodir, 1u);   // (only "none" / "some" matters)
 }
 
 }  // namespace
 
 int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s, int64_t row_off,
-           int64_t Hg)
+           int64_t Hg, unsigned int *d_interior_nodir)
 {
     if (Hg <= 0) Hg = H;
     // measured at 16384^2 (stage time, HIP events): 64 rows per wave 0.538 ms, 128 rows 0.524 (fewer halo rows re-read);
     // non-temporal loads 0.56-0.58, a second row in flight 0.54-0.62: the kernel is not waiting for memory latency
     constexpr int RPW = 128;
     hipLaunchKernelGGL((d8_kernel<RPW, false, 1>), dim3((unsigned)cdiv(cdiv(W, STRIP), 4), (unsigned)cdiv(H, RPW)), dim3(256), 0, s, d_z, d_out, H, W,
-                       edges_outward, row_off, Hg);
+                       edges_outward, row_off, Hg, d_interior_nodir);
     MH_HIP(hipGetLastError());
     return MHIP_OK;
 }

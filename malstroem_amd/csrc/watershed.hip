@@ -107,6 +107,148 @@ __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, i
     if (ch) *open = 1u;
 }
 
+// ---- fast path, tile first --------------------------------------------------------------------------------------------------
+// One workgroup resolves the pointers of a 64 x 64 tile in LDS (pull-only jumping on 16-bit tile-local indices: no atomics):
+// afterwards an unlabelled cell points at the labelled cell of ITS TILE it drains to (DONE), out of the raster (NONE), or at the
+// first cell of its path outside the tile -- an ENTRY cell on the perimeter of a neighbouring tile.  Only perimeter cells are
+// jumped through global memory (6 % of the raster, and one hop now crosses a tile); the final pass takes one more hop for the
+// cells that still point at an entry.
+constexpr int WT = 64;
+__global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict__ fd, const int32_t *__restrict__ lab, int32_t *__restrict__ P, int64_t H,
+                                                     int64_t W, int ntc, int32_t unassigned)
+{
+    __shared__ uint16_t ptr[WT * WT];
+    __shared__ int32_t val[WT * WT];     // of a terminal: its own index (labelled), NONE, or the entry cell its path continues at
+    const int ti = blockIdx.x / ntc, tj = blockIdx.x - ti * ntc;
+    const int64_t r0 = (int64_t)ti * WT, c0 = (int64_t)tj * WT;
+    // global I/O: a thread owns 16 consecutive cells of a tile row (one 16-byte load of the directions, four of the labels, four
+    // 16-byte stores); the jumping in between walks the table with consecutive lanes on consecutive cells
+    const int lr = threadIdx.x >> 2, lc0 = (threadIdx.x & 3) * 16;
+    const int64_t r = r0 + lr, cbase = c0 + lc0;
+    const bool vec = (W & 15) == 0 && r < H && cbase + 16 <= W;     // whole, 16-byte aligned group
+    uint8_t code[16];
+    int32_t lb[16];
+    if (vec) {
+        const uint4 cv = *reinterpret_cast<const uint4 *>(fd + r * W + cbase);
+        memcpy(code, &cv, 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int4 lv = *reinterpret_cast<const int4 *>(lab + r * W + cbase + 4 * q);
+            lb[4 * q] = lv.x; lb[4 * q + 1] = lv.y; lb[4 * q + 2] = lv.z; lb[4 * q + 3] = lv.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool in = r < H && cbase + k < W;
+            code[k] = in ? fd[r * W + cbase + k] : (uint8_t)8;
+            lb[k] = in ? lab[r * W + cbase + k] : unassigned;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int li = lr * WT + lc0 + k;
+        const int64_t c = cbase + k;
+        uint16_t p = (uint16_t)li;
+        int32_t v = NONE;
+        if (r < H && c < W) {
+            if (lb[k] != unassigned) {
+                v = (int32_t)(r * W + c);               // labelled: a fixed point
+            } else if (code[k] <= 7u) {
+                const int64_t nr = r + dir_dr((int)code[k]), nc = c + dir_dc((int)code[k]);
+                if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
+                    const int64_t lr2 = nr - r0, lc2 = nc - c0;
+                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) p = (uint16_t)(lr2 * WT + lc2);
+                    else v = (int32_t)(nr * W + nc);    // leaves the tile: the path continues at that entry cell
+                }
+            }
+        }
+        ptr[li] = p;
+        val[li] = v;
+    }
+    __syncthreads();
+    for (int round = 0; round < 13; ++round) {
+        bool ch = false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int li = k * 256 + (int)threadIdx.x;
+            const uint16_t p = ptr[li], q = ptr[p];
+            if (q != p) {
+                ptr[li] = q;        // racing readers see p or q: both further down the same path
+                ch = true;
+            }
+        }
+        if (!__syncthreads_or(ch)) break;
+    }
+    int32_t out[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int li = lr * WT + lc0 + k;
+        const int t = ptr[li];
+        const int64_t gt = (r0 + (t >> 6)) * W + c0 + (t & 63);
+        if (ptr[t] != t) out[k] = (int32_t)gt;              // a flow cycle inside the tile: never resolves
+        else {
+            const int32_t v = val[t];
+            out[k] = (v == (int32_t)gt && t != li) ? (v | DONE) : v;   // v: own index (a labelled cell keeps P == self), NONE, or an entry cell
+        }
+    }
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<int4 *>(P + r * W + cbase + 4 * q) = make_int4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (r < H && cbase + k < W) P[r * W + cbase + k] = out[k];
+    }
+}
+
+// the jump of ws_jump_kernel for the perimeter cells of the tiles only
+__global__ __launch_bounds__(256) void ws_jump_perimeter_kernel(int32_t *P, int64_t H, int64_t W, int ntc, int64_t ntiles, unsigned int *open)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = k >> 8;
+    const int p = (int)(k & 255);
+    if (tile >= ntiles || p >= 4 * WT - 4) return;
+    int lr, lc;
+    if (p < WT) { lr = 0; lc = p; }
+    else if (p < 2 * WT) { lr = WT - 1; lc = p - WT; }
+    else if (p < 3 * WT - 2) { lr = p - 2 * WT + 1; lc = 0; }
+    else { lr = p - (3 * WT - 2) + 1; lc = WT - 1; }
+    const int64_t r = (tile / ntc) * WT + lr, c = (tile % ntc) * WT + lc;
+    if (r >= H || c >= W) return;
+    const int64_t i = r * W + c;
+    int32_t t = P[i];
+    if (t < 0 || t == NONE || t == (int32_t)i) return;
+    const int32_t t0 = t;
+#pragma unroll
+    for (int h = 0; h < HOPS; ++h) {
+        const int32_t pt = P[t];
+        if (pt == t) {
+            t |= DONE;
+            break;
+        }
+        t = pt;
+        if (t < 0 || t == NONE) break;
+    }
+    if (t != t0) P[i] = t;
+    if (t >= 0 && t != NONE) *open = 1u;
+}
+
+// final pass of the fast path: a cell that still points at an entry cell takes that cell's (resolved) pointer
+__global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__restrict__ P, int32_t *lab, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t p = P[i];
+    if (p == NONE || p == (int32_t)i) return;      // flows out unlabelled, or labelled
+    if (p >= 0) {                                   // an entry cell
+        const int32_t q = P[p];
+        if (q == p) p = q | DONE;                   // the entry cell is labelled itself
+        else if (q < 0) p = q;                      // resolved through the entry cell
+        else return;                                // NONE, or a flow cycle: stays unassigned
+    }
+    lab[i] = lab[p & ~DONE];
+}
+
 __global__ __launch_bounds__(256) void ws_assign_kernel(const int32_t *__restrict__ P, const uint32_t *__restrict__ Q,
                                                        int32_t *lab, int64_t n, int32_t unassigned)
 {
@@ -151,7 +293,8 @@ int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nl
     return MHIP_OK;
 }
 
-int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s, bool band_mode)
+int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s, bool band_mode,
+                   const unsigned int *d_known_interior_nodir)
 {
     const int64_t n = H * W;
     if (n >= (int64_t)NONE - 1) {
@@ -164,9 +307,10 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     MH_TRY(flags.alloc(sizeof(unsigned int) * 4));
     MH_HIP(hipMemsetAsync(flags.p, 0, sizeof(unsigned int) * 4, s));
     unsigned int *d_cnt = flags.as<unsigned int>(), *d_changed = d_cnt + 2;
-    hipLaunchKernelGGL(ws_count_interior_nodir, dim3(grid), dim3(256), 0, s, d_fd, H, W, d_cnt);
     unsigned int interior_nodir = 0;
-    MH_HIP(hipMemcpyAsync(&interior_nodir, d_cnt, 4, hipMemcpyDeviceToHost, s));
+    // flow directions of unknown origin: count; the D8 kernel leaves the number next to its result
+    if (!d_known_interior_nodir) hipLaunchKernelGGL(ws_count_interior_nodir, dim3(grid), dim3(256), 0, s, d_fd, H, W, d_cnt);
+    MH_HIP(hipMemcpyAsync(&interior_nodir, d_known_interior_nodir ? d_known_interior_nodir : d_cnt, 4, hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     uint32_t *q = nullptr;
     if (interior_nodir && band_mode) {
@@ -176,6 +320,26 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     if (interior_nodir) {
         MH_TRY(Q.alloc(4 * (size_t)n));
         q = Q.as<uint32_t>();
+    }
+    if (!q) {
+        const int64_t ntr = cdiv(H, WT), ntc = cdiv(W, WT), ntiles = ntr * ntc;
+        hipLaunchKernelGGL(ws_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), H, W, (int)ntc, unassigned);
+        constexpr int MAX_ROUNDS = 40;   // x 5 hops over entry cells; flow cycles end here
+        for (int round = 0; round < MAX_ROUNDS;) {
+            const int k = round == 0 ? 2 : 1;
+            MH_HIP(hipMemsetAsync(d_changed, 0, 8, s));
+            for (int j = 0; j < k; ++j)
+                hipLaunchKernelGGL(ws_jump_perimeter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, P.as<int32_t>(), H, W, (int)ntc, ntiles, d_changed + j);
+            unsigned int h[2] = {0, 0};
+            MH_HIP(hipMemcpyAsync(h, d_changed, 8, hipMemcpyDeviceToHost, s));
+            MH_HIP(hipStreamSynchronize(s));
+            round += k;
+            if (!h[k - 1]) break;
+        }
+        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), d_labels, n);
+        MH_HIP(hipGetLastError());
+        MH_HIP(hipStreamSynchronize(s));
+        return MHIP_OK;
     }
     hipLaunchKernelGGL(ws_init_kernel, dim3(grid), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), q, H, W, unassigned);
     // two launches (paths up to 2**10 cells), then one at a time; every launch has its own "still open" flag

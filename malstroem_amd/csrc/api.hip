@@ -465,7 +465,7 @@ struct mhip_ctx {
     DevBuf comm_stage, comm_word, comm_flags;
     // second stream + fork/join events of the stage DAG (mhip_ctx_run)
     hipStream_t stream_b = nullptr, stream_c = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr, ev_label = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr, ev_label = nullptr, ev_tail = nullptr;
 };
 
 static size_t raster_elem(int which)
@@ -522,7 +522,11 @@ int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t ro
     c->H = H_local + c->ht + c->hb;
     c->W = W; c->H_global = H_global; c->row0 = row0;
     c->device = device; c->rank = rank; c->nranks = nranks;
-    if (hipStreamCreate(&c->stream) != hipSuccess) {
+    // the main stream carries the critical path (fill -> no-flats -> D8 -> accumulation): highest priority; the label / watershed
+    // branch of mhip_ctx_run fills the gaps on streams of the lowest
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest) != hipSuccess) {
         comm_destroy(c->comm);
         delete c;
         set_error("hipStreamCreate failed");
@@ -553,7 +557,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
             (void)hipStreamDestroy(st);
         }
     }
-    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label})
+    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label, c->ev_tail})
         if (e) (void)hipEventDestroy(e);
     delete c->geo;
     delete c->pf;
@@ -580,6 +584,7 @@ int mhip_ctx_side_begin(mhip_ctx *c)
         MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_label, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     }
     MH_HIP(hipEventRecord(c->ev_fork, c->stream));          // everything the main stream has been given so far ...
     MH_HIP(hipStreamWaitEvent(c->stream_b, c->ev_fork, 0));  // ... is visible to the side stream
@@ -1328,7 +1333,7 @@ static int stage_fill(mhip_ctx *c, hipStream_t s, bool with_depths = true)
 }
 
 // shdg_done: minimum_safe_short_and_diag of the current DEM is already in c->sh / c->dg (computed next to the fill)
-static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false)
+static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false, StageHook *tail_hook = nullptr)
 {
     const int64_t H = c->H, W = c->W, n = H * W;
     MH_ARG(c->have[MHIP_R_DEM], "NOFLAT needs the DEM");
@@ -1344,7 +1349,7 @@ static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false)
         c->have[MHIP_R_FILLED] = true;
     }
     MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st,
-                           c->r[MHIP_R_FILLED].as<float>()));
+                           c->r[MHIP_R_FILLED].as<float>(), tail_hook));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_NOFLAT] = true;
     c->noflat_rounds = st.rounds;
@@ -1495,20 +1500,39 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         MH_HIP(hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, least));
     }
-    if (!c->stream_c) MH_HIP(hipStreamCreateWithFlags(&c->stream_c, hipStreamNonBlocking));
+    if (!c->stream_c) {
+        int least = 0, greatest = 0;
+        MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        MH_HIP(hipStreamCreateWithPriority(&c->stream_c, hipStreamNonBlocking, least));
+    }
     if (!c->ev_fork) {
         MH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_label, hipEventDisableTiming));
+        MH_HIP(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     }
     hipStream_t sb = c->stream_b;
     const bool do_fill = (mask & MHIP_STAGE_FILL) != 0;
     MH_ARG(c->have[MHIP_R_DEM] || !(mask & (MHIP_STAGE_FILL | MHIP_STAGE_NOFLAT)), "FILL / NOFLAT need the DEM");
 
     // hand-overs between the two host threads (each value is an error code)
-    std::promise<int> fill_done, shdg_done, flowdir_ready, label_ready;
-    std::future<int> fill_fut = fill_done.get_future(), shdg_fut = shdg_done.get_future();
+    std::promise<int> fill_done, shdg_done, flowdir_ready, label_ready, tail_reached;
+    std::future<int> fill_fut = fill_done.get_future(), shdg_fut = shdg_done.get_future(), tail_fut = tail_reached.get_future();
+    // The label branch does not start with the no-flats fill but behind it (ev_tail).  Measured at 16384^2 (ms per step): label
+    // next to the whole no-flats fill 38.0 (the fill's rounds 14.6 instead of 9.8: every one of its ~85 small launches queues behind
+    // the labelling's long workgroups), from the fill's latency-bound tail rounds on 37.4, behind the fill 36.7 -- then labelling and
+    // watersheds run next to D8 + accumulation.  MHIP_LABEL_START = 0 / 1 / 2 selects (development knob).
+    struct TailCtx {
+        mhip_ctx *c;
+        std::promise<int> *p;
+    } tail_ctx{c, &tail_reached};
+    StageHook tail_hook;
+    tail_hook.arg = &tail_ctx;
+    tail_hook.fn = [](void *arg, hipStream_t st) {
+        TailCtx *t = static_cast<TailCtx *>(arg);
+        t->p->set_value(hipEventRecord(t->c->ev_tail, st) == hipSuccess ? MHIP_OK : MHIP_EHIP);
+    };
     std::future<int> flowdir_fut = flowdir_ready.get_future(), label_fut = label_ready.get_future();
     const bool ws_needs_new_flowdir = (mask & MHIP_STAGE_WATERSHED) && (mask & MHIP_STAGE_FLOWDIR);
     int rc_b = MHIP_OK;
@@ -1524,7 +1548,8 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
             shdg_done.set_value(rc_e);
             shdg_set = true;
             int rc_l = rc_e == MHIP_OK ? fill_fut.get() : rc_e;   // ev_fork has been recorded on the main stream
-            if (rc_l == MHIP_OK && hipStreamWaitEvent(sb, c->ev_fork, 0) != hipSuccess) rc_l = MHIP_EHIP;
+            if (rc_l == MHIP_OK) rc_l = tail_fut.get();           // ... and ev_tail behind it (or at the same place)
+            if (rc_l == MHIP_OK && hipStreamWaitEvent(sb, c->ev_tail, 0) != hipSuccess) rc_l = MHIP_EHIP;
             if (rc_l == MHIP_OK && (mask & MHIP_STAGE_LABEL)) rc_l = stage_label(c, sb);   // incl. the bluespot depths
             else if (rc_l == MHIP_OK && do_fill && !c->have[MHIP_R_DEPTHS]) rc_l = stage_depths(c, sb);
             // both consumers (WATERSHED here, POURPOINTS on the main thread) want the final labels: settle them once
@@ -1561,13 +1586,16 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     const int rc_e = shdg_fut.get();
     if (rc_a == MHIP_OK) rc_a = [&]() -> int {
         MH_TRY(rc_e);
-        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, /*shdg_done=*/true));
+        static const int label_start = [] { const char *e = getenv("MHIP_LABEL_START"); return e ? atoi(e) : 2; }();   // 0: with the no-flats fill, 1: at its tail, 2: after it
+        if (label_start == 0) tail_hook.fire(s);
+        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, /*shdg_done=*/true, label_start == 1 ? &tail_hook : nullptr));
         if (mask & MHIP_STAGE_FLOWDIR) {
             MH_TRY(stage_flowdir(c, s));
             MH_HIP(hipEventRecord(c->ev_flowdir, s));
         }
         return MHIP_OK;
     }();
+    tail_hook.fire(s);                    // (no NOFLAT in the mask, or it failed early: the other thread is never left waiting)
     flowdir_ready.set_value(rc_a);
     if (rc_a == MHIP_OK && (mask & MHIP_STAGE_ACCUM)) rc_a = stage_accum(c, s);
     // POURPOINTS needs the final labels and the accumulation, not the watersheds: it runs next to them

@@ -163,6 +163,21 @@ struct PfRun {
     int solve(hipStream_t s);
     int publish_edges(hipStream_t s);
 };
+// a call-back fired once, on the stage's stream, at a chosen point of a stage (mhip_ctx_run starts the label branch when the
+// no-flats fill has left its throughput-bound first rounds: see api.hip)
+struct StageHook {
+    void (*fn)(void *, hipStream_t) = nullptr;
+    void *arg = nullptr;
+    bool fired = false;
+    void fire(hipStream_t s)
+    {
+        if (fn && !fired) {
+            fired = true;
+            fn(arg, s);
+        }
+    }
+};
+
 // noflat_geo.hip: the no-flats fill as an integer geodesic distance transform; resumable for row bands
 struct GeoRun {
     const float *dem = nullptr, *filled = nullptr;   // local raster incl. halo rows; `filled` = the converged plain fill
@@ -174,6 +189,7 @@ struct GeoRun {
     bool allow_partial = false;                       // flats of irregular levels: leave them to the caller (else: not applicable)
     double seed_add = 0;                              // ... with the upper bound F + seed_add in `out`
     bool partial = false;                             // set by end(): `out` still needs the float64 relaxation on those flats
+    StageHook *tail_hook = nullptr;                   // fired when the first batch of rounds has been launched
     struct Impl;
     Impl *impl;
     GeoRun();
@@ -188,11 +204,11 @@ struct GeoRun {
 };
 // noflat_geo.hip: MHIP_ELIMIT = not applicable, run the float64 relaxation
 int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
-                             hipStream_t s, FillStats *st, bool *partial);
+                             hipStream_t s, FillStats *st, bool *partial, StageHook *tail_hook = nullptr);
 int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok, int fixed_top = 0,
                       int fixed_bot = 0);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                    FillStats *st, const float *d_filled = nullptr);
+                    FillStats *st = nullptr, const float *d_filled = nullptr, StageHook *tail_hook = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);
 int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s);
 // d8.hip

@@ -778,6 +778,7 @@ int GeoRun::batch(hipStream_t s, bool *active)
             return MHIP_ENOTCONV;
         }
         MH_TRY(launch_rounds(s, BATCH));
+        if (tail_hook) tail_hook->fire(s);      // the throughput-bound rounds are behind this point of the stream
         uint32_t h_any[BATCH];
         MH_HIP(hipMemcpyAsync(h_any, m.d_any + (m.round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
@@ -863,9 +864,10 @@ int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_
 // which hold an upper bound (F + seed_add): the caller relaxes those in float64 and verifies.  MHIP_ELIMIT: not applicable to
 // this raster (NaN cells, epsilons without weights, a cell the verification rejects): the caller runs the float64 relaxation.
 int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
-                             hipStream_t s, FillStats *st, bool *partial)
+                             hipStream_t s, FillStats *st, bool *partial, StageHook *tail_hook)
 {
     GeoRun g;
+    g.tail_hook = tail_hook;
     g.dem = d_dem; g.filled = d_filled; g.out = d_out; g.H = H; g.W = W; g.sh = sh; g.dg = dg;
     g.allow_partial = partial != nullptr && seed_add == seed_add && seed_add < 1e300;
     g.seed_add = seed_add;

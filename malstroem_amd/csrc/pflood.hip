@@ -30,6 +30,7 @@
 // Capacity limits (basins / basin pairs / seed pairs / links per tile) raise an overflow flag and the caller falls back to
 // the iterative schedule (fill.hip), which has none; row bands with halo rows use the iterative schedule as well.
 #include "common.hpp"
+#include <algorithm>
 #include <vector>
 
 namespace mh {
@@ -683,8 +684,11 @@ constexpr int RT = BT + 2;                 // region edge (block + ring)
 constexpr int EMAX = 6144;                 // directed relaxations held in LDS per block (the rest is streamed from memory)
 struct SolveArgs {
     PfArgs a;
-    uint8_t *act_cur, *act_nxt;            // [nbr * nbc]
-    unsigned int *any_nxt;
+    unsigned int *mark_cur, *mark_nxt;     // [nbr * nbc] "is in the list of this / the next round"
+    const int *list_cur;                   // the blocks of this round ...
+    const unsigned int *count_cur;         // ... and how many
+    int *list_nxt;
+    unsigned int *count_nxt;
     unsigned long long *visits;
     int nbr, nbc;                          // blocks
     int first;                             // 1: every block
@@ -699,13 +703,21 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
     __shared__ int s_wake, s_over;
     const PfArgs &a = sa.a;
     const int t = threadIdx.x;
-    const int blk = blockIdx.x, bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
-    if (!sa.first) {
-        if (sa.act_cur[blk] == 0) return;              // block-uniform
-        __syncthreads();
-        if (t == 0) sa.act_cur[blk] = 0;               // this buffer is appended to again two rounds from now
+    // a resident grid walks the round's list: launching one workgroup per block of the raster (4489 x 1024 threads at 16384^2,
+    // nearly all of them only to find their block inactive) cost more than the visits themselves
+    const unsigned int nwork = sa.first ? (unsigned int)(sa.nbr * sa.nbc) : *sa.count_cur;
+    for (unsigned int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    __syncthreads();                                   // the LDS arrays of the previous visit are free
+    const int blk = sa.first ? (int)wi : sa.list_cur[wi], bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
+    if (t == 0) {
+        sa.mark_cur[blk] = 0u;                         // this buffer is appended to again two rounds from now
+        s_wake = 0;
+        s_over = 0;
     }
-    if (t == 0) { s_wake = 0; s_over = 0; }
+#ifdef PF_PROFILE
+    long long pk0 = __builtin_amdgcn_s_memtime(), pk1 = 0, pk2 = 0;
+    int pk_it = 0;
+#endif
     // ---- levels of the region
     for (int i = t; i < RT * RT * NSMAX; i += ST) {
         const int rt = i / NSMAX, k = i - rt * NSMAX;
@@ -739,23 +751,28 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
     __syncthreads();
     if (s_over) {   // block-uniform; more relaxations than LDS holds (6144 ~ 16 x 380): tell the caller to fall back
         if (t == 0) atomicOr(a.flags, 1u);
-        return;
+        continue;
     }
     const int NE = s_seg[BT * BT];
-    for (int bt = 0; bt < BT * BT; ++bt) {
+    // all 16 tiles at once (one tile after the other left 15 of 16 load latencies in a row on the critical path of the visit)
+    for (int idx = t; idx < BT * BT * (LMAX + SPMAX); idx += ST) {
+        const int bt = idx / (LMAX + SPMAX), e0 = idx - bt * (LMAX + SPMAX);
         const int p = bi * BT + bt / BT, q = bj * BT + bt % BT;
-        if (p >= a.ntr || q >= a.ntc) continue;        // block-uniform
+        if (p >= a.ntr || q >= a.ntc) continue;
         const int tile = p * a.ntc + q;
-        const int nl = s_nl[bt], seg = s_seg[bt], ne = s_seg[bt + 1] - seg;
+        const int nl = s_nl[bt], seg = s_seg[bt], ns = (s_seg[bt + 1] - seg - nl) / 2;
         const int base = ((bt / BT + 1) * RT + bt % BT + 1) * NSMAX;     // this tile's levels in L
-        for (int e = t; e < nl; e += ST) {
+        if (e0 < LMAX) {
+            const int e = e0;
+            if (e >= nl) continue;
             const unsigned long long v = a.links[(size_t)tile * LMAX + e];
             const uint32_t key = (uint32_t)(v >> 32);
             const int mylab = (int)(key >> 16), dir = (int)((key >> 8) & 0xffu), nlab = (int)(key & 0xffu);
             const int src = nlab == OCEAN ? 0xFFFF : ((bt / BT + dir / 3) * RT + bt % BT + dir % 3) * NSMAX + nlab;
             E[seg + e] = ((unsigned long long)(base + mylab) << 48) | ((unsigned long long)src << 32) | (uint32_t)v;
-        }
-        for (int e = t; e < (ne - nl) / 2; e += ST) {
+        } else {
+            const int e = e0 - LMAX;
+            if (e >= ns) continue;
             const unsigned long long v = a.spill[(size_t)tile * SPMAX + e];
             const uint32_t key = (uint32_t)(v >> 32);
             const int la = (int)(key >> 8), lb = (int)(key & 0xffu);
@@ -765,11 +782,22 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
         }
     }
     __syncthreads();
+#ifdef PF_PROFILE
+    pk1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- the block's fixed point
+    // a thread's relaxations stay in registers over the iterations (EMAX / ST = 6): only the levels are read from LDS
+    unsigned long long er[EMAX / ST];
+#pragma unroll
+    for (int k = 0; k < EMAX / ST; ++k) er[k] = t + k * ST < NE ? E[t + k * ST] : ~0ull;
     for (int it = 0; it < BT * BT * NSMAX; ++it) {
+#ifdef PF_PROFILE
+        ++pk_it;
+#endif
         bool ch = false;
-        for (int e = t; e < NE; e += ST) {
-            const unsigned long long r = E[e];
+#pragma unroll
+        for (int k = 0; k < EMAX / ST; ++k) {
+            const unsigned long long r = er[k];
             if (r == ~0ull) continue;
             const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
             const uint32_t v = max((uint32_t)r, src == 0xFFFF ? 0u : L[src]);
@@ -780,6 +808,9 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
         }
         if (!__syncthreads_or(ch)) break;
     }
+#ifdef PF_PROFILE
+    pk2 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- write back; wake the neighbouring blocks that hold a link to a seed whose level dropped
     bool moved = false;
     for (int i = t; i < BT * BT * NSMAX; i += ST) {
@@ -810,11 +841,24 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
         wake = (unsigned)s_wake;
         if (t < 9 && ((wake >> t) & 1u)) {
             const int p = bi + t / 3 - 1, q = bj + t % 3 - 1;
-            if (p >= 0 && p < sa.nbr && q >= 0 && q < sa.nbc) sa.act_nxt[p * sa.nbc + q] = 1;
+            if (p >= 0 && p < sa.nbr && q >= 0 && q < sa.nbc) {
+                const int nb = p * sa.nbc + q;
+                if (atomicExch(&sa.mark_nxt[nb], 1u) == 0u) sa.list_nxt[atomicAdd(sa.count_nxt, 1u)] = nb;
+            }
         }
-        if (t == 0 && wake) *sa.any_nxt = 1u;
     }
     if (t == 0) atomicAdd(sa.visits, 1ull);
+#ifdef PF_PROFILE
+    if (t == 0) {
+        const long long pk3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&a.prof[19], (unsigned long long)(pk1 - pk0));
+        atomicAdd(&a.prof[21], (unsigned long long)(pk2 - pk1));
+        atomicAdd(&a.prof[22], (unsigned long long)(pk3 - pk2));
+        atomicAdd(&a.prof[23], (unsigned long long)pk_it);
+        atomicAdd(&a.prof[20], (unsigned long long)NE);
+    }
+#endif
+    }   // the round's list
 }
 
 // ---- K4: final level of every basin, then the raster ---------------------------------------------------------------------
@@ -943,10 +987,10 @@ __global__ __launch_bounds__(256) void pf_edge_rows_kernel(PfArgs a, float *__re
     filled[r * a.W + c] = f;
 }
 
-__global__ void pf_set_bytes_kernel(uint8_t *p, int n)
+__global__ void pf_append_row_kernel(unsigned int *mark, int *list, unsigned int *count, int first, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 1;
+    if (i < n && atomicExch(&mark[first + i], 1u) == 0u) list[atomicAdd(count, 1u)] = first + i;
 }
 __global__ void pf_fill_f32_kernel(float *p, int64_t n, float v)
 {
@@ -960,8 +1004,9 @@ __global__ void pf_fill_f32_kernel(float *p, int64_t n, float v)
 struct PfRun::Impl {
     DevBuf ws;
     PfArgs a;
-    uint8_t *act = nullptr;
-    unsigned int *any = nullptr;
+    unsigned int *mark = nullptr;      // [2][nslots]
+    int *list = nullptr;               // [2][nslots]
+    unsigned int *any = nullptr;       // [round]: blocks in the list of that round
     unsigned long long *visits = nullptr;
     int64_t ntiles = 0;
     size_t nslots = 0;
@@ -990,14 +1035,17 @@ int PfRun::solve(hipStream_t s)
             const int r = m.round + k;
             SolveArgs sa;
             sa.a = m.a;
-            sa.act_cur = m.act + (size_t)(r & 1) * m.nslots;
-            sa.act_nxt = m.act + (size_t)((r + 1) & 1) * m.nslots;
-            sa.any_nxt = m.any + r + 1;
+            sa.mark_cur = m.mark + (size_t)(r & 1) * m.nslots;
+            sa.mark_nxt = m.mark + (size_t)((r + 1) & 1) * m.nslots;
+            sa.list_cur = m.list + (size_t)(r & 1) * m.nslots;
+            sa.list_nxt = m.list + (size_t)((r + 1) & 1) * m.nslots;
+            sa.count_cur = m.any + r;
+            sa.count_nxt = m.any + r + 1;
             sa.visits = m.visits;
             sa.nbr = m.nbr;
             sa.nbc = m.nbc;
             sa.first = r == 0;
-            hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)m.nslots), dim3(ST), 0, s, sa);
+            hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 512)), dim3(ST), 0, s, sa);   // two resident per CU
         }
         m.launches += PF_BATCH;
         MH_HIP(hipGetLastError());
@@ -1058,7 +1106,8 @@ int PfRun::begin(hipStream_t s)
     m.nbc = (int)cdiv(ntc, BT);
     m.nslots = (size_t)m.nbr * m.nbc;
     m.ntiles = ntiles;
-    const size_t o_act = off; off = al(off + m.nslots * 2);
+    const size_t o_act = off; off = al(off + m.nslots * 2 * 4);
+    const size_t o_list = off; off = al(off + m.nslots * 2 * 4);
     const size_t o_cnt = off; off = al(off + (size_t)(PF_MAXR + 2) * 4 + 64 + 32 * 8);
     MH_TRY(m.ws.alloc(off));
     char *b = m.ws.as<char>();
@@ -1081,7 +1130,8 @@ int PfRun::begin(hipStream_t s)
     a.flags = m.any + (PF_MAXR + 2);
     m.visits = reinterpret_cast<unsigned long long *>(a.flags + 2);
     a.prof = m.visits + 1;   // 24 words (inside the zeroed tail of the workspace)
-    m.act = reinterpret_cast<uint8_t *>(b + o_act);
+    m.mark = reinterpret_cast<unsigned int *>(b + o_act);
+    m.list = reinterpret_cast<int *>(b + o_list);
     m.round = 0;
     m.halo_dirty = false;
 
@@ -1108,9 +1158,12 @@ int PfRun::batch(hipStream_t s)
     if (!m.halo_dirty) return MHIP_OK;
     m.halo_dirty = false;
     hipLaunchKernelGGL(pf_halo_links_kernel, dim3((unsigned)(2 * m.a.ntc)), dim3(128), 0, s, m.a, (const float *)out);
-    uint8_t *cur = m.act + (size_t)(m.round & 1) * m.nslots;
-    hipLaunchKernelGGL(pf_set_bytes_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, cur, m.nbc);
-    hipLaunchKernelGGL(pf_set_bytes_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, cur + (size_t)(m.nbr - 1) * m.nbc, m.nbc);
+    // the blocks of the first and of the last tile row go into the list of the round that comes next
+    unsigned int *mark = m.mark + (size_t)(m.round & 1) * m.nslots;
+    int *list = m.list + (size_t)(m.round & 1) * m.nslots;
+    hipLaunchKernelGGL(pf_append_row_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, mark, list, m.any + m.round, 0, m.nbc);
+    if (m.nbr > 1)
+        hipLaunchKernelGGL(pf_append_row_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, mark, list, m.any + m.round, (m.nbr - 1) * m.nbc, m.nbc);
     MH_HIP(hipGetLastError());
     MH_TRY(solve(s));
     return publish_edges(s);

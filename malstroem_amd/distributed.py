@@ -1075,9 +1075,31 @@ class BandPipeline(object):
                 raise err[0] if err else RuntimeError("another band failed in this phase of the chain")
 
         try:
-            together([("noflat", self.noflat), ("flowdir", self.flowdir)], label_branch)
-            # like the single-GPU DAG: watersheds (need labels + flow directions) next to the accumulation
-            together([("accum", self.accum)], ws_branch)
+            if os.environ.get("MALSTROEM_BAND_LABEL_START", "noflat") == "fill":
+                together([("noflat", self.noflat), ("flowdir", self.flowdir)], label_branch)
+                together([("accum", self.accum)], ws_branch)
+            else:
+                # like the single-GPU DAG (csrc/api.hip, measured there): the no-flats fill has the GPU to itself -- its many small
+                # launches queue behind the labelling's long workgroups otherwise -- then labelling + watersheds (the latter
+                # need labels and flow directions) run next to D8 + accumulation
+                timed("noflat", self.noflat)
+                if self.comm.allreduce_max(0.0) > 0.0:      # (keeps the bands in step before the two-thread phase)
+                    raise RuntimeError("another band failed in the no-flats fill")
+                flow_ready = threading.Event()
+
+                def flowdir_then_signal():
+                    try:
+                        self.flowdir()
+                    finally:
+                        flow_ready.set()
+
+                def side():
+                    label_branch()
+                    flow_ready.wait()
+                    if not err:
+                        ws_branch()
+
+                together([("flowdir", flowdir_then_signal), ("accum", self.accum)], side)
         finally:
             sys.setswitchinterval(old_switch)
         if records:

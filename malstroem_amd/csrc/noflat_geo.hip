@@ -15,16 +15,19 @@
 // (V is a float32, the total rise stays far below a float32 step), where the ulp u is a constant and every value is a multiple
 // of u: fl(x + eps) = x + rn(eps / u) * u exactly, whatever x.  So  G = V + u * D  with D the chamfer distance for the INTEGER
 // weights S = rn(short / u), Dg = rn(diag / u) -- order independent, exact in uint32.  A level whose binade does not give such
-// weights (V = 0, denormals, NaN/inf, a tie in the rounding, weights out of range) is IRREGULAR; any irregular flat cell sends
-// the whole raster to the float64 relaxation of fill.hip.
+// weights (V = 0, denormals, inf, a tie in the rounding, weights out of range) is IRREGULAR: its flat cells are left alone here
+// (distance word D_IRR) and get the upper bound F + seed_add in the surface; so does a distance that outgrows the uint32
+// headroom.  The caller settles those flats with the float64 relaxation of fill.hip (a "partial" surface).  NaN cells: not for
+// this path at all.
 // None of this is trusted: after the distances are turned into G, ng_verify_kernel evaluates (*) at EVERY cell in the
-// reference's own float64 arithmetic.  One mismatch anywhere -> the caller runs the float64 relaxation instead.
+// reference's own float64 arithmetic.  One mismatch anywhere -> the caller runs the float64 relaxation from scratch.
 //
-// Kernels.  ng_first (every tile once): classifies the window from F -- per cell a 16-bit word = same-level adjacency byte |
-// binade class << 8 -- and keeps it as a block per tile.  ng_first / ng_round (one launch per round): a wavefront holds a 64 x 64 window (62 x 62 tile + halo ring) of distances in 64 VGPRs
-// and relaxes it by row-sequential passes (down, up; transposed through wave-private LDS: right, left) with DPP neighbours;
-// a tile whose edge cells moved marks the neighbouring tiles for the next round (one byte per tile, plain stores -- no
-// atomics, no work lists: wave w owns the tiles w, w + nwaves, ... and scans their marks with one vector load).
+// Kernels.  ng_first (every tile once, one wavefront per 62 x 62 tile + ring): classifies the window from F -- per cell a 16-bit
+// word = same-level adjacency byte | binade class << 8 -- builds the words of both layouts the passes want and keeps them as a
+// 16 KB block per tile + a header; writes the start distances.  ng_round (one launch per round, tiles from a compacted list): a
+// wavefront holds the 64 x 64 window of distances in 64 VGPRs and relaxes it by row-sequential passes (down, up; transposed
+// through wave-private LDS: right, left) with DPP neighbours; a tile whose edge cells moved marks the neighbouring tiles it
+// shares a flat with (one byte per tile, plain stores); ng_compact turns the marks into the next round's list.
 // ng_assemble (streaming): G = F + u * D.  ng_verify (streaming): (*).
 #include <algorithm>
 #include <cmath>
@@ -49,9 +52,6 @@ constexpr int DPP_WF_SL1 = 0x130;          // lane i <- lane i+1
 constexpr int DPP_WF_SR1 = 0x138;          // lane i <- lane i-1
 #ifndef NG_MAXCYC
 #define NG_MAXCYC 1      // local (down, up, right, left) cycles per visit; a visit that is cut off re-queues its own tile
-#endif
-#ifndef NG_FIRSTCYC
-#define NG_FIRSTCYC 1    // ... in the first round: flats that fit into one tile are finished there
 #endif
 enum { C_IRREGULAR = 0, C_UNREACHED = 1, C_MISMATCH = 2, C_FATAL = 3, C_STATS = 8 };   // counters[]; C_STATS: 64 x {visits, cycles}
 
@@ -651,7 +651,7 @@ struct GeoRun::Impl {
     int ntr = 0, ntc = 0, round = 0, used = 0;
     int64_t nt = 0;
     size_t lds = 0;
-    int maxcyc = NG_MAXCYC, firstcyc = NG_FIRSTCYC;
+    int maxcyc = NG_MAXCYC;
     bool debug = false;
     unsigned long long irregular = 0;
 };
@@ -675,7 +675,7 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
     a.blk = m.d_blk; a.hdr = m.d_hdr; a.mark = m.d_mark; a.list = m.d_list; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot;
     const unsigned grid = (unsigned)std::min<int64_t>((m.nt + 3) / 4, 512);
     for (int k = 0; k < nb; ++k, ++m.round) {
-        a.maxcyc = m.round == 0 ? m.firstcyc : m.maxcyc;
+        a.maxcyc = m.maxcyc;
         a.count = m.d_any + m.round;     // tiles of this round (round 0: every tile)
         if (m.round) {
             hipLaunchKernelGGL(ng_compact_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(m.d_mark), (int)((m.nt + 7) / 8),
@@ -696,8 +696,7 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
     Impl &m = *impl;
     static const bool off = [] { const char *e = getenv("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
     m.debug = getenv("MHIP_NG_DEBUG") != nullptr;
-    if (getenv("MHIP_NG_MAXCYC")) m.maxcyc = atoi(getenv("MHIP_NG_MAXCYC"));        // tuning knobs (development)
-    if (getenv("MHIP_NG_FIRSTCYC")) m.firstcyc = atoi(getenv("MHIP_NG_FIRSTCYC"));
+    if (getenv("MHIP_NG_MAXCYC")) m.maxcyc = atoi(getenv("MHIP_NG_MAXCYC"));        // tuning knob (development)
     *applicable = false;
     *active = false;
     if (off || !filled || H < 3 || W < 3) return MHIP_OK;

@@ -68,6 +68,7 @@ struct PfArgs {
     uint32_t *Lv;           // [ntiles * NSMAX] minimax level of every seed (keys)
     unsigned int *flags;    // [0]: overflow
     unsigned long long *prof;   // -DPF_PROFILE builds: clock ticks per phase of pf_tile_kernel, summed over the tiles
+    int stop;                   // -DPF_PHASES builds: pf_tile_kernel returns after phase `stop` - 1 (timing launches only)
 };
 
 #ifdef PF_PROFILE
@@ -79,6 +80,11 @@ struct PfArgs {
             atomicAdd(&a.prof[i], (unsigned long long)(now_ - pf_t0_));           \
             pf_t0_ = now_;                                                        \
         }                                                                         \
+    } while (0)
+#elif defined(PF_PHASES)
+#define PF_STAMP(i)                       \
+    do {                                  \
+        if ((a.stop & 0xff) == (i) + 1) return;    \
     } while (0)
 #else
 #define PF_STAMP(i)
@@ -127,7 +133,7 @@ __device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
     return C_VALID;
 }
 
-__global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_tile_kernel(PfArgs a)
 {
     // LDS plan (49 KB: three workgroups = 24 wavefronts per CU; the phases below are bound by LDS / barrier latency, not by
     // LDS bandwidth, so residency is what pays):
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
     __shared__ int s_scan[NT / 64];
     __shared__ int s_cnt, s_ne;
 
-    const int t = threadIdx.x, wc = t & 63, q = t >> 6;
+    const int t = threadIdx.x, wc = t & 63, q = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
     WinGeom g;
     g.r0 = (int64_t)ti * TI; g.c0 = (int64_t)tj * TI; g.H = a.H; g.W = a.W; g.fixed_top = a.fixed_top; g.fixed_bot = a.fixed_bot;
@@ -155,15 +161,27 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
 #ifdef PF_PROFILE
     long long pf_t0_ = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- S1: window -> LDS
+    // ---- S1: window -> LDS.  Buffer addressing: one per-lane byte offset + a scalar row offset (eight 64-bit addresses per thread
+    // cost the registers of a third resident workgroup); rows / columns outside the raster read a clamped cell and become KINV
     const int64_t cc = g.c0 + wc;
-    uint8_t mycls[CPT];
+    const int Wi = (int)W;
+    const int64_t row_b = g.r0 + wr0 < g.H ? g.r0 + wr0 : g.H - 1;                  // wave-uniform
+    const int nrow_in = (int)(g.H - row_b < CPT ? g.H - row_b : CPT);              // rows of the strip inside the raster (>= 1)
+    const int lane_b = (int)(cc < W ? wc : W - 1 - g.c0);
+    const __amdgpu_buffer_rsrc_t rdem = __builtin_amdgcn_make_buffer_rsrc((void *)(a.dem + row_b * W + g.c0), 0, 0x7fffffff, 0x00020000);
+    uint32_t clsw = 0;    // the classes of the strip's cells, four bits each (one register instead of CPT)
+    auto cls = [&](int k) -> uint8_t { return (uint8_t)((clsw >> (4 * k)) & 7u); };
+    {
+        int so = 0;
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int wr = wr0 + k;
-        const uint8_t c = cell_class(g, wr * WN + wc);
-        mycls[k] = c;
-        zk[wr * WN + wc] = c ? dem_key(a.dem[(g.r0 + wr) * W + cc]) : KINV;
+        for (int k = 0; k < CPT; ++k) {
+            const int wr = wr0 + k;
+            const uint8_t c = cell_class(g, wr * WN + wc);
+            clsw |= (uint32_t)c << (4 * k);
+            const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdem, lane_b * 4, so * 4, 0));
+            zk[wr * WN + wc] = c ? dem_key(v) : KINV;
+            so = k + 1 < nrow_in ? so + Wi : so;
+        }
     }
     if (t == 0) { s_cnt = 0; s_ne = 0; }
     __syncthreads();
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
             const bool lower = valid && best < own;
             if (eq) eqmask |= 1u << k;
             if (lower) lowmask |= 1u << k;
-            ptr[ci] = (uint16_t)((lower && !(mycls[k] & C_BORDER)) ? bi : ci);   // a raster border cell is a root by decree (OCEAN)
+            ptr[ci] = (uint16_t)((lower && !(cls(k) & C_BORDER)) ? bi : ci);   // a raster border cell is a root by decree (OCEAN)
 #pragma unroll
             for (int j = 0; j < 3; ++j) { up[j] = mid[j]; mid[j] = dn[j]; }
         }
@@ -218,7 +236,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
             comp[ci] = (uint16_t)ci;
             uint16_t cand = NODRAIN;
             if ((eqmask >> k) & 1u) {
-                if (mycls[k] & C_BORDER) cand = (uint16_t)ci;
+                if (cls(k) & C_BORDER) cand = (uint16_t)ci;
                 else if ((lowmask >> k) & 1u) cand = ptr[ci];       // still the steepest-descent target
             }
             drain[ci] = cand;
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
         }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
-            if (!((eqmask >> k) & 1u) || (mycls[k] & C_BORDER)) continue;
+            if (!((eqmask >> k) & 1u) || (cls(k) & C_BORDER)) continue;
             const int ci = (wr0 + k) * WN + wc;
             const uint16_t root = comp[ci];
             if (root != (uint16_t)ci) ptr[ci] = root;
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
     for (int k = 0; k < CPT; ++k) {
         const int ci = (wr0 + k) * WN + wc;
         myroot[k] = ptr[ci];
-        if (mycls[k] && myroot[k] == (uint16_t)ci) {
+        if (cls(k) && myroot[k] == (uint16_t)ci) {
             rootmask |= 1u << k;
             ++nroot;
         }
@@ -319,15 +337,15 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
         ptr[ci] = (uint16_t)s;
         unsigned long long key = ~0ull;
         uint8_t ty = 1;
-        if (mycls[k] & C_BORDER) { key = ((unsigned long long)zk[ci] << 32) | OCEAN; ty = 0; }
-        else if (mycls[k] & C_RING) { key = ((unsigned long long)zk[ci] << 32) | (unsigned)ring_pos(wr, wc); ty = 0; }
+        if (cls(k) & C_BORDER) { key = ((unsigned long long)zk[ci] << 32) | OCEAN; ty = 0; }
+        else if (cls(k) & C_RING) { key = ((unsigned long long)zk[ci] << 32) | (unsigned)ring_pos(wr, wc); ty = 0; }
         bkey[s] = key;
         btype[s] = ty;
     }
     __syncthreads();
     uint16_t myslot[CPT];
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) myslot[k] = mycls[k] ? ptr[myroot[k]] : (uint16_t)0xFFFF;
+    for (int k = 0; k < CPT; ++k) myslot[k] = cls(k) ? ptr[myroot[k]] : (uint16_t)0xFFFF;
     __syncthreads();
     // ring cells inside an interior-pit basin are outlets of that basin at their own elevation; and every cell's basin slot
     // replaces its pointer
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
     for (int k = 0; k < CPT; ++k) {
         const int wr = wr0 + k;
         ptr[wr * WN + wc] = myslot[k];
-        if (!(mycls[k] & C_RING)) continue;
+        if (!(cls(k) & C_RING)) continue;
         const int s = myslot[k];
         if (btype[s]) atomicMin(&bkey[s], ((unsigned long long)zk[wr * WN + wc] << 32) | (unsigned)ring_pos(wr, wc));
     }
@@ -348,26 +366,31 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
     bool overflow = false;
     {
         constexpr uint16_t NONE = 0xFFFF;
-        uint16_t sl[CPT + 1], sr[CPT + 1];
-        uint32_t zl[CPT + 1], zr[CPT + 1], myz[CPT];
-#pragma unroll
-        for (int j = 0; j <= CPT; ++j) {
-            const int row = wr0 + j;
-            const bool okl = row < WN && wc > 0, okr = row < WN && wc < WN - 1;
-            sl[j] = okl ? ptr[row * WN + wc - 1] : NONE;
-            zl[j] = okl ? zk[row * WN + wc - 1] : KINV;
-            sr[j] = okr ? ptr[row * WN + wc + 1] : NONE;
-            zr[j] = okr ? zk[row * WN + wc + 1] : KINV;
-        }
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) myz[k] = zk[(wr0 + k) * WN + wc];
-        const bool below = wr0 + CPT < WN;
-        const uint16_t s_dn = below ? ptr[(wr0 + CPT) * WN + wc] : NONE;
-        const uint32_t z_dn = below ? zk[(wr0 + CPT) * WN + wc] : KINV;
+        // a rolling window of the strip's column and its left / right neighbour columns (slots and elevations), read from LDS
+        // two rows ahead: the reads of row k + 2 are in flight while the pairs between rows k and k + 1 are folded.  Reads are
+        // unconditional at clamped addresses and masked afterwards (a conditional read is a branch and a wait each).  The loop
+        // is NOT unrolled and keeps no per-row registers (unrolled, with the probe loops of the slow path, this phase alone was
+        // 70 000 instructions -- more than the instruction cache -- and its registers cost the third resident workgroup)
+        const uint32_t ml = wc > 0 ? 0u : 0xFFFFFFFFu, mr = wc < WN - 1 ? 0u : 0xFFFFFFFFu;   // no column there: NONE / KINV
+        const int cl = wc > 0 ? wc - 1 : 0, cr = wc < WN - 1 ? wc + 1 : WN - 1;
+        struct Row { uint32_t sl, sc, sr, zl, zc, zr; };
+        auto rd_row = [&](int row) -> Row {
+            const uint32_t mrow = row < WN ? 0u : 0xFFFFFFFFu;      // wave-uniform
+            const int rb = (row < WN ? row : WN - 1) * WN;
+            Row r;
+            r.sl = ((uint32_t)ptr[rb + cl] | ml | mrow) & 0xFFFFu;
+            r.sc = ((uint32_t)ptr[rb + wc] | mrow) & 0xFFFFu;
+            r.sr = ((uint32_t)ptr[rb + cr] | mr | mrow) & 0xFFFFu;
+            r.zl = zk[rb + cl] | ml | mrow;
+            r.zc = zk[rb + wc] | mrow;
+            r.zr = zk[rb + cr] | mr | mrow;
+            return r;
+        };
+        Row ra = rd_row(wr0), rb1 = rd_row(wr0 + 1);
         // LDS atomics are the expensive instruction here (several cycles per active lane, more when lanes share a slot): a
         // thread first folds its 4 * CPT candidates into a register set of distinct pairs (adjacent cells mostly straddle the
         // same two basins) and only the set goes to the hash; a candidate that finds the set full goes there directly
-        constexpr int NCK = 6;
+        constexpr int NCK = 4;
         uint32_t ck[NCK], cw[NCK];
 #pragma unroll
         for (int j = 0; j < NCK; ++j) { ck[j] = EMPTY; cw[j] = EMPTY; }
@@ -378,6 +401,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
 #endif
         auto hash_insert = [&](uint32_t key, uint32_t w) {
             unsigned hh = (key * 2654435761u) >> 21;
+#pragma nounroll
             for (int probe = 0; probe < 64; ++probe) {
                 const uint32_t pv = atomicCAS(&hk[hh], EMPTY, key);
                 if (pv == EMPTY || pv == key) {
@@ -388,16 +412,17 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
             }
             return false;
         };
-#pragma unroll
+#pragma nounroll
         for (int k = 0; k < CPT; ++k) {
-            const uint32_t sa = myslot[k], own = myz[k];
-            const uint16_t nb[4] = {sr[k], sl[k + 1], k + 1 < CPT ? myslot[k + 1] : s_dn, sr[k + 1]};
-            const uint32_t nz[4] = {zr[k], zl[k + 1], k + 1 < CPT ? myz[k + 1] : z_dn, zr[k + 1]};
+            const Row rc = rd_row(wr0 + k + 2);
+            const uint32_t sa = ra.sc, own = ra.zc;
+            const uint32_t nb[4] = {ra.sr, rb1.sl, rb1.sc, rb1.sr};
+            const uint32_t nz[4] = {ra.zr, rb1.zl, rb1.zc, rb1.zr};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const uint32_t sb = nb[d];
-                const bool cand = sa != NONE && sb != NONE && sb != sa;
-                const uint32_t key = cand ? (sa < sb ? (sa << 10 | sb) : (sb << 10 | sa)) : EMPTY;
+                const bool cand = (sa != NONE) & (sb != NONE) & (sb != sa);
+                const uint32_t key = cand ? (min(sa, sb) << 10 | max(sa, sb)) : EMPTY;
                 const uint32_t w = max(own, nz[d]);
                 bool placed = !cand;
 #pragma unroll
@@ -417,6 +442,8 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
                     if (!hash_insert(key, w)) overflow = true;
                 }
             }
+            ra = rb1;
+            rb1 = rc;
         }
         {
             uint32_t prev[NCK];
@@ -425,6 +452,9 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
             for (int j = 0; j < NCK; ++j) {
                 h[j] = (ck[j] * 2654435761u) >> 21;
                 prev[j] = EMPTY;
+#ifdef PF_PHASES
+                if (a.stop & 0x100) continue;
+#endif
                 if (ck[j] != EMPTY) prev[j] = atomicCAS(&hk[h[j]], EMPTY, ck[j]);
             }
 #pragma unroll
@@ -432,6 +462,10 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
                 if (ck[j] == EMPTY) continue;
 #ifdef PF_PROFILE
                 ++pf_nlive;
+#endif
+#ifdef PF_PHASES
+                if (a.stop & 0x100) { if (ck[j] + cw[j] == 12345u) overflow = true; continue; }
+                if (a.stop & 0x200) continue;
 #endif
                 if (prev[j] == EMPTY || prev[j] == ck[j]) atomicMin(&hv[h[j]], cw[j]);
                 else if (!hash_insert(ck[j], cw[j])) overflow = true;
@@ -541,14 +575,15 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
         a.tabL[(size_t)tile * NBMAX + sI] = cmap[(int)(bkey[sI] & 0xffu)];
     }
     if (t == 0) a.tileNB[tile] = NB;
+    const __amdgpu_buffer_rsrc_t rslot = __builtin_amdgcn_make_buffer_rsrc((void *)(a.bslot + (g.r0 + wr0) * W + g.c0), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int wr = wr0 + k;
-        const uint8_t c = mycls[k];
+        const uint8_t c = cls(k);
         if (!c || (c & C_BORDER)) continue;
-        const int sI = myslot[k];
+        const int sI = ptr[wr * WN + wc];
         if (c & C_RING) a.ringLab[(size_t)tile * 256 + ring_pos(wr, wc)] = cmap[(int)(bkey[sI] & 0xffu)];
-        else a.bslot[(g.r0 + wr) * W + cc] = (uint16_t)sI;
+        else __builtin_amdgcn_raw_buffer_store_b16((short)sI, rslot, wc * 2, k * Wi * 2, 0);   // (an owned cell: inside the raster)
     }
     PF_STAMP(7);
     // min spill elevation between pairs of seeds
@@ -563,6 +598,7 @@ __global__ __launch_bounds__(NT) void pf_tile_kernel(PfArgs a)
         const uint32_t k2 = la < lb ? (la << 8 | lb) : (lb << 8 | la);
         unsigned hh = (k2 * 2654435761u) >> 23;
         bool done = false;
+#pragma nounroll
         for (int probe = 0; probe < 64; ++probe) {
             const uint32_t prev = atomicCAS(&sk[hh], EMPTY, k2);
             if (prev == EMPTY || prev == k2) {
@@ -1114,7 +1150,7 @@ int PfRun::begin(hipStream_t s)
     MH_HIP(hipMemsetAsync(b + o_act, 0, off - o_act, s));                 // active bytes, per-round words, flags, visits
     MH_HIP(hipMemsetAsync(b + o_ring, NOLAB, (size_t)ntiles * 256, s));
     PfArgs &a = m.a;
-    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = dem; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot;
+    a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = dem; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot; a.stop = 0;
     a.bslot = reinterpret_cast<uint16_t *>(b + o_bslot);
     a.tabV = reinterpret_cast<uint32_t *>(b + o_tabV);
     a.tabL = reinterpret_cast<uint8_t *>(b + o_tabL);
@@ -1137,6 +1173,43 @@ int PfRun::begin(hipStream_t s)
 
     if (fixed_top) hipLaunchKernelGGL(pf_fill_f32_kernel, dim3((unsigned)cdiv(W, 256)), dim3(256), 0, s, out, W, __builtin_inff());
     if (fixed_bot) hipLaunchKernelGGL(pf_fill_f32_kernel, dim3((unsigned)cdiv(W, 256)), dim3(256), 0, s, out + (H - 1) * W, W, __builtin_inff());
+#ifdef PF_PHASES
+    {   // cumulative cost of the phases: the kernel cut short after each of them (development builds)
+        static const char *names[9] = {"load", "descent+plateaus", "doubling", "slots", "pairs", "compact", "label-correcting", "outputs", "spill"};
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        fprintf(stderr, "[pf_tile phases] cumulative ms:");
+        for (int st = 1; st <= 9; ++st) {
+            PfArgs b = a;
+            b.stop = st;
+            hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, b);
+            hipEventRecord(e0, s);
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, b);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            fprintf(stderr, " %s=%.2f", names[st - 1], ms / 3);
+        }
+        for (int var = 1; var <= 2; ++var) {
+            PfArgs b = a;
+            b.stop = 5 | (var << 8);
+            hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, b);
+            hipEventRecord(e0, s);
+            for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, b);
+            hipEventRecord(e1, s);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            fprintf(stderr, " | pairs %s=%.2f", var == 1 ? "without the flush atomics" : "with the CAS only", ms / 3);
+        }
+        fprintf(stderr, "\n");
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        MH_HIP(hipMemsetAsync(a.flags, 0, 4, s));
+    }
+#endif
     hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
     MH_HIP(hipGetLastError());

@@ -45,9 +45,7 @@ constexpr uint64_t SUM_MASK = (1ull << A_SHIFT) - 1;
 constexpr uint64_t A_MASK = 0x1fffull, R_MASK = 0xfffull, SENT13 = A_MASK;
 constexpr uint64_t FIELDS = (A_MASK << A_SHIFT) | (R_MASK << R_SHIFT);
 constexpr uint16_t NO_EXIT = 0xffffu;
-constexpr int ATN = 512;                  // threads per tile: eight wavefronts (three tiles = 24 wavefronts resident per CU; with 256
-                                          // threads the 16 cells per thread cost 146 VGPRs and 12 wavefronts had to hide the LDS atomics)
-constexpr int CPT = AT * AT / ATN;        // cells per thread
+constexpr int CPT = AT * AT / 256;        // cells per thread
 constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simple path
 // phase-2 node word: an exit cell can be fed by every entry of its tile (hundreds), so the pending field is wider
 constexpr int G_SHIFT = 44;
@@ -98,7 +96,7 @@ template <bool FINAL>
 // Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
 // final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
 // they never receive and are never written here.
-__global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
+__global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
                                                         int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot, int halo_zero)
 {
     auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
@@ -114,8 +112,14 @@ __global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // flow-direction window incl. the 1-cell ring; outside the raster = NODIR (never flows, never receives).
     // Per window row: four 16-byte chunks (the tile's own columns) + the two ring bytes.
     __shared__ __attribute__((aligned(16))) uint8_t win[(AT + 2) * FS];
+    __shared__ uint64_t inflow_l[FINAL ? NODE_STRIDE : 1];
+    __shared__ uint32_t arrived_l[FINAL ? NODE_STRIDE : 1];
+    if (FINAL) {  // what phase 2 delivered to my perimeter cells: one coalesced read per array
+        inflow_l[tid] = nd.inflow[(int64_t)tile * NODE_STRIDE + tid];
+        arrived_l[tid] = nd.arrived[(int64_t)tile * NODE_STRIDE + tid];
+    }
     const bool wide = (W % 16) == 0 && c0 + AT <= W;   // c0 is a multiple of 64: chunks are 16-byte aligned in global memory
-    for (int q = tid; q < (AT + 2) * 6; q += ATN) {
+    for (int q = tid; q < (AT + 2) * 6; q += 256) {
         const int wr = q / 6, k = q - wr * 6;
         const int64_t rr = r0 + wr - 1;
         const bool row_in = rr >= 0 && rr < H;
@@ -158,11 +162,11 @@ __global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
 
-    // my CPT cells: i = tid + ATN j (consecutive lanes = consecutive LDS words)
+    // my CPT cells: i = tid + 256 j (consecutive lanes = consecutive LDS words)
     uint64_t sreg[CPT];   // my cells' words as of the last barrier (what I push)
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int i = tid + ATN * j;
+        const int i = tid + 256 * j;
         const int r = i / AT, c = i - r * AT;
         const bool inside = (r0 + r) < H && (c0 + c) < W;
         const int slot = perim_slot(r, c);
@@ -176,9 +180,8 @@ __global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             v = halo_zero ? 0ull : (ext > 0.0 ? (uint64_t)ext : TAINT);
             deg_ext = 0;
         }
-        if (FINAL && deg_ext && inside) {   // what phase 2 delivered to this perimeter cell (read straight from the node arrays: a staging copy
-                                            // in LDS cost the fourth resident tile)
-            if (nd.arrived[(int64_t)tile * NODE_STRIDE + slot] == deg_ext) v += nd.inflow[(int64_t)tile * NODE_STRIDE + slot];
+        if (FINAL && deg_ext && inside) {
+            if (arrived_l[slot] == deg_ext) v += inflow_l[slot];
             else v |= TAINT;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
         }
         // downstream cell: inside the tile, the raster and the band, else the path ends here
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         bool mine = false;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int i = tid + ATN * j;
+            const int i = tid + 256 * j;
             if (((sreg[j] >> A_SHIFT) & A_MASK) != SENT13) {
                 const uint64_t w = (S[i] & ~FIELDS) | (got[j] & FIELDS);   // S_{k+1} | A_{k+1} | R_{k+1}
                 S[i] = w;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (FINAL) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int i = tid + ATN * j;
+            const int i = tid + 256 * j;
             const int r = i / AT, c = i - r * AT;
             if ((r0 + r) < H && (c0 + c) < W && !halo_row(r0 + r)) {
                 const uint64_t s = S[i];
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(ATN) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (nd.halo_first) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int i = tid + ATN * j;
+            const int i = tid + 256 * j;
             const int r = i / AT, c = i - r * AT;
             if (!((r0 + r) < H && (c0 + c) < W && halo_row(r0 + r))) continue;
             const uint64_t s = S[i];
@@ -447,13 +450,13 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     nd.bexit = d_exit_map ? reinterpret_cast<int32_t *>(b + o_bexit) : nullptr;
     if (d_exit_map) MH_HIP(hipMemsetAsync(nd.halo_first, 0xff, 8 * (size_t)W, s));
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
-    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     hipLaunchKernelGGL(accum_link_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     if (d_exit_map)
         hipLaunchKernelGGL(accum_band_exit_kernel, dim3((unsigned)cdiv(2 * W, 256)), dim3(256), 0, s, nd, H, W, ntc, ntiles, fixed_top, fixed_bot, d_exit_map);
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
-    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
 #ifdef MH_PROFILE_ACCUM

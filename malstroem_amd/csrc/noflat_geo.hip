@@ -92,6 +92,14 @@ struct GeoArgs {
     const uint32_t *tab;            // [256] S | [256] Dg by class
     unsigned long long *counters;
     int maxcyc;                     // local cycles per visit in this round
+    // light rounds (few tiles: the tail, where a launch is worth as much as the visits): no mark bytes and no compaction launch, a
+    // woken tile is appended to the next round's list at once.  amark[t] = the last round t was listed for (atomicMax: one entry
+    // per round whoever wakes it, and a wake in round r always gives a visit in round r + 1 -- the tile's visit of round r may
+    // have run before the waker's stores)
+    int append, round_next;
+    int *amark;                     // [nt]
+    int *list_next;
+    uint32_t *count_next;
     int fixed_top, fixed_bot;       // row band: local row 0 / H - 1 is a halo row of the neighbouring band (not a raster border, not mine)
 };
 
@@ -287,6 +295,9 @@ constexpr uint32_t HDR_ACTIVE = 1u << 31, HDR_UNIFORM = 1u << 9, HDR_OPEN = 1u <
 template <bool FIRST>
 __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &visits, unsigned &cycles)
 {
+#ifdef NG_PROFILE
+    const long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
     const int64_t H = a.H, W = a.W;
     const int ti = t / a.ntc, tj = t - ti * a.ntc;
     const int64_t r0 = (int64_t)ti * TI, c0 = (int64_t)tj * TI;
@@ -475,6 +486,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     }
     ++visits;
     __builtin_amdgcn_sched_barrier(0);
+#ifdef NG_PROFILE
+    const long long tp1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long tp2 = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t eref = (hdr >> 16) & 0xffu;
     unsigned wake = 0;
     bool changed = false, capped = false;
@@ -482,6 +498,9 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     else if (hdr & HDR_UNIFORM) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     wake &= hdr & 0x1ffu;
+#ifdef NG_PROFILE
+    const long long tp3 = __builtin_amdgcn_s_memtime();
+#endif
 
     if (changed) {
         const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
@@ -493,11 +512,37 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     }
     if (capped) wake |= 1u << 4;
     if (wake) {
-        if (lane < 9 && ((wake >> lane) & 1u)) {
-            const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
-            if (p >= 0 && p < a.ntr && q >= 0 && q < a.ntc) a.mark[(int64_t)p * a.ntc + q] = 1;
+        const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
+        const bool mine = lane < 9 && ((wake >> lane) & 1u) && p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
+        const int tp = p * a.ntc + q;
+        if (!FIRST && a.append) {
+            bool fresh = false;
+            if (mine) fresh = atomicMax(&a.amark[tp], a.round_next) < a.round_next;
+            const uint64_t bal = __ballot(fresh);
+            if (bal) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.count_next, (uint32_t)__builtin_popcountll(bal));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (fresh) a.list_next[base + (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull))] = tp;
+            }
+        } else if (mine) {
+            a.mark[tp] = 1;
         }
     }
+#ifdef NG_PROFILE
+    if (!FIRST) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long tp4 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            const int o = C_STATS + 128 + ((hdr & HDR_OPEN) ? 8 : 0);
+            atomicAdd(&a.counters[o + 0], 1ull);
+            atomicAdd(&a.counters[o + 1], (unsigned long long)(tp1 - tp0));
+            atomicAdd(&a.counters[o + 2], (unsigned long long)(tp2 - tp1));
+            atomicAdd(&a.counters[o + 3], (unsigned long long)(tp3 - tp2));
+            atomicAdd(&a.counters[o + 4], (unsigned long long)(tp4 - tp3));
+        }
+    }
+#endif
 }
 
 template <bool FIRST>
@@ -647,8 +692,10 @@ struct GeoRun::Impl {
     uint32_t *d_tab = nullptr, *d_any = nullptr, *d_hdr = nullptr, *d_blk = nullptr;
     unsigned long long *d_cnt = nullptr;
     uint8_t *d_mark = nullptr;
-    int *d_list = nullptr;
+    int *d_list = nullptr, *d_list2 = nullptr, *d_amark = nullptr;
     int ntr = 0, ntc = 0, round = 0, used = 0;
+    bool light = false;          // the rounds from light_from on append to the next round's list themselves
+    int light_from = 0;
     int64_t nt = 0;
     size_t lds = 0;
     int maxcyc = NG_MAXCYC;
@@ -657,6 +704,7 @@ struct GeoRun::Impl {
 };
 namespace {
 constexpr int MAXR = 8192, BATCH = 16;
+constexpr uint32_t LIGHT_TILES = 6144;     // a round of at most this many tiles appends to the next list (one atomic per wake)
 __global__ void ng_mark_row_kernel(uint8_t *mark, int ti, int ntc)
 {
     const int tj = blockIdx.x * blockDim.x + threadIdx.x;
@@ -673,17 +721,28 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
     GeoArgs a;
     a.H = H; a.W = W; a.ntr = m.ntr; a.ntc = m.ntc; a.nt = (int)m.nt; a.F = filled; a.d = dist; a.tab = m.d_tab; a.counters = m.d_cnt;
     a.blk = m.d_blk; a.hdr = m.d_hdr; a.mark = m.d_mark; a.list = m.d_list; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot;
+    a.append = 0; a.round_next = 0; a.amark = m.d_amark; a.list_next = nullptr; a.count_next = nullptr;
     const unsigned grid = (unsigned)std::min<int64_t>((m.nt + 3) / 4, 512);
     for (int k = 0; k < nb; ++k, ++m.round) {
         a.maxcyc = m.maxcyc;
         a.count = m.d_any + m.round;     // tiles of this round (round 0: every tile)
-        if (m.round) {
+        if (!m.round) {
+            hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), m.lds, s, a);
+            continue;
+        }
+        // the marks of the last mark-mode round become the list of this one
+        if (!m.light || m.round == m.light_from)
             hipLaunchKernelGGL(ng_compact_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(m.d_mark), (int)((m.nt + 7) / 8),
                                m.d_list, m.d_any + m.round);
-            hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), m.lds, s, a);
-        } else {
-            hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), m.lds, s, a);
+        if (m.light) {
+            const bool odd = ((m.round - m.light_from) & 1) != 0;
+            a.append = 1;
+            a.round_next = m.round + 1;
+            a.list = odd ? m.d_list2 : m.d_list;
+            a.list_next = odd ? m.d_list : m.d_list2;
+            a.count_next = m.d_any + m.round + 1;
         }
+        hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), m.lds, s, a);
     }
     MH_HIP(hipGetLastError());
     return MHIP_OK;
@@ -719,8 +778,9 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
     m.nt = (int64_t)m.ntr * m.ntc;
     auto align = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t o_d = 0, o_tab = align(o_d + (dist ? 0 : 4 * (size_t)n)), o_cnt = align(o_tab + 2048);
-    const size_t o_any = align(o_cnt + 8 * (C_STATS + 128)), o_mark = align(o_any + 4 * (size_t)(MAXR + BATCH));
-    const size_t o_list = align(o_mark + (size_t)m.nt + 8), o_hdr = align(o_list + 4 * (size_t)m.nt), o_blk = align(o_hdr + 4 * (size_t)m.nt);
+    const size_t o_any = align(o_cnt + 8 * (C_STATS + 128 + 16)), o_mark = align(o_any + 4 * (size_t)(MAXR + BATCH));
+    const size_t o_amark = align(o_mark + (size_t)m.nt + 8), o_list = align(o_amark + 4 * (size_t)m.nt), o_list2 = align(o_list + 4 * (size_t)m.nt);
+    const size_t o_hdr = align(o_list2 + 4 * (size_t)m.nt), o_blk = align(o_hdr + 4 * (size_t)m.nt);
     MH_TRY(m.ws.alloc(o_blk + 4 * (size_t)m.nt * WN * WN + 256));
     char *b = m.ws.as<char>();
     if (!dist) dist = reinterpret_cast<uint32_t *>(b + o_d);
@@ -729,6 +789,8 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
     m.d_any = reinterpret_cast<uint32_t *>(b + o_any);
     m.d_mark = reinterpret_cast<uint8_t *>(b + o_mark);
     m.d_list = reinterpret_cast<int *>(b + o_list);
+    m.d_list2 = reinterpret_cast<int *>(b + o_list2);
+    m.d_amark = reinterpret_cast<int *>(b + o_amark);
     m.d_hdr = reinterpret_cast<uint32_t *>(b + o_hdr);
     m.d_blk = reinterpret_cast<uint32_t *>(b + o_blk);
     MH_HIP(hipMemsetAsync(b + o_cnt, 0, o_list - o_cnt, s));
@@ -771,6 +833,7 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
 int GeoRun::batch(hipStream_t s, bool *active)
 {
     Impl &m = *impl;
+    static const bool no_light = getenv("MHIP_NG_NOLIGHT") != nullptr;   // development knob
     for (;;) {
         if (m.round + BATCH > MAXR) {
             set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
@@ -784,9 +847,14 @@ int GeoRun::batch(hipStream_t s, bool *active)
         for (int k = 0; k < BATCH; ++k) {
             if (!h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
                 *active = false;
+                m.light = false;   // (a band's halo exchange wakes tiles through the mark bytes: the next round compacts them)
                 return MHIP_OK;
             }
             ++m.used;
+        }
+        if (!m.light && h_any[BATCH - 1] <= LIGHT_TILES && !no_light) {   // the tail: from here on the rounds build their lists themselves
+            m.light = true;
+            m.light_from = m.round;
         }
     }
 }
@@ -810,7 +878,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
         hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, dem, out, H, W, sh, dg,
                            fixed_top, fixed_bot, m.d_cnt);
     MH_HIP(hipGetLastError());
-    unsigned long long h_all[C_STATS + 128];
+    unsigned long long h_all[C_STATS + 128 + 16];
     MH_HIP(hipMemcpyAsync(h_all, m.d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
     if (allow_partial && h_all[C_UNREACHED]) partial = true;      // (the verification above then reported those cells: ignored)
@@ -834,6 +902,13 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
         }
         fprintf(stderr, "[noflat geodesic] tiles %lld, visits %llu, cycles %llu; tiles per round:", (long long)m.nt, v, cy);
         for (int k = 1; k < m.round && k < 200; ++k) fprintf(stderr, " %u", cnt[k]);
+#ifdef NG_PROFILE
+        for (int o = 0; o < 2; ++o) {
+            const unsigned long long *q = h_all + C_STATS + 128 + 8 * o;
+            if (q[0]) fprintf(stderr, "\n[noflat visits, %s] %llu: ticks per visit: setup+issue %.0f, wait for loads %.0f, relax %.0f, store %.0f", o ? "open" : "masked", q[0],
+                              (double)q[1] / q[0], (double)q[2] / q[0], (double)q[3] / q[0], (double)q[4] / q[0]);
+        }
+#endif
         fprintf(stderr, "\n[noflat geodesic] %lld x %lld: rounds %d, unreached %llu, mismatches %llu\n", (long long)H, (long long)W, m.used, h_all[C_UNREACHED],
                 h_all[C_MISMATCH]);
     }
@@ -847,7 +922,7 @@ int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_
                       int fixed_bot)
 {
     DevBuf cnt;
-    MH_TRY(cnt.alloc(8 * (C_STATS + 128)));
+    MH_TRY(cnt.alloc(8 * (C_STATS + 128 + 16)));
     MH_HIP(hipMemsetAsync(cnt.p, 0, 8 * (C_STATS + 128), s));
     hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, d_dem, d_out, H, W, sh, dg, fixed_top,
                        fixed_bot, cnt.as<unsigned long long>());

@@ -8,15 +8,36 @@ namespace mh {
 namespace {
 
 // ---- min/max reduction for minimum_safe_short_and_diag -------------------------------------------
+// 16-byte loads, four in flight per thread (4-byte loads in a rolled grid-stride loop ran at 1.9 TB/s); the unaligned head and
+// the tail of the array go through thread 0 of block 0
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, int64_t n, unsigned int *out)
 {
     float mx = -__builtin_inff(), mn = __builtin_inff();
     bool has_nan = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = x[i];
+    auto take = [&](float v) {
         has_nan |= v != v;
         mx = fmaxf(mx, v);
         mn = fminf(mn, v);
+    };
+    const int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2) < n ? (int64_t)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2) : n;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x + head);
+    const int64_t n4 = (n - head) >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        take(a.x); take(a.y); take(a.z); take(a.w);
+        take(b.x); take(b.y); take(b.z); take(b.w);
+        take(c.x); take(c.y); take(c.z); take(c.w);
+        take(d.x); take(d.y); take(d.z); take(d.w);
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = x4[i];
+        take(a.x); take(a.y); take(a.z); take(a.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int64_t k = 0; k < head; ++k) take(x[k]);
+        for (int64_t k = head + (n4 << 2); k < n; ++k) take(x[k]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -55,7 +76,7 @@ int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, 
     MH_TRY(acc.alloc(sizeof(unsigned int) * 4));
     unsigned int init[4] = {0u, 0xffffffffu, 0u, 0u};
     MH_HIP(hipMemcpyAsync(acc.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-    const unsigned grid = (unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
+    const unsigned grid = (unsigned)(cdiv(n, 1024) < 4096 ? cdiv(n, 1024) : 4096);
     hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, d_x, n, acc.as<unsigned int>());
     MH_HIP(hipGetLastError());
     unsigned int h[4];
@@ -192,7 +213,7 @@ int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStr
     MH_TRY(acc.alloc(sizeof(unsigned int) * 4));
     unsigned int init[4] = {0u, 0xffffffffu, 0u, 0u};
     MH_HIP(hipMemcpyAsync(acc.p, init, sizeof(init), hipMemcpyHostToDevice, s));
-    const unsigned grid = (unsigned)(cdiv(n, 256) < 4096 ? cdiv(n, 256) : 4096);
+    const unsigned grid = (unsigned)(cdiv(n, 1024) < 4096 ? cdiv(n, 1024) : 4096);
     hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, s, d_dem, n, acc.as<unsigned int>());
     MH_HIP(hipGetLastError());
     unsigned int h[4];

@@ -26,6 +26,7 @@
 // (a cell that can never be resolved: unknown band halo, entry whose inflow never arrives, flow cycle); it travels
 // downstream with the sums and turns the result into the reference's 0.
 #include "common.hpp"
+#include <type_traits>
 
 namespace mh {
 namespace {
@@ -37,13 +38,16 @@ constexpr int FS = AT + 32;           // LDS row stride of the flow-direction wi
                                       // 16-byte chunks of a row land 16-byte aligned (ring columns at 15 and AT + 16)
 constexpr int WOFF = 16;
 constexpr uint64_t SRC = 1ull << 63;      // phase-2 node word: source flag
-// tile word (LDS, one per cell): bits 0..37 running sum | 38..50 A (2**k-th downstream cell, SENT13 = none) |
-// 51..62 R (last in-tile cell reached so far) | 63 taint.  Sums stay below 2**38 (accum_dev refuses larger rasters).
-constexpr uint64_t TAINT = 1ull << 63;    // never resolved
-constexpr int A_SHIFT = 38, R_SHIFT = 51;
-constexpr uint64_t SUM_MASK = (1ull << A_SHIFT) - 1;
-constexpr uint64_t A_MASK = 0x1fffull, R_MASK = 0xfffull, SENT13 = A_MASK;
-constexpr uint64_t FIELDS = (A_MASK << A_SHIFT) | (R_MASK << R_SHIFT);
+// Tile state in LDS, two arrays (one 64-bit word per cell pushed to with a RETURNING 64-bit atomic was the first design: the LDS
+// atomic unit was the bound, and a returning 64-bit atomic is its most expensive operation):
+//   S[i]  running sum, bit 31 / 63 = taint.  32-bit when no sum can pass 2**31 (phase 1 outside the final band pass: at most
+//         the 4096 cells of the tile), else 64-bit with sums below 2**38 (accum_dev refuses larger rasters)
+//   P[i]  A (2**k-th downstream cell, SENT13 = none) | R << 13 (last in-tile cell reached so far; phase 1 only: 16-bit words
+//         without R in phase 3).  Written by the owner of the cell between two barriers only, so the push phase reads it plainly.
+constexpr uint64_t TAINT = 1ull << 63;    // never resolved (64-bit sums; TAINT32 in the 32-bit ones)
+constexpr uint32_t TAINT32 = 1u << 31;
+constexpr int R_SHIFT = 13;
+constexpr uint32_t A_MASK = 0x1fffu, R_MASK = 0xfffu, SENT13 = A_MASK;
 constexpr uint16_t NO_EXIT = 0xffffu;
 constexpr int CPT = AT * AT / 256;        // cells per thread
 constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simple path
@@ -92,15 +96,22 @@ __device__ unsigned long long g_accum_prof[2][8];
 #endif
 
 // ---- the tile kernel (phase 1 when FINAL == false, phase 3 when FINAL == true) ------------------------------
-template <bool FINAL>
+// WIDE: 64-bit sums (phase 3 always; phase 1 only in the final pass of a row band, where the halo cells are sources of the
+// neighbouring band's flux)
+template <bool FINAL, bool WIDE>
 // Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
 // final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
 // they never receive and are never written here.
 __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
                                                         int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot, int halo_zero)
 {
+    static_assert(WIDE || !FINAL, "phase 3 sums are 64-bit");
+    using sum_t = typename std::conditional<WIDE, unsigned long long, uint32_t>::type;
+    using ptr_t = typename std::conditional<FINAL, uint16_t, uint32_t>::type;
+    constexpr sum_t TAINT_S = WIDE ? (sum_t)TAINT : (sum_t)TAINT32;
     auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
-    __shared__ uint64_t S[AT * AT];
+    __shared__ sum_t S[AT * AT];
+    __shared__ ptr_t P[AT * AT];
     const int tile = blockIdx.x;
     const int ti = tile / ntc, tj = tile - ti * ntc;
     const int64_t r0 = (int64_t)ti * AT, c0 = (int64_t)tj * AT;
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     __syncthreads();
 
     // my CPT cells: i = tid + 256 j (consecutive lanes = consecutive LDS words)
-    uint64_t sreg[CPT];   // my cells' words as of the last barrier (what I push)
+    sum_t sreg[CPT];      // my cells' sums as of the last barrier (what I push)
+    uint32_t preg[CPT];   // ... and their A | R << 13
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int i = tid + 256 * j;
@@ -171,45 +183,49 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         const bool inside = (r0 + r) < H && (c0 + c) < W;
         const int slot = perim_slot(r, c);
         unsigned deg_ext = slot >= 0 ? dext_l[slot] : 0u;
-        uint64_t v = inside ? 1ull : TAINT;   // not a raster cell: nothing flows into it (its neighbours see NODIR... it has none)
+        sum_t v = inside ? (sum_t)1 : TAINT_S;   // not a raster cell: nothing flows into it (its neighbours see NODIR... it has none)
         const bool halo = inside && halo_row(r0 + r);
         if (halo) {  // the neighbouring band's cell: known (> 0) = a source of that much flux, else it blocks its path
             // boundary pass of the band protocol (halo_zero): a known source of NO flux -- the local sums then are the band's own
             // contribution, and the halo cell's path is traced to where it leaves the band (accum_band_exit_kernel)
             const double ext = halo_zero ? 0.0 : out[(r0 + r) * W + c0 + c];
-            v = halo_zero ? 0ull : (ext > 0.0 ? (uint64_t)ext : TAINT);
+            v = halo_zero ? (sum_t)0 : (ext > 0.0 ? (sum_t)(unsigned long long)ext : TAINT_S);   // (not halo_zero: a WIDE launch)
             deg_ext = 0;
         }
         if (FINAL && deg_ext && inside) {
-            if (arrived_l[slot] == deg_ext) v += inflow_l[slot];
-            else v |= TAINT;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
+            if (arrived_l[slot] == deg_ext) v += (sum_t)inflow_l[slot];
+            else v |= TAINT_S;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
         }
         // downstream cell: inside the tile, the raster and the band, else the path ends here
         const unsigned code = win[(r + 1) * FS + c + WOFF];
-        uint64_t nx = SENT13;
+        uint32_t nx = SENT13;
         if (inside && code <= 7u) {
             const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
             if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr))
-                nx = (uint64_t)(nr * AT + nc);
+                nx = (uint32_t)(nr * AT + nc);
         }
-        v |= (nx << A_SHIFT) | ((uint64_t)i << R_SHIFT);
+        const uint32_t pw = nx | ((uint32_t)i << R_SHIFT);
         S[i] = v;
+        P[i] = (ptr_t)pw;       // (phase 3 keeps A only)
         sreg[j] = v;
+        preg[j] = pw;
     }
     __syncthreads();
     MH_ASTAMP(1);
 
     bool more = true;
     for (int round = 0; round < MAX_DOUBLINGS && more; ++round) {
-        uint64_t got[CPT];
+        uint32_t got[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const uint64_t v = sreg[j], a = (v >> A_SHIFT) & A_MASK;
+            const uint32_t a = preg[j] & A_MASK;
             got[j] = 0;
             if (a != SENT13) {
-                // push my sum to A_k[me]; the word that comes back carries A_k and R_k of that cell
-                got[j] = atomicAdd(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)(v & SUM_MASK));
-                if (v & TAINT) atomicOr(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)TAINT);
+                // push my sum to A_k[me] (no value comes back) and read A_k, R_k of that cell
+                const sum_t v = sreg[j];
+                atomicAdd(&S[a], (sum_t)(v & ~TAINT_S));
+                if (v & TAINT_S) atomicOr(&S[a], TAINT_S);
+                got[j] = P[a];
             }
         }
         __syncthreads();   // every push of this round is done; nobody but its owner touches a word until the next barrier
@@ -217,11 +233,12 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int i = tid + 256 * j;
-            if (((sreg[j] >> A_SHIFT) & A_MASK) != SENT13) {
-                const uint64_t w = (S[i] & ~FIELDS) | (got[j] & FIELDS);   // S_{k+1} | A_{k+1} | R_{k+1}
-                S[i] = w;
-                sreg[j] = w;
-                mine |= ((w >> A_SHIFT) & A_MASK) != SENT13;
+            if ((preg[j] & A_MASK) != SENT13) {
+                const uint32_t w = FINAL ? (got[j] & A_MASK) : got[j];   // A_{k+1} | R_{k+1}
+                P[i] = (ptr_t)w;
+                preg[j] = w;
+                sreg[j] = S[i];                                           // S_{k+1}
+                mine |= (w & A_MASK) != SENT13;
             }
         }
         more = __syncthreads_or(mine) != 0;
@@ -231,8 +248,8 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         // such paths these ancestors cover every cell of the cycle (a rotation of the cycle is onto)
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const uint64_t a = (sreg[j] >> A_SHIFT) & A_MASK;
-            if (a != SENT13) atomicOr(reinterpret_cast<unsigned long long *>(&S[a]), (unsigned long long)TAINT);
+            const uint32_t a = preg[j] & A_MASK;
+            if (a != SENT13) atomicOr(&S[a], TAINT_S);
         }
         __syncthreads();
     }
@@ -244,8 +261,8 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             const int i = tid + 256 * j;
             const int r = i / AT, c = i - r * AT;
             if ((r0 + r) < H && (c0 + c) < W && !halo_row(r0 + r)) {
-                const uint64_t s = S[i];
-                out[(r0 + r) * W + c0 + c] = (s & TAINT) ? 0.0 : (double)(s & SUM_MASK);
+                const sum_t s = S[i];
+                out[(r0 + r) * W + c0 + c] = (s & TAINT_S) ? 0.0 : (double)(s & ~TAINT_S);
             }
         }
         MH_ASTAMP(3);
@@ -261,13 +278,13 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             const int i = tid + 256 * j;
             const int r = i / AT, c = i - r * AT;
             if (!((r0 + r) < H && (c0 + c) < W && halo_row(r0 + r))) continue;
-            const uint64_t s = S[i];
+            const uint32_t pw = P[i];
             int32_t first = -1;
             const unsigned own = win[(r + 1) * FS + c + WOFF];
             const bool enters = own <= 7u && dir_dr((int)own) != 0 && (r0 + r + dir_dr((int)own)) >= 0 && (r0 + r + dir_dr((int)own)) < H &&
                                 (c0 + c + dir_dc((int)own)) >= 0 && (c0 + c + dir_dc((int)own)) < W && !halo_row(r0 + r + dir_dr((int)own));
-            if (enters && ((s >> A_SHIFT) & A_MASK) == SENT13) {
-                const int last = (int)((s >> R_SHIFT) & R_MASK);
+            if (enters && (pw & A_MASK) == SENT13) {
+                const int last = (int)((pw >> R_SHIFT) & R_MASK);
                 const int pr = last / AT, pc = last - pr * AT;
                 const unsigned cd = win[(pr + 1) * FS + pc + WOFF];
                 if (cd <= 7u) {
@@ -288,8 +305,9 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         perim_cell(tid, r, c);
         const int64_t node = (int64_t)tile * NODE_STRIDE + tid;
         const bool inside = (r0 + r) < H && (c0 + c) < W;
-        const uint64_t s = S[r * AT + c];
-        const bool resolved = inside && !(s & TAINT);
+        const sum_t s = S[r * AT + c];
+        const uint32_t pw = P[r * AT + c];
+        const bool resolved = inside && !(s & TAINT_S);
         const unsigned code = win[(r + 1) * FS + c + WOFF];
         uint8_t fl = resolved ? F_RESOLVED : 0;
         int32_t dst = -1;
@@ -318,8 +336,8 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
             // the last in-tile cell of my path (doubling above); the path leaves through it iff that cell flows into a
             // raster cell outside the tile.  A path that ends in a sink, leaves the raster, continues in the neighbouring
             // band or runs into a flow cycle has no exit.
-            if (((s >> A_SHIFT) & A_MASK) == SENT13) {
-                const int last = (int)((s >> R_SHIFT) & R_MASK);
+            if ((pw & A_MASK) == SENT13) {
+                const int last = (int)((pw >> R_SHIFT) & R_MASK);
                 const int pr = last / AT, pc = last - pr * AT;
                 const unsigned cd = win[(pr + 1) * FS + pc + WOFF];
                 if (cd <= 7u) {
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         nd.flags[node] = fl;
         nd.dst[node] = dst;
         nd.exit_of[node] = ex;
-        nd.gstate[node] = ((resolved ? 0ull : 1ull) << G_SHIFT) | (s & SUM_MASK);  // unresolved: blocks itself forever
+        nd.gstate[node] = ((resolved ? 0ull : 1ull) << G_SHIFT) | (unsigned long long)(s & ~TAINT_S);  // unresolved: blocks itself forever
         nd.inflow[node] = 0;
         nd.arrived[node] = 0;
         nd.next[node] = -1;
@@ -450,13 +468,17 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     nd.bexit = d_exit_map ? reinterpret_cast<int32_t *>(b + o_bexit) : nullptr;
     if (d_exit_map) MH_HIP(hipMemsetAsync(nd.halo_first, 0xff, 8 * (size_t)W, s));
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
-    hipLaunchKernelGGL(accum_tile_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    // the local sums of phase 1 fit 32 bits unless halo cells bring the neighbouring band's flux in (the final pass of a row band)
+    if ((fixed_top || fixed_bot) && !halo_zero)
+        hipLaunchKernelGGL((accum_tile_kernel<false, true>), dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    else
+        hipLaunchKernelGGL((accum_tile_kernel<false, false>), dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     hipLaunchKernelGGL(accum_link_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     if (d_exit_map)
         hipLaunchKernelGGL(accum_band_exit_kernel, dim3((unsigned)cdiv(2 * W, 256)), dim3(256), 0, s, nd, H, W, ntc, ntiles, fixed_top, fixed_bot, d_exit_map);
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
-    hipLaunchKernelGGL(accum_tile_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
 #ifdef MH_PROFILE_ACCUM

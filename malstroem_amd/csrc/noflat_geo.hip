@@ -669,6 +669,71 @@ __global__ __launch_bounds__(256) void ng_verify_kernel(const float *__restrict_
     if (bad) atomicAdd(&counters[C_MISMATCH], (unsigned long long)bad);
 }
 
+// ---- both at once (the usual case: no irregular level): G is assembled in registers, checked against its eight neighbours and
+// written -- the separate verification read all of G back (8 of its 12 bytes per cell).  A wavefront owns 62 columns; lanes 0 and
+// 63 carry the neighbouring columns (values only), left / right neighbours come over DPP like in the tile kernels.
+constexpr int FRB = 32;   // rows per thread
+__device__ __forceinline__ double dleft(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = from_left((uint32_t)b), hi = from_left((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double dright(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = from_right((uint32_t)b), hi = from_right((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__global__ __launch_bounds__(256) void ng_finish_kernel(const float *__restrict__ F, const uint32_t *__restrict__ d, const float *__restrict__ dem,
+                                                        double *__restrict__ G, int64_t H, int64_t W, double sh, double dg, double seed_add, int fixed_top,
+                                                        int fixed_bot, unsigned long long *counters)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + wave) * TI + lane - 1;
+    const int64_t rb = (int64_t)blockIdx.y * FRB;
+    const bool col_in = c >= 0 && c < W;
+    const int64_t cc = c < 0 ? 0 : (c < W ? c : W - 1);
+    const bool mine = lane >= 1 && lane <= TI && col_in;                // this lane writes (and checks) its column
+    const bool inner_col = c > 0 && c + 1 < W;
+    const double PINF = __builtin_inf();
+    unsigned unreached = 0, bad = 0;
+    auto value = [&](int64_t r) -> double {
+        if (!(r >= 0 && r < H && col_in)) return PINF;
+        const float f = F[r * W + cc];
+        const uint32_t dd = d[r * W + cc];
+        if (dd == D_IRR) return (double)f + seed_add;                   // (ng_assemble_kernel)
+        if (dd >= 0x80000000u) {
+            unreached += mine && r >= rb && r < rb + FRB ? 1u : 0u;
+            return (double)f + seed_add;
+        }
+        return dd ? (double)f + (double)dd * class_ulp(class_above(f)) : (double)f;
+    };
+    double a = value(rb - 1), b = value(rb);
+    for (int i = 0; i < FRB; ++i) {
+        const int64_t r = rb + i;
+        if (r >= H) break;
+        const double n = value(r + 1);
+        const double al = dleft(a), ar = dright(a), bl = dleft(b), br = dright(b), nl = dleft(n), nr = dright(n);
+        if (mine) {
+            const double dv = (double)dem[r * W + c];
+            double want = dv;
+            if (r > 0 && r < H - 1 && inner_col) {
+                const double md = fmin(fmin(al, ar), fmin(nl, nr)) + dg;
+                const double me = fmin(fmin(a, bl), fmin(br, n)) + sh;
+                want = fmax(fmin(md, me), dv);
+            }
+            const bool halo = (r == 0 && fixed_top) || (r == H - 1 && fixed_bot);   // the neighbouring band checks its own rows
+            bad += (b == want || halo) ? 0u : 1u;                                    // NaN anywhere fails too
+            G[r * W + c] = b;
+        }
+        a = b;
+        b = n;
+    }
+    if (unreached) atomicAdd(&counters[C_UNREACHED], (unsigned long long)unreached);
+    if (bad) atomicAdd(&counters[C_MISMATCH], (unsigned long long)bad);
+}
+
 // rn(eps / 2**(E - 52)) for the binade class e (E = e - 127) with eps = M * 2**q exactly; 0: no integer weight in (0, 2**28)
 uint32_t class_weight(double eps, int e)
 {
@@ -873,10 +938,13 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     Impl &m = *impl;
     const int64_t n = H * W;
     partial = m.irregular != 0 && allow_partial;
-    hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, seed_add, m.d_cnt);
-    if (!partial)     // (a partial surface is checked by the caller once the relaxation has settled the irregular flats)
-        hipLaunchKernelGGL(ng_verify_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)((H + VRB - 1) / VRB)), dim3(256), 0, s, dem, out, H, W, sh, dg,
-                           fixed_top, fixed_bot, m.d_cnt);
+    if (getenv("MHIP_NG_CORRUPT") && W > 8)   // test hook (tests/test_gpu_noflat_geodesic.py): wrong distances in the middle row -- the check
+        MH_HIP(hipMemsetAsync(dist + (H / 2) * W + 1, 0x01, 4 * (size_t)(W - 2), s));   // below has to catch them and send the raster to the relaxation
+    if (!partial)
+        hipLaunchKernelGGL(ng_finish_kernel, dim3((unsigned)((W + 4 * TI - 1) / (4 * TI)), (unsigned)((H + FRB - 1) / FRB)), dim3(256), 0, s, filled, dist, dem,
+                           out, H, W, sh, dg, seed_add, fixed_top, fixed_bot, m.d_cnt);
+    else              // (a partial surface is checked by the caller once the relaxation has settled the irregular flats)
+        hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, seed_add, m.d_cnt);
     MH_HIP(hipGetLastError());
     unsigned long long h_all[C_STATS + 128 + 16];
     MH_HIP(hipMemcpyAsync(h_all, m.d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));

@@ -97,6 +97,15 @@ def test_a_flat_longer_than_the_uint32_headroom():
     check(dem, algorithm=3)
 
 
+def test_the_device_check_is_live(monkeypatch):
+    """MHIP_NG_CORRUPT makes the transform hand wrong distances (one raster row) to the final check: the check has to see them,
+    the call has to fall back to the float64 relaxation (algorithm 0) -- and still return the reference's surface."""
+    dem = fbm(300, 260, beta=2.0, seed=5) + np.float32(10.0)
+    assert check(dem) == 2
+    monkeypatch.setenv("MHIP_NG_CORRUPT", "1")
+    assert check(dem) == 0
+
+
 @pytest.mark.parametrize("short,diag", [(2.0 ** -30, 2.0 ** -30 * 2 ** 0.5), (1e-9, 1.5e-9), (1e-3, 1.4142e-3), (3e-7, 3e-7), (2.0 ** -20, 2.0 ** -19),
                                         (1e-13, 1.5e-13), (0.0, 0.0), (0.25, 0.5)])
 def test_user_epsilons_whatever_path_they_take(short, diag):

@@ -131,6 +131,16 @@ int mhip_trace_downstream_i32(const uint8_t *flowdir, const int32_t *labels, int
 int mhip_rain_events(int64_t n, const int64_t *down_index, const double *wshed_area, const double *bspot_vol, int32_t nevents,
                      const double *mmrain, double *rainv, double *spillv, double *v, double *pctv, int64_t *order, int64_t *ncomputed);
 
+/* The two boundary systems of the row-band protocol (malstroem_amd/distributed.py; no reference counterpart: the reference works
+ * on one undivided raster).  Host code, no device needed; every rank solves them on the gathered seam rows of all bands.
+ * band_forest_solve: flow accumulation over the forest of seam crossings.  val[i] > 0 = node i's own (known) contribution,
+ *   parent[i] = the node its flux continues in or -1.  On return val[i] = own + everything upstream for every node whose upstream
+ *   is completely known, 0 for every other node (_flow.pyx:212-247 leaves cells behind a flow cycle 0 as well).
+ * band_ws_resolve: vals[i] >= 0 is a watershed label (0 = none), vals[i] < 0 means "whatever node -vals[i] - 1 resolves to";
+ *   chains are followed to their end, a cycle resolves to 0 (_flow.pyx:276-314 leaves such cells unassigned). */
+int mhip_band_forest_solve(int64_t n, const int64_t *parent, double *val);
+int mhip_band_ws_resolve(int64_t n, int64_t *vals);
+
 /* ---- device-resident pipeline (DemTool / BluespotTool sequences, reference dem.py:53-93,
  *      bluespots.py:138-216): one upload, all stages in HBM, downloads only for the writers. ------- */
 typedef struct mhip_ctx mhip_ctx;

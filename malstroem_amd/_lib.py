@@ -32,7 +32,7 @@ SYMBOLS = [
     "mhip_fill_f32", "mhip_fill_noflat_f64", "mhip_short_diag", "mhip_depths_f32", "mhip_d8_f64", "mhip_accum",
     "mhip_ccl8_f32", "mhip_ccl8_u8", "mhip_relabel_keep", "mhip_keep_mask", "mhip_label_stats_f32", "mhip_label_stats_f64",
     "mhip_label_argmin_f64", "mhip_label_argmax_f64", "mhip_label_count", "mhip_label_max", "mhip_watersheds_i32",
-    "mhip_trace_downstream_i32", "mhip_ctx_trace_downstream", "mhip_rain_events",
+    "mhip_trace_downstream_i32", "mhip_ctx_trace_downstream", "mhip_rain_events", "mhip_band_forest_solve", "mhip_band_ws_resolve",
     "mhip_ctx_create", "mhip_comm_unique_id", "mhip_ctx_create_band", "mhip_ctx_destroy", "mhip_ctx_upload_dem",
     "mhip_ctx_upload", "mhip_ctx_download", "mhip_ctx_upload_rows", "mhip_ctx_download_rows", "mhip_ctx_run", "mhip_ctx_sync", "mhip_ctx_stage_ms",
     "mhip_ctx_kernel_ms", "mhip_ctx_get_i64", "mhip_ctx_get_f64", "mhip_ctx_raw_stats", "mhip_ctx_apply_keep",

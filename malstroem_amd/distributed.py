@@ -23,6 +23,7 @@ import pickle
 import queue
 import socket
 import struct
+import sys
 import threading
 
 import numpy as np
@@ -566,21 +567,32 @@ def solve_band_accum(info, W):
         if b < R - 1:       # my bottom halo row = the first row of band b + 1
             m = ex[W:] >= 0
             parent[((b + 1) * 2) * W + cols[m]] = b * 2 * W + ex[W:][m]
-    ok = val > 0
-    nchild = np.bincount(parent[parent >= 0], minlength=N)
-    final = np.zeros(N, dtype=bool)
-    frontier = np.flatnonzero(ok & (nchild == 0))
-    while frontier.size:
-        final[frontier] = True
-        p = parent[frontier]
-        m = p >= 0
-        np.add.at(val, p[m], val[frontier[m]])
-        np.subtract.at(nchild, p[m], 1)
-        cand = np.unique(p[m])
-        frontier = cand[(nchild[cand] == 0) & ok[cand]]
-    val[~final] = 0.0
+    # Kahn's walk over the forest, one O(N) pass in the library (host C++; as NumPy levels -- ufunc.at, unique -- it cost more
+    # than the band's GPU work at 8 bands of 65536 columns)
+    val = np.ascontiguousarray(val)
+    _lib.call("mhip_band_forest_solve", _lib.i64(N), _lib.ptr(parent), _lib.ptr(val))
     val = val.reshape(R, 2, W)
     return [(val[b - 1, 1] if b > 0 else None, val[b + 1, 0] if b < R - 1 else None) for b in range(R)]
+
+
+_PROF = os.environ.get("MALSTROEM_BAND_PROFILE") is not None    # development: wall clock of the steps inside label() / _merged()
+
+
+class _Lap:
+    """with-less lap timer: lap(name) charges the time since the previous lap to `name`; report() prints (rank 0 only)"""
+    def __init__(self, what, rank):
+        import time
+        self.t, self.what, self.rank, self.acc, self.clock = time.perf_counter(), what, rank, [], time.perf_counter
+
+    def lap(self, name):
+        if _PROF:
+            now = self.clock()
+            self.acc.append((name, (now - self.t) * 1e3))
+            self.t = now
+
+    def report(self):
+        if _PROF and self.rank == 0:
+            print("[band profile] %s: %s" % (self.what, ", ".join("%s %.1f" % kv for kv in self.acc)), file=sys.stderr, flush=True)
 
 
 class BandPipeline(object):
@@ -821,19 +833,27 @@ class BandPipeline(object):
         import scipy.sparse
         import scipy.sparse.csgraph
         b, comm, W = self.band, self._cur_comm(), self.W
+        lap = _Lap("label", comm.rank)
         nloc = b.ccl_local()
+        lap.lap("ccl_local")
         rows = dict(nloc=nloc, first=b.get_edge_row("labels", 0), last=b.get_edge_row("labels", 1),
                     top=b.get_edge_row("labels", 2) if self.has_up else None,
                     bot=b.get_edge_row("labels", 3) if self.has_down else None)
+        lap.lap("edge rows")
         allrows = comm.allgather(rows)
+        lap.lap("allgather")
         R = comm.size
         key = lambda r, lab: (np.int64(r) << 32) | lab.astype(np.int64)
-        # equivalences between band r and r+1: r.last == (r+1).top and r.bot == (r+1).first, cell by cell
+        # equivalences between band r and r+1: r.last == (r+1).top and r.bot == (r+1).first, cell by cell -- one edge per RUN of
+        # equal (a, c) pairs along the row (the cells of a run repeat the same edge; everything below then works on a few
+        # thousand edges instead of 2 W per seam: at W = 65536 and 8 bands this merge was 350 ms of host time on every rank)
         ea, eb = [], []
         for r in range(R - 1):
             up, dn = allrows[r], allrows[r + 1]
             for a, c in ((up["last"], dn["top"]), (up["bot"], dn["first"])):
                 m = (a > 0) & (c > 0)
+                if a.size > 1:
+                    m[1:] &= (a[1:] != a[:-1]) | (c[1:] != c[:-1])
                 ea.append(key(r, a[m]))
                 eb.append(key(r + 1, c[m]))
         ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
@@ -848,15 +868,23 @@ class BandPipeline(object):
         node_rank = (nodes >> 32).astype(np.int64)
         node_lab = (nodes & 0xffffffff).astype(np.int64)
         # phantom = local component made of halo cells only (no owned cell): in a halo row but not in the adjacent owned row
+        def run_values(row):
+            """the distinct positive labels of a row, from its run starts (a row holds far fewer runs than cells)"""
+            keep = row > 0
+            if row.size > 1:
+                keep[1:] &= row[1:] != row[:-1]
+            return np.unique(row[keep])
         phantom = np.zeros(nn, bool)
+        bounds = np.searchsorted(node_rank, np.arange(R + 1))     # `nodes` is sorted by (rank, label): rank r = one slice
         for r in range(R):
             rr = allrows[r]
-            mine = node_rank == r
+            sl = slice(int(bounds[r]), int(bounds[r + 1]))
             for halo, edge in ((rr["top"], rr["first"]), (rr["bot"], rr["last"])):
                 if halo is None:
                     continue
-                ph = np.setdiff1d(halo[halo > 0], edge[edge > 0])
-                phantom |= mine & np.isin(node_lab, ph)
+                ph = np.setdiff1d(run_values(halo), run_values(edge), assume_unique=True)
+                if ph.size:
+                    phantom[sl] |= np.isin(node_lab[sl], ph, assume_unique=True)
         # class owner = smallest rank with a real member; representative = smallest local label of the owner's members
         big = np.int64(1) << 62
         score = np.where(phantom, big, (node_rank << 32) | node_lab)
@@ -883,12 +911,15 @@ class BandPipeline(object):
         target[np.searchsorted(dropped, node_lab[members])] = class_label[cls[members]]
         # global labels with cells in more than one band (same array on every rank): their records need a merge
         real = ~phantom
-        pairs = np.unique(np.stack([cls[real], node_rank[real]], axis=1), axis=0) if real.any() else np.zeros((0, 2), np.int64)
-        ranks_per_class = np.bincount(pairs[:, 0], minlength=ncls) if ncls else np.zeros(0, np.int64)
+        pairs = np.unique(cls[real].astype(np.int64) * R + node_rank[real]) if real.any() else np.zeros(0, np.int64)   # (class, rank)
+        ranks_per_class = np.bincount(pairs // R, minlength=ncls) if ncls else np.zeros(0, np.int64)
         self.shared_labels = np.unique(class_label[np.flatnonzero(ranks_per_class > 1)]).astype(np.int64)
         self.nlabels = int(offsets[-1])
         self.label_range = (int(offsets[comm.rank]) + 1, int(offsets[comm.rank + 1]))
+        lap.lap("merge (host)")
         b.relabel_sparse(nloc, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels)
+        lap.lap("relabel_sparse")
+        lap.report()
         return self.nlabels
 
     def watershed(self):
@@ -908,12 +939,8 @@ class BandPipeline(object):
                 up = idx < W          # pseudo label of band r's top halo = last owned row of band r-1
                 tgt = np.where(up, (2 * (r - 1) + 1) * W + idx, (2 * (r + 1)) * W + (idx - W))
                 seg[neg] = -(tgt + 1)
-        for _ in range(64):
-            neg = vals < 0
-            if not neg.any():
-                break
-            vals[neg] = vals[-vals[neg] - 1]
-        vals[vals < 0] = 0            # a flow cycle across bands: stays unassigned
+        vals = np.ascontiguousarray(vals)
+        _lib.call("mhip_band_ws_resolve", _lib.i64(vals.size), _lib.ptr(vals))   # chains followed to their end; a flow cycle across bands: 0
         lut = np.zeros(2 * W, np.int64)
         if self.has_up:
             lut[:W] = vals[(2 * (comm.rank - 1) + 1) * W:(2 * (comm.rank - 1) + 2) * W]
@@ -933,9 +960,17 @@ class BandPipeline(object):
         by `merge(list of per-rank record arrays) -> array`.  fetch_own=False: compute and merge only (the slice of this
         band's own labels stays on the device, like the records of the single-GPU pipeline until somebody asks for them)"""
         b, (lo, hi) = self.band, self.label_range
+        lap = _Lap("records %d" % which, self.comm.rank)
         b.records_compute(which)
+        lap.lap("compute")
         ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
-        m = merge(self._cur_comm().allgather(b.records_gather(which, ids)))
+        g = b.records_gather(which, ids)
+        lap.lap("gather %d" % ids.size)
+        parts = self._cur_comm().allgather(g)
+        lap.lap("allgather")
+        m = merge(parts)
+        lap.lap("merge")
+        lap.report()
         if not fetch_own:
             return {"first_label": lo, "records": None, "shared_labels": ids, "shared_records": m, "background": m[0].copy()}
         own = b.records_fetch(which, lo, hi - lo + 1)

@@ -285,3 +285,52 @@ def test_protocol_gloo_processes(world, worker, tmp_path):
     for k in KEYS:
         assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
     assert all(int(p["nlabels"]) == ref["nlabels"] for p in parts)
+
+
+def test_band_forest_solve_against_a_plain_walk():
+    """mhip_band_forest_solve (host C++ of the library) == Kahn's walk written out in Python, on random forests with unknown
+    nodes and cycles"""
+    import ctypes
+    from malstroem_amd import _lib
+    rng = np.random.default_rng(5)
+    for case in range(20):
+        n = int(rng.integers(1, 400))
+        parent = np.where(rng.random(n) < 0.6, rng.integers(0, n, n), -1).astype(np.int64)
+        val = np.where(rng.random(n) < 0.85, rng.integers(1, 1000, n), 0).astype(np.float64)
+        want = val.copy()
+        nchild = np.bincount(parent[parent >= 0], minlength=n)
+        ok = val > 0
+        final = np.zeros(n, bool)
+        stack = [i for i in range(n) if ok[i] and nchild[i] == 0]
+        while stack:
+            i = stack.pop()
+            final[i] = True
+            p = parent[i]
+            if p >= 0:
+                want[p] += want[i]
+                nchild[p] -= 1
+                if nchild[p] == 0 and ok[p]:
+                    stack.append(p)
+        want[~final] = 0.0
+        got = val.copy()
+        _lib.call("mhip_band_forest_solve", _lib.i64(n), _lib.ptr(parent), _lib.ptr(got))
+        assert np.array_equal(got, want), case
+
+
+def test_band_ws_resolve_against_pointer_jumping():
+    """mhip_band_ws_resolve == the 64 rounds of pointer jumping it replaced (chains end at a label, cycles at 0)"""
+    from malstroem_amd import _lib
+    rng = np.random.default_rng(6)
+    for case in range(20):
+        n = int(rng.integers(1, 500))
+        vals = np.where(rng.random(n) < 0.5, rng.integers(0, 50, n), -(rng.integers(0, n, n) + 1)).astype(np.int64)
+        want = vals.copy()
+        for _ in range(64):
+            neg = want < 0
+            if not neg.any():
+                break
+            want[neg] = want[-want[neg] - 1]
+        want[want < 0] = 0
+        got = vals.copy()
+        _lib.call("mhip_band_ws_resolve", _lib.i64(n), _lib.ptr(got))
+        assert np.array_equal(got, want), case

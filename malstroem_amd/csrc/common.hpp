@@ -161,6 +161,7 @@ struct PfRun {
     int batch(hipStream_t s);                     // MHIP_ELIMIT as above
     int finish(hipStream_t s, float *d_depths, FillStats *st);
     int solve(hipStream_t s);
+    int pack(hipStream_t s, int row0, int nrows);
     int publish_edges(hipStream_t s);
 };
 // a call-back fired once, on the stage's stream, at a chosen point of a stage (mhip_ctx_run starts the label branch when the

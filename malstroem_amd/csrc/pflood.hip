@@ -728,46 +728,25 @@ struct SolveArgs {
     unsigned long long *visits;
     int nbr, nbc;                          // blocks
     int first;                             // 1: every block
+    unsigned long long *eblk;              // [nbr * nbc][EMAX] the directed relaxations of every block, packed once (pf_pack_kernel)
+    int row0;                              // pf_pack_kernel: first block row of the launch
 };
 
-constexpr int ST = 1024;                  // threads per block visit (the LDS fixed point is barrier bound: more, shorter strides)
-__global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
+constexpr int ST = 512;                   // threads per block visit
+
+// The graph does not change during the solve: the directed relaxations of a block (its 16 tiles' links and spill edges, with the
+// positions of their two seeds in the block's 6 x 6 region of levels) are packed ONCE into EMAX words per block, unused words ~0.
+// A visit then loads its relaxations with the same round trip as the levels -- decoding them from the per-tile tables took three
+// dependent round trips and 48 KB of LDS at every one of the ~9 visits of a block.  (A row band re-packs its first and last
+// block rows after a halo exchange changed their links.)
+__global__ __launch_bounds__(ST) void pf_pack_kernel(SolveArgs sa)
 {
-    __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
-    __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
-    __shared__ unsigned long long E[EMAX];             // 48 KB: dst << 48 | src << 32 | w   (src 0xFFFF = OCEAN)
-    __shared__ int s_wake, s_over;
+    __shared__ int s_seg[BT * BT + 1], s_nl[BT * BT];
     const PfArgs &a = sa.a;
     const int t = threadIdx.x;
-    // a resident grid walks the round's list: launching one workgroup per block of the raster (4489 x 1024 threads at 16384^2,
-    // nearly all of them only to find their block inactive) cost more than the visits themselves
-    const unsigned int nwork = sa.first ? (unsigned int)(sa.nbr * sa.nbc) : *sa.count_cur;
-    for (unsigned int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-    __syncthreads();                                   // the LDS arrays of the previous visit are free
-    const int blk = sa.first ? (int)wi : sa.list_cur[wi], bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
-    if (t == 0) {
-        sa.mark_cur[blk] = 0u;                         // this buffer is appended to again two rounds from now
-        s_wake = 0;
-        s_over = 0;
-    }
-#ifdef PF_PROFILE
-    long long pk0 = __builtin_amdgcn_s_memtime(), pk1 = 0, pk2 = 0;
-    int pk_it = 0;
-#endif
-    // ---- levels of the region
-    for (int i = t; i < RT * RT * NSMAX; i += ST) {
-        const int rt = i / NSMAX, k = i - rt * NSMAX;
-        const int p = bi * BT + rt / RT - 1, q = bj * BT + rt % RT - 1;
-        const bool ok = p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
-        L[i] = ok ? a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k] : EMPTY;
-    }
-    __syncthreads();
-    for (int i = t; i < BT * BT * NSMAX; i += ST) {
-        const int bt = i / NSMAX, k = i - bt * NSMAX;
-        Lold[i] = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
-    }
-    // ---- edges of the block's tiles -> directed relaxations in LDS (fixed positions: tile segment + entry, no atomics)
-    __shared__ int s_seg[BT * BT + 1], s_nl[BT * BT];
+    const int bi = sa.row0 + (int)blockIdx.y, bj = (int)blockIdx.x, blk = bi * sa.nbc + bj;
+    unsigned long long *E = sa.eblk + (size_t)blk * EMAX;
+    for (int i = t; i < EMAX; i += ST) E[i] = ~0ull;
     if (t < BT * BT) {
         const int p = bi * BT + t / BT, q = bj * BT + t % BT;
         int nl = 0, ns = 0;
@@ -778,26 +757,23 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
         s_nl[t] = nl;
         s_seg[t + 1] = nl + 2 * ns;
     }
-    __syncthreads();
+    __syncthreads();      // (also orders the ~0 fill before the entries below: same workgroup, same addresses)
     if (t == 0) {
         s_seg[0] = 0;
         for (int k = 0; k < BT * BT; ++k) s_seg[k + 1] += s_seg[k];
-        if (s_seg[BT * BT] > EMAX) s_over = 1;
     }
     __syncthreads();
-    if (s_over) {   // block-uniform; more relaxations than LDS holds (6144 ~ 16 x 380): tell the caller to fall back
+    if (s_seg[BT * BT] > EMAX) {   // block-uniform; more relaxations than a visit holds (6144 ~ 16 x 380): tell the caller to fall back
         if (t == 0) atomicOr(a.flags, 1u);
-        continue;
+        return;
     }
-    const int NE = s_seg[BT * BT];
-    // all 16 tiles at once (one tile after the other left 15 of 16 load latencies in a row on the critical path of the visit)
     for (int idx = t; idx < BT * BT * (LMAX + SPMAX); idx += ST) {
         const int bt = idx / (LMAX + SPMAX), e0 = idx - bt * (LMAX + SPMAX);
         const int p = bi * BT + bt / BT, q = bj * BT + bt % BT;
         if (p >= a.ntr || q >= a.ntc) continue;
         const int tile = p * a.ntc + q;
         const int nl = s_nl[bt], seg = s_seg[bt], ns = (s_seg[bt + 1] - seg - nl) / 2;
-        const int base = ((bt / BT + 1) * RT + bt % BT + 1) * NSMAX;     // this tile's levels in L
+        const int base = ((bt / BT + 1) * RT + bt % BT + 1) * NSMAX;     // this tile's levels in the region
         if (e0 < LMAX) {
             const int e = e0;
             if (e >= nl) continue;
@@ -817,15 +793,49 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
             E[seg + nl + 2 * e + 1] = lb != OCEAN ? ((unsigned long long)ib << 48) | ((unsigned long long)ia << 32) | (uint32_t)v : ~0ull;
         }
     }
+}
+
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_solve_kernel(SolveArgs sa)
+{
+    __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
+    __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
+    __shared__ int s_wake;
+    const PfArgs &a = sa.a;
+    const int t = threadIdx.x;
+    // a resident grid walks the round's list: launching one workgroup per block of the raster (4489 x 1024 threads at 16384^2,
+    // nearly all of them only to find their block inactive) cost more than the visits themselves
+    const unsigned int nwork = sa.first ? (unsigned int)(sa.nbr * sa.nbc) : *sa.count_cur;
+    for (unsigned int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    __syncthreads();                                   // the LDS arrays of the previous visit are free
+    const int blk = sa.first ? (int)wi : sa.list_cur[wi], bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
+    if (t == 0) {
+        sa.mark_cur[blk] = 0u;                         // this buffer is appended to again two rounds from now
+        s_wake = 0;
+    }
+#ifdef PF_PROFILE
+    long long pk0 = __builtin_amdgcn_s_memtime(), pk1 = 0, pk2 = 0;
+    int pk_it = 0;
+#endif
+    // ---- the block's relaxations: registers for the whole visit (EMAX / ST = 6 per thread); in flight together with the levels
+    unsigned long long er[EMAX / ST];
+#pragma unroll
+    for (int k = 0; k < EMAX / ST; ++k) er[k] = sa.eblk[(size_t)blk * EMAX + t + k * ST];
+    // ---- levels of the region
+    for (int i = t; i < RT * RT * NSMAX; i += ST) {
+        const int rt = i / NSMAX, k = i - rt * NSMAX;
+        const int p = bi * BT + rt / RT - 1, q = bj * BT + rt % RT - 1;
+        const bool ok = p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
+        L[i] = ok ? a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k] : EMPTY;
+    }
     __syncthreads();
+    for (int i = t; i < BT * BT * NSMAX; i += ST) {
+        const int bt = i / NSMAX, k = i - bt * NSMAX;
+        Lold[i] = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
+    }
 #ifdef PF_PROFILE
     pk1 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- the block's fixed point
-    // a thread's relaxations stay in registers over the iterations (EMAX / ST = 6): only the levels are read from LDS
-    unsigned long long er[EMAX / ST];
-#pragma unroll
-    for (int k = 0; k < EMAX / ST; ++k) er[k] = t + k * ST < NE ? E[t + k * ST] : ~0ull;
+    // ---- the block's fixed point (only the levels are read from LDS)
     for (int it = 0; it < BT * BT * NSMAX; ++it) {
 #ifdef PF_PROFILE
         ++pk_it;
@@ -860,16 +870,17 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
     }
     if (__syncthreads_or(moved)) {
         unsigned wake = 0;
-        for (int e = t; e < NE; e += ST) {
-            const unsigned long long r = E[e];
+#pragma unroll
+        for (int k = 0; k < EMAX / ST; ++k) {
+            const unsigned long long r = er[k];
             const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
             if (src == 0xFFFF) continue;                                       // also the ~0 placeholders
             const int st = src / NSMAX, si = st / RT, sj = st % RT;             // region tile of the source
             if (si >= 1 && si <= BT && sj >= 1 && sj <= BT) continue;          // inside the block
             const int dt = dst / NSMAX, di_ = dt / RT - 1, dj_ = dt % RT - 1;   // block-local tile of the destination
             if (L[dst] < Lold[(di_ * BT + dj_) * NSMAX + dst % NSMAX]) {
-                const int wi = si == 0 ? 0 : (si == RT - 1 ? 2 : 1), wj = sj == 0 ? 0 : (sj == RT - 1 ? 2 : 1);
-                wake |= 1u << (wi * 3 + wj);
+                const int wi2 = si == 0 ? 0 : (si == RT - 1 ? 2 : 1), wj = sj == 0 ? 0 : (sj == RT - 1 ? 2 : 1);
+                wake |= 1u << (wi2 * 3 + wj);
             }
         }
         if (wake) atomicOr(&s_wake, (int)wake);
@@ -891,7 +902,6 @@ __global__ __launch_bounds__(ST) void pf_solve_kernel(SolveArgs sa)
         atomicAdd(&a.prof[21], (unsigned long long)(pk2 - pk1));
         atomicAdd(&a.prof[22], (unsigned long long)(pk3 - pk2));
         atomicAdd(&a.prof[23], (unsigned long long)pk_it);
-        atomicAdd(&a.prof[20], (unsigned long long)NE);
     }
 #endif
     }   // the round's list
@@ -1044,6 +1054,7 @@ struct PfRun::Impl {
     int *list = nullptr;               // [2][nslots]
     unsigned int *any = nullptr;       // [round]: blocks in the list of that round
     unsigned long long *visits = nullptr;
+    unsigned long long *eblk = nullptr;   // [nslots][EMAX] packed relaxations (pf_pack_kernel)
     int64_t ntiles = 0;
     size_t nslots = 0;
     int nbr = 0, nbc = 0, round = 0, launches = 0;
@@ -1055,6 +1066,21 @@ constexpr int PF_MAXR = 1 << 14, PF_BATCH = 32;
 
 PfRun::PfRun() : impl(new Impl) {}
 PfRun::~PfRun() { delete impl; }
+
+// the relaxations of the block rows [row0, row0 + nrows) into their packed form
+int PfRun::pack(hipStream_t s, int row0, int nrows)
+{
+    Impl &m = *impl;
+    SolveArgs sa = {};
+    sa.a = m.a;
+    sa.nbr = m.nbr;
+    sa.nbc = m.nbc;
+    sa.eblk = m.eblk;
+    sa.row0 = row0;
+    hipLaunchKernelGGL(pf_pack_kernel, dim3((unsigned)m.nbc, (unsigned)nrows), dim3(ST), 0, s, sa);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
 
 // rounds of the seed-graph solve until a round appends nothing
 int PfRun::solve(hipStream_t s)
@@ -1081,7 +1107,9 @@ int PfRun::solve(hipStream_t s)
             sa.nbr = m.nbr;
             sa.nbc = m.nbc;
             sa.first = r == 0;
-            hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 512)), dim3(ST), 0, s, sa);   // two resident per CU
+            sa.eblk = m.eblk;
+            sa.row0 = 0;
+            hipLaunchKernelGGL(pf_solve_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 768)), dim3(ST), 0, s, sa);   // three resident per CU
         }
         m.launches += PF_BATCH;
         MH_HIP(hipGetLastError());
@@ -1145,9 +1173,10 @@ int PfRun::begin(hipStream_t s)
     const size_t o_act = off; off = al(off + m.nslots * 2 * 4);
     const size_t o_list = off; off = al(off + m.nslots * 2 * 4);
     const size_t o_cnt = off; off = al(off + (size_t)(PF_MAXR + 2) * 4 + 64 + 32 * 8);
+    const size_t o_eblk = off; off = al(off + m.nslots * EMAX * 8);
     MH_TRY(m.ws.alloc(off));
     char *b = m.ws.as<char>();
-    MH_HIP(hipMemsetAsync(b + o_act, 0, off - o_act, s));                 // active bytes, per-round words, flags, visits
+    MH_HIP(hipMemsetAsync(b + o_act, 0, o_eblk - o_act, s));              // active bytes, per-round words, flags, visits
     MH_HIP(hipMemsetAsync(b + o_ring, NOLAB, (size_t)ntiles * 256, s));
     PfArgs &a = m.a;
     a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = dem; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot; a.stop = 0;
@@ -1168,6 +1197,7 @@ int PfRun::begin(hipStream_t s)
     a.prof = m.visits + 1;   // 24 words (inside the zeroed tail of the workspace)
     m.mark = reinterpret_cast<unsigned int *>(b + o_act);
     m.list = reinterpret_cast<int *>(b + o_list);
+    m.eblk = reinterpret_cast<unsigned long long *>(b + o_eblk);
     m.round = 0;
     m.halo_dirty = false;
 
@@ -1212,8 +1242,9 @@ int PfRun::begin(hipStream_t s)
 #endif
     hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
+    MH_TRY(pack(s, 0, m.nbr));
     MH_HIP(hipGetLastError());
-    m.launches = 2;
+    m.launches = 3;
     MH_TRY(solve(s));
     return publish_edges(s);
 }
@@ -1237,6 +1268,8 @@ int PfRun::batch(hipStream_t s)
     hipLaunchKernelGGL(pf_append_row_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, mark, list, m.any + m.round, 0, m.nbc);
     if (m.nbr > 1)
         hipLaunchKernelGGL(pf_append_row_kernel, dim3((unsigned)cdiv(m.nbc, 256)), dim3(256), 0, s, mark, list, m.any + m.round, (m.nbr - 1) * m.nbc, m.nbc);
+    MH_TRY(pack(s, 0, 1));                                  // the halo links of the first / last tile row changed
+    if (m.nbr > 1) MH_TRY(pack(s, m.nbr - 1, 1));
     MH_HIP(hipGetLastError());
     MH_TRY(solve(s));
     return publish_edges(s);

@@ -1419,9 +1419,9 @@ static int stage_watershed(mhip_ctx *c, hipStream_t s)
     MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_WATERSHED, s, &e1));
-    MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
+    // (out of place: the watersheds start from the label raster without a copy of it)
     MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s, false,
-                          c->nodir_valid ? c->nodir_cnt.as<unsigned int>() : nullptr));
+                          c->nodir_valid ? c->nodir_cnt.as<unsigned int>() : nullptr, c->r[MHIP_R_LABELS].as<int32_t>()));
     MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
     MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s, W));
     MH_HIP(hipEventRecord(*e1, s));

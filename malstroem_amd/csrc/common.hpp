@@ -255,7 +255,7 @@ int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d
 int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
 // watershed.hip
 int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s,
-                   bool band_mode = false, const unsigned int *d_known_interior_nodir = nullptr);
+                   bool band_mode = false, const unsigned int *d_known_interior_nodir = nullptr, const int32_t *d_src = nullptr);
 int band_pseudo_labels_dev(int32_t *d_ws, int64_t H, int64_t W, int top, int bottom, hipStream_t s);
 int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nlut, hipStream_t s);
 

@@ -234,19 +234,23 @@ __global__ __launch_bounds__(256) void ws_jump_perimeter_kernel(int32_t *P, int6
 }
 
 // final pass of the fast path: a cell that still points at an entry cell takes that cell's (resolved) pointer
-__global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__restrict__ P, int32_t *lab, int64_t n)
+// `src` != `lab`: out of place -- every cell of `lab` is written (its own label unless it takes one from downstream), which saves
+// the caller the copy of the label raster it would otherwise start from
+__global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__restrict__ P, const int32_t *src, int32_t *lab, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const bool copy = src != lab;
     int32_t p = P[i];
-    if (p == NONE || p == (int32_t)i) return;      // flows out unlabelled, or labelled
-    if (p >= 0) {                                   // an entry cell
+    bool take = !(p == NONE || p == (int32_t)i);    // not: flows out unlabelled, or labelled
+    if (take && p >= 0) {                           // an entry cell
         const int32_t q = P[p];
         if (q == p) p = q | DONE;                   // the entry cell is labelled itself
         else if (q < 0) p = q;                      // resolved through the entry cell
-        else return;                                // NONE, or a flow cycle: stays unassigned
+        else take = false;                          // NONE, or a flow cycle: stays unassigned
     }
-    lab[i] = lab[p & ~DONE];
+    if (take) lab[i] = src[p & ~DONE];              // (a labelled cell: never written in place)
+    else if (copy) lab[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void ws_assign_kernel(const int32_t *__restrict__ P, const uint32_t *__restrict__ Q,
@@ -294,8 +298,11 @@ int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nl
 }
 
 int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s, bool band_mode,
-                   const unsigned int *d_known_interior_nodir)
+                   const unsigned int *d_known_interior_nodir, const int32_t *d_src)
 {
+    // d_src (optional): the label raster to start from when d_labels does not hold a copy of it yet -- the fast path then reads
+    // the labels there and writes every cell of d_labels; the general path makes the copy first
+    const int32_t *src = d_src ? d_src : d_labels;
     const int64_t n = H * W;
     if (n >= (int64_t)NONE - 1) {
         set_error("watersheds: %lld cells exceed the int32 index domain", (long long)n);
@@ -323,7 +330,7 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     }
     if (!q) {
         const int64_t ntr = cdiv(H, WT), ntc = cdiv(W, WT), ntiles = ntr * ntc;
-        hipLaunchKernelGGL(ws_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), H, W, (int)ntc, unassigned);
+        hipLaunchKernelGGL(ws_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, src, P.as<int32_t>(), H, W, (int)ntc, unassigned);
         constexpr int MAX_ROUNDS = 40;   // x 5 hops over entry cells; flow cycles end here
         for (int round = 0; round < MAX_ROUNDS;) {
             const int k = round == 0 ? 2 : 1;
@@ -336,11 +343,12 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
             round += k;
             if (!h[k - 1]) break;
         }
-        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), d_labels, n);
+        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), src, d_labels, n);
         MH_HIP(hipGetLastError());
         MH_HIP(hipStreamSynchronize(s));
         return MHIP_OK;
     }
+    if (src != d_labels) MH_HIP(hipMemcpyAsync(d_labels, src, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(ws_init_kernel, dim3(grid), dim3(256), 0, s, d_fd, d_labels, P.as<int32_t>(), q, H, W, unassigned);
     // two launches (paths up to 2**10 cells), then one at a time; every launch has its own "still open" flag
     constexpr int MAX_ROUNDS = 32;   // x 5 hops each: paths up to 2**160 cells; flow cycles end here

@@ -366,27 +366,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     bool overflow = false;
     {
         constexpr uint16_t NONE = 0xFFFF;
-        // a rolling window of the strip's column and its left / right neighbour columns (slots and elevations), read from LDS
-        // two rows ahead: the reads of row k + 2 are in flight while the pairs between rows k and k + 1 are folded.  Reads are
-        // unconditional at clamped addresses and masked afterwards (a conditional read is a branch and a wait each).  The loop
-        // is NOT unrolled and keeps no per-row registers (unrolled, with the probe loops of the slow path, this phase alone was
-        // 70 000 instructions -- more than the instruction cache -- and its registers cost the third resident workgroup)
-        const uint32_t ml = wc > 0 ? 0u : 0xFFFFFFFFu, mr = wc < WN - 1 ? 0u : 0xFFFFFFFFu;   // no column there: NONE / KINV
+        // Phase A: which of the strip's 4 * CPT neighbour pairs (right, down-left, down, down-right of each of its cells) straddle
+        // two basins -- bit 4 k + d of `cmask`.  Only 29 % of them do, and only those are folded below (folding every pair,
+        // candidate or not, was 47 instructions x 32 pairs per thread: the one VALU-bound phase of the kernel).  Slots come from
+        // LDS two rows ahead, unconditionally at clamped addresses, masked afterwards (a conditional read is a branch and a wait).
+        const uint32_t ml = wc > 0 ? 0u : 0xFFFFu, mr = wc < WN - 1 ? 0u : 0xFFFFu;     // no column there: NONE
         const int cl = wc > 0 ? wc - 1 : 0, cr = wc < WN - 1 ? wc + 1 : WN - 1;
-        struct Row { uint32_t sl, sc, sr, zl, zc, zr; };
-        auto rd_row = [&](int row) -> Row {
-            const uint32_t mrow = row < WN ? 0u : 0xFFFFFFFFu;      // wave-uniform
+        struct Slots { uint32_t sl, sc, sr; };
+        auto rd_slots = [&](int row) -> Slots {
+            const uint32_t mrow = row < WN ? 0u : 0xFFFFu;          // wave-uniform
             const int rb = (row < WN ? row : WN - 1) * WN;
-            Row r;
-            r.sl = ((uint32_t)ptr[rb + cl] | ml | mrow) & 0xFFFFu;
-            r.sc = ((uint32_t)ptr[rb + wc] | mrow) & 0xFFFFu;
-            r.sr = ((uint32_t)ptr[rb + cr] | mr | mrow) & 0xFFFFu;
-            r.zl = zk[rb + cl] | ml | mrow;
-            r.zc = zk[rb + wc] | mrow;
-            r.zr = zk[rb + cr] | mr | mrow;
+            Slots r;
+            r.sl = (uint32_t)ptr[rb + cl] | ml | mrow;
+            r.sc = (uint32_t)ptr[rb + wc] | mrow;
+            r.sr = (uint32_t)ptr[rb + cr] | mr | mrow;
             return r;
         };
-        Row ra = rd_row(wr0), rb1 = rd_row(wr0 + 1);
+        uint32_t cmask = 0;
+        {
+            Slots ra = rd_slots(wr0), rb1 = rd_slots(wr0 + 1);
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const Slots rc = rd_slots(wr0 + k + 2);
+                const uint32_t sa = ra.sc;
+                const uint32_t nb[4] = {ra.sr, rb1.sl, rb1.sc, rb1.sr};
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    cmask |= ((sa != NONE) & (nb[d] != NONE) & (nb[d] != sa)) ? 1u << (4 * k + d) : 0u;
+                ra = rb1;
+                rb1 = rc;
+            }
+        }
         // LDS atomics are the expensive instruction here (several cycles per active lane, more when lanes share a slot): a
         // thread first folds its 4 * CPT candidates into a register set of distinct pairs (adjacent cells mostly straddle the
         // same two basins) and only the set goes to the hash; a candidate that finds the set full goes there directly
@@ -412,38 +422,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             }
             return false;
         };
+        // Phase B: one candidate per lane and turn until the slowest lane of the wavefront is through (9 candidates per lane on
+        // average, but a lane on a basin boundary that runs down its strip holds ~3 per row: pair phase 1.63 -> 1.51 ms only;
+        // prefetching the next turn's operands changes nothing -- the turns are VALU, not latency)
 #pragma nounroll
-        for (int k = 0; k < CPT; ++k) {
-            const Row rc = rd_row(wr0 + k + 2);
-            const uint32_t sa = ra.sc, own = ra.zc;
-            const uint32_t nb[4] = {ra.sr, rb1.sl, rb1.sc, rb1.sr};
-            const uint32_t nz[4] = {ra.zr, rb1.zl, rb1.zc, rb1.zr};
+        while (__any(cmask != 0u)) {
+            const bool cand = cmask != 0u;
+            const int bpos = cand ? __builtin_ctz(cmask) : 0;
+            cmask &= cmask - 1u;                                     // (0 stays 0)
+            const int kk = bpos >> 2, dd = bpos & 3;
+            const int ci = (wr0 + kk) * WN + wc;
+            const int ni_ = min(ci + (dd == 0 ? 1 : WN - 2 + dd), NC - 1);   // right | down-left, down, down-right
+            const uint32_t sa = ptr[ci], sb = ptr[ni_];
+            const uint32_t w = max(zk[ci], zk[ni_]);
+            const uint32_t key = cand ? (min(sa, sb) << 10 | max(sa, sb)) : EMPTY;
+            bool placed = !cand;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint32_t sb = nb[d];
-                const bool cand = (sa != NONE) & (sb != NONE) & (sb != sa);
-                const uint32_t key = cand ? (min(sa, sb) << 10 | max(sa, sb)) : EMPTY;
-                const uint32_t w = max(own, nz[d]);
-                bool placed = !cand;
-#pragma unroll
-                for (int j = 0; j < NCK; ++j) {
-                    const bool hit = !placed && (ck[j] == key || ck[j] == EMPTY);
-                    cw[j] = hit ? min(cw[j], w) : cw[j];
-                    ck[j] = hit ? key : ck[j];
-                    placed = placed || hit;
-                }
-#ifdef PF_PROFILE
-                pf_ncand += cand;
-#endif
-                if (!placed) {   // set full (rare)
-#ifdef PF_PROFILE
-                    ++pf_nslow;
-#endif
-                    if (!hash_insert(key, w)) overflow = true;
-                }
+            for (int j = 0; j < NCK; ++j) {
+                const bool hit = !placed && (ck[j] == key || ck[j] == EMPTY);
+                cw[j] = hit ? min(cw[j], w) : cw[j];
+                ck[j] = hit ? key : ck[j];
+                placed = placed || hit;
             }
-            ra = rb1;
-            rb1 = rc;
+#ifdef PF_PROFILE
+            pf_ncand += cand;
+#endif
+            if (!placed) {   // set full (rare)
+#ifdef PF_PROFILE
+                ++pf_nslow;
+#endif
+                if (!hash_insert(key, w)) overflow = true;
+            }
         }
         {
             uint32_t prev[NCK];

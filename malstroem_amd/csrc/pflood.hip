@@ -366,35 +366,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     bool overflow = false;
     {
         constexpr uint16_t NONE = 0xFFFF;
-        // Phase A: which of the strip's 4 * CPT neighbour pairs (right, down-left, down, down-right of each of its cells) straddle
-        // two basins -- bit 4 k + d of `cmask`.  Only 29 % of them do, and only those are folded below (folding every pair,
-        // candidate or not, was 47 instructions x 32 pairs per thread: the one VALU-bound phase of the kernel).  Slots come from
-        // LDS two rows ahead, unconditionally at clamped addresses, masked afterwards (a conditional read is a branch and a wait).
-        const uint32_t ml = wc > 0 ? 0u : 0xFFFFu, mr = wc < WN - 1 ? 0u : 0xFFFFu;     // no column there: NONE
-        const int cl = wc > 0 ? wc - 1 : 0, cr = wc < WN - 1 ? wc + 1 : WN - 1;
-        struct Slots { uint32_t sl, sc, sr; };
-        auto rd_slots = [&](int row) -> Slots {
-            const uint32_t mrow = row < WN ? 0u : 0xFFFFu;          // wave-uniform
-            const int rb = (row < WN ? row : WN - 1) * WN;
-            Slots r;
-            r.sl = (uint32_t)ptr[rb + cl] | ml | mrow;
-            r.sc = (uint32_t)ptr[rb + wc] | mrow;
-            r.sr = (uint32_t)ptr[rb + cr] | mr | mrow;
-            return r;
-        };
+        // Phase A: which neighbour pairs (right, down-left, down, down-right of a cell) straddle two basins.  Only 29 % of them do,
+        // and only those are folded below (folding every pair, candidate or not, was 47 instructions x 32 pairs per thread: the one
+        // VALU-bound phase of the kernel).  For this phase a thread owns a block of 4 rows x 2 columns of the wavefront's 8 x 64
+        // strip, not its 8 x 1 column: the turns of phase B are set by the lane with the most candidates, and a lane on a basin
+        // boundary that runs down its column held ~3 per row.  Bit 8 r + 4 c + d of `cmask`: row r, column c of the block, pair d.
+        const int bc0 = 2 * (wc & 31), br0 = wr0 + 4 * (wc >> 5);
         uint32_t cmask = 0;
         {
-            Slots ra = rd_slots(wr0), rb1 = rd_slots(wr0 + 1);
+            // slots of the block's rows br0 .. br0 + 4, columns bc0 - 1 .. bc0 + 2 (NONE outside the window)
+            auto slot = [&](int row, int col) -> uint32_t {
+                const bool in = row < WN && col >= 0 && col < WN;
+                const uint32_t v = ptr[(row < WN ? row : WN - 1) * WN + (col < 0 ? 0 : (col < WN ? col : WN - 1))];
+                return in ? v : (uint32_t)NONE;
+            };
+            uint32_t up[4], dn[4];
 #pragma unroll
-            for (int k = 0; k < CPT; ++k) {
-                const Slots rc = rd_slots(wr0 + k + 2);
-                const uint32_t sa = ra.sc;
-                const uint32_t nb[4] = {ra.sr, rb1.sl, rb1.sc, rb1.sr};
+            for (int j = 0; j < 4; ++j) up[j] = slot(br0, bc0 - 1 + j);
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    cmask |= ((sa != NONE) & (nb[d] != NONE) & (nb[d] != sa)) ? 1u << (4 * k + d) : 0u;
-                ra = rb1;
-                rb1 = rc;
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dn[j] = slot(br0 + r + 1, bc0 - 1 + j);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t sa = up[1 + c];
+                    const uint32_t nb[4] = {up[2 + c], dn[c], dn[1 + c], dn[2 + c]};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        cmask |= ((sa != NONE) & (nb[d] != NONE) & (nb[d] != sa)) ? 1u << (8 * r + 4 * c + d) : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) up[j] = dn[j];
             }
         }
         // LDS atomics are the expensive instruction here (several cycles per active lane, more when lanes share a slot): a
@@ -430,8 +432,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             const bool cand = cmask != 0u;
             const int bpos = cand ? __builtin_ctz(cmask) : 0;
             cmask &= cmask - 1u;                                     // (0 stays 0)
-            const int kk = bpos >> 2, dd = bpos & 3;
-            const int ci = (wr0 + kk) * WN + wc;
+            const int dd = bpos & 3;
+            const int ci = (br0 + (bpos >> 3)) * WN + bc0 + ((bpos >> 2) & 1);
             const int ni_ = min(ci + (dd == 0 ? 1 : WN - 2 + dd), NC - 1);   // right | down-left, down, down-right
             const uint32_t sa = ptr[ci], sb = ptr[ni_];
             const uint32_t w = max(zk[ci], zk[ni_]);

@@ -899,17 +899,20 @@ int GeoRun::batch(hipStream_t s, bool *active)
 {
     Impl &m = *impl;
     static const bool no_light = getenv("MHIP_NG_NOLIGHT") != nullptr;   // development knob
+    // rounds per host read-back; MHIP_NG_BATCH (tests): a small batch makes small rasters reach the self-listing tail rounds too
+    const char *eb = getenv("MHIP_NG_BATCH");
+    const int nb = eb && atoi(eb) >= 1 && atoi(eb) <= BATCH ? atoi(eb) : BATCH;
     for (;;) {
         if (m.round + BATCH > MAXR) {
             set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
             return MHIP_ENOTCONV;
         }
-        MH_TRY(launch_rounds(s, BATCH));
+        MH_TRY(launch_rounds(s, nb));
         if (tail_hook) tail_hook->fire(s);      // the throughput-bound rounds are behind this point of the stream
         uint32_t h_any[BATCH];
-        MH_HIP(hipMemcpyAsync(h_any, m.d_any + (m.round - BATCH), sizeof(h_any), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(h_any, m.d_any + (m.round - nb), sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
-        for (int k = 0; k < BATCH; ++k) {
+        for (int k = 0; k < nb; ++k) {
             if (!h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
                 *active = false;
                 m.light = false;   // (a band's halo exchange wakes tiles through the mark bytes: the next round compacts them)
@@ -917,7 +920,7 @@ int GeoRun::batch(hipStream_t s, bool *active)
             }
             ++m.used;
         }
-        if (!m.light && h_any[BATCH - 1] <= LIGHT_TILES && !no_light) {   // the tail: from here on the rounds build their lists themselves
+        if (!m.light && h_any[nb - 1] <= LIGHT_TILES && !no_light) {   // the tail: from here on the rounds build their lists themselves
             m.light = true;
             m.light_from = m.round;
         }

@@ -70,6 +70,18 @@ def test_bands_match_oracle(nbands, h, w):
     assert out[0]["exchanges"]["fill"] <= 12 and out[0]["exchanges"]["noflat"] <= 12
 
 
+@pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (4, 1000, 130), (3, 380, 260)])
+def test_bands_with_self_listing_tail_rounds(monkeypatch, nbands, h, w):
+    """the geodesic rounds that build their own lists (the tail at 16384^2; MHIP_NG_BATCH=1: every round after the first here) across
+    halo exchanges: an exchange wakes tiles through the mark bytes, the next round compacts them, the rounds after it append again"""
+    monkeypatch.setenv("MHIP_NG_BATCH", "1")
+    dem = fbm(h, w, beta=2.0, seed=24)
+    dem[h // 2 - 30:h // 2 + 30, w // 5:w // 5 + 80] = dem[h // 2, w // 5]           # a flat across a seam
+    out = run_bands(dem, nbands)
+    check_bands_against_oracle(dem, out)
+    assert all(o["engines"][1] == 2 for o in out), [o["engines"] for o in out]
+
+
 @pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (3, 380, 130), (4, 1000, 130)])
 def test_bands_off_the_tile_grid_run_the_iterative_fill(nbands, h, w):
     dem = fbm(h, w, beta=2.0, seed=22)

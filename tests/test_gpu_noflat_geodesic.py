@@ -97,6 +97,16 @@ def test_a_flat_longer_than_the_uint32_headroom():
     check(dem, algorithm=3)
 
 
+@pytest.mark.parametrize("h,w,beta,seed", [(300, 260, 2.0, 5), (700, 513, 3.0, 6), (190, 1000, 2.5, 7)])
+def test_self_listing_tail_rounds_on_small_rasters(monkeypatch, h, w, beta, seed):
+    """At 16384^2 the rounds after the first batch hold few tiles and build the next round's list themselves (atomic appends
+    instead of mark bytes + a compaction launch).  MHIP_NG_BATCH=1 makes every raster take that path from its second round on."""
+    monkeypatch.setenv("MHIP_NG_BATCH", "1")
+    dem = fbm(h, w, beta=beta, seed=seed) + np.float32(10.0)
+    dem[h // 3:h // 3 + 40, w // 4:w // 4 + 150] = dem[h // 3, w // 4]            # a flat that spans several tiles
+    assert check(dem) == 2
+
+
 def test_the_device_check_is_live(monkeypatch):
     """MHIP_NG_CORRUPT makes the transform hand wrong distances (one raster row) to the final check: the check has to see them,
     the call has to fall back to the float64 relaxation (algorithm 0) -- and still return the reference's surface."""

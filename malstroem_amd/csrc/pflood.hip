@@ -15,8 +15,9 @@
 //                         of every ring cell, and the min spill elevation between pairs of seeds.
 //   K2 pf_link_kernel     a ring cell of tile T is an owned cell of a neighbouring tile T': both seeds it drains to are
 //                         joined by an edge of weight W_T'[cell]; de-duplicated per tile.
-//   K3 pf_solve_kernel    minimax distance of every seed to OCEAN over (spill edges + links): tile worklist rounds like
-//                         fill.hip's, but a visit touches ~2 KB instead of a 48 KB window.
+//   K3 pf_pack_kernel /   minimax distance of every seed to OCEAN over (spill edges + links): worklist rounds over blocks of
+//      pf_solve_kernel    4 x 4 tiles; the block's relaxations are packed once and held in registers during a visit, the levels
+//                         of its 6 x 6 region of tiles in LDS.
 //   K4 pf_final_kernel /  level of a basin = max(V, L[seed]);  F[c] = max(dem[c], level[basin[c]]), depths = F - dem.
 //      pf_apply_kernel
 //
@@ -135,8 +136,8 @@ __device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
 
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_tile_kernel(PfArgs a)
 {
-    // LDS plan (49 KB: three workgroups = 24 wavefronts per CU; the phases below are bound by LDS / barrier latency, not by
-    // LDS bandwidth, so residency is what pays):
+    // LDS plan (49 KB: three workgroups = 24 wavefronts per CU -- which also takes <= 80 VGPRs, see the launch attribute; all
+    // phases but the pair fold are bound by LDS / barrier latency, not by LDS bandwidth, so residency is what pays):
     //   zk   16 KB  elevation keys of the window                      -> after S5: the compacted basin pairs (ek | ew)
     //   ptr   8 KB  steepest-descent pointer -> pit (root) of a cell  -> S4: basin slot of a root -> S5: basin slot of a cell
     //   hkv  16 KB  plateau ids | plateau drains (16 bit each, S2b)   -> basin-pair hash (keys | values, S5)
@@ -717,13 +718,13 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
 }
 
 // ---- K3: one round of the seed-graph solve; a workgroup visits a BLOCK of BT x BT tiles --------------------------------------
-// The levels L of the block's seeds and of the ring of tiles around it (a (BT+2)^2 region), and the block's edges (links and
-// spill edges, as directed relaxations dst <- max(w, src)) sit in LDS; the block iterates to ITS fixed point there, with the
-// ring frozen, and writes its levels back.  Information crosses BT tiles per round (the per-tile version of this kernel
+// The levels L of the block's seeds and of the ring of tiles around it (a (BT+2)^2 region) sit in LDS, the block's edges (links
+// and spill edges, as directed relaxations dst <- max(w, src)) in registers; the block iterates to ITS fixed point there, with
+// the ring frozen, and writes its levels back.  Information crosses BT tiles per round (the per-tile version of this kernel
 // needed ~225 rounds at 16384^2 and was bound by the latency of ~25 small dependent global accesses per visit).
-// Worklist without atomics: one "active" byte per block, double buffered over the rounds; a block that lowered a seed with a
-// link into a neighbouring block sets that block's byte for the next round with a plain store and raises the round's
-// "somebody appended" word.  Levels move with plain loads / stores: a value written in this round may or may not be seen by
+// Worklist: a list of blocks per round, double buffered; a block that lowered a seed with a link into a neighbouring block
+// appends that block to the next round's list (one atomicExch on its mark word + one atomicAdd on the list's counter, a few
+// thousand per round).  Levels move with plain loads / stores: a value written in this round may or may not be seen by
 // a neighbour visited in the same round (it is only ever lower: harmless), and that neighbour is visited again in the next
 // round -- a new launch -- where it is seen for sure.
 constexpr int BT = 4;                      // tiles per block edge

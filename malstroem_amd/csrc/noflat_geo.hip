@@ -19,16 +19,19 @@
 // (distance word D_IRR) and get the upper bound F + seed_add in the surface; so does a distance that outgrows the uint32
 // headroom.  The caller settles those flats with the float64 relaxation of fill.hip (a "partial" surface).  NaN cells: not for
 // this path at all.
-// None of this is trusted: after the distances are turned into G, ng_verify_kernel evaluates (*) at EVERY cell in the
-// reference's own float64 arithmetic.  One mismatch anywhere -> the caller runs the float64 relaxation from scratch.
+// None of this is trusted: as the distances are turned into G, ng_finish_kernel (ng_verify_kernel for a partial surface)
+// evaluates (*) at EVERY cell in the reference's own float64 arithmetic.  One mismatch anywhere -> the caller runs the float64
+// relaxation from scratch.
 //
 // Kernels.  ng_first (every tile once, one wavefront per 62 x 62 tile + ring): classifies the window from F -- per cell a 16-bit
 // word = same-level adjacency byte | binade class << 8 -- builds the words of both layouts the passes want and keeps them as a
 // 16 KB block per tile + a header; writes the start distances.  ng_round (one launch per round, tiles from a compacted list): a
 // wavefront holds the 64 x 64 window of distances in 64 VGPRs and relaxes it by row-sequential passes (down, up; transposed
 // through wave-private LDS: right, left) with DPP neighbours; a tile whose edge cells moved marks the neighbouring tiles it
-// shares a flat with (one byte per tile, plain stores); ng_compact turns the marks into the next round's list.
-// ng_assemble (streaming): G = F + u * D.  ng_verify (streaming): (*).
+// shares a flat with (one byte per tile, plain stores); ng_compact turns the marks into the next round's list.  Once the rounds
+// are small (the tail) they append the woken tiles to the next round's list themselves and the compaction launch goes.
+// ng_finish (streaming): G = F + u * D assembled in registers, (*) checked against the eight neighbours, G written.
+// ng_assemble / ng_verify: the same in two passes, for a partial surface and for the caller's check after the relaxation.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

@@ -249,18 +249,28 @@ __global__ __launch_bounds__(WB) void ccl_bits_prefix_kernel(const unsigned long
 }
 
 // labels[i] = 1 + rank of root(i):  i -> its tile root -> (flattened) the component's root -> bits before it
+// (four cells per thread, 16-byte loads / stores: the tile-root -> component-root -> rank look-ups of the four are independent)
 __global__ __launch_bounds__(256) void ccl_emit_ranked_kernel(const int32_t *__restrict__ parent, const unsigned long long *__restrict__ rootbits,
                                                               const uint32_t *__restrict__ wordprefix, int32_t *__restrict__ labels, int64_t n)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t p = parent[i];
-    int32_t lab = 0;
-    if (p >= 0) {
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    auto rank_of = [&](int32_t p) -> int32_t {
+        if (p < 0) return 0;
         const int32_t g = parent[p];      // parent[tile root] = component root; a component root is its own parent
-        lab = (int32_t)(wordprefix[g >> 6] + (uint32_t)__popcll(rootbits[g >> 6] & ((1ull << (g & 63)) - 1ull))) + 1;
+        return (int32_t)(wordprefix[g >> 6] + (uint32_t)__popcll(rootbits[g >> 6] & ((1ull << (g & 63)) - 1ull))) + 1;
+    };
+    if (i0 + 4 <= n) {
+        const int4 p = *reinterpret_cast<const int4 *>(parent + i0);
+        int4 l;
+        l.x = rank_of(p.x);
+        l.y = rank_of(p.y);
+        l.z = rank_of(p.z);
+        l.w = rank_of(p.w);
+        *reinterpret_cast<int4 *>(labels + i0) = l;
+    } else {
+        for (int64_t i = i0; i < n; ++i) labels[i] = rank_of(parent[i]);
     }
-    labels[i] = lab;
 }
 
 // unions across the tile seams.  Horizontal seams (rows that start a tile): the rule of ccl_merge_kernel for N / NW / NE.
@@ -444,7 +454,7 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bcounts.as<uint32_t>(), nwb, total.as<unsigned long long>());
         hipLaunchKernelGGL(ccl_bits_prefix_kernel, dim3((unsigned)nwb), dim3(WB), 0, s, bits.as<unsigned long long>(), nwords, bcounts.as<uint32_t>(),
                            wprefix.as<uint32_t>());
-        hipLaunchKernelGGL(ccl_emit_ranked_kernel, dim3(g256), dim3(256), 0, s, parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, n);
+        hipLaunchKernelGGL(ccl_emit_ranked_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, n);
         MH_HIP(hipGetLastError());
         unsigned long long h_total = 0;
         MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));

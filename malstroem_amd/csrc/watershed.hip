@@ -238,19 +238,43 @@ __global__ __launch_bounds__(256) void ws_jump_perimeter_kernel(int32_t *P, int6
 // the caller the copy of the label raster it would otherwise start from
 __global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__restrict__ P, const int32_t *src, int32_t *lab, int64_t n)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // four cells per thread: 16-byte loads of P (and of src out of place), one 16-byte store out of place
+    const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
     const bool copy = src != lab;
-    int32_t p = P[i];
-    bool take = !(p == NONE || p == (int32_t)i);    // not: flows out unlabelled, or labelled
-    if (take && p >= 0) {                           // an entry cell
-        const int32_t q = P[p];
-        if (q == p) p = q | DONE;                   // the entry cell is labelled itself
-        else if (q < 0) p = q;                      // resolved through the entry cell
-        else take = false;                          // NONE, or a flow cycle: stays unassigned
+    auto target = [&](int64_t i, int32_t p) -> int32_t {     // the cell whose label cell i takes, or -1: it keeps its own
+        if (p == NONE || p == (int32_t)i) return -1;         // flows out unlabelled, or labelled
+        if (p >= 0) {                                         // an entry cell
+            const int32_t q = P[p];
+            if (q == p) p = q | DONE;                         // the entry cell is labelled itself
+            else if (q < 0) p = q;                            // resolved through the entry cell
+            else return -1;                                   // NONE, or a flow cycle: stays unassigned
+        }
+        return p & ~DONE;
+    };
+    if (i0 + 4 <= n) {
+        const int4 p = *reinterpret_cast<const int4 *>(P + i0);
+        const int32_t t0 = target(i0, p.x), t1 = target(i0 + 1, p.y), t2 = target(i0 + 2, p.z), t3 = target(i0 + 3, p.w);
+        if (copy) {
+            int4 v = *reinterpret_cast<const int4 *>(src + i0);
+            if (t0 >= 0) v.x = src[t0];
+            if (t1 >= 0) v.y = src[t1];
+            if (t2 >= 0) v.z = src[t2];
+            if (t3 >= 0) v.w = src[t3];
+            *reinterpret_cast<int4 *>(lab + i0) = v;
+        } else {      // in place: a labelled cell is never written
+            if (t0 >= 0) lab[i0] = src[t0];
+            if (t1 >= 0) lab[i0 + 1] = src[t1];
+            if (t2 >= 0) lab[i0 + 2] = src[t2];
+            if (t3 >= 0) lab[i0 + 3] = src[t3];
+        }
+    } else {
+        for (int64_t i = i0; i < n; ++i) {
+            const int32_t t = target(i, P[i]);
+            if (t >= 0) lab[i] = src[t];
+            else if (copy) lab[i] = src[i];
+        }
     }
-    if (take) lab[i] = src[p & ~DONE];              // (a labelled cell: never written in place)
-    else if (copy) lab[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void ws_assign_kernel(const int32_t *__restrict__ P, const uint32_t *__restrict__ Q,
@@ -343,7 +367,7 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
             round += k;
             if (!h[k - 1]) break;
         }
-        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), src, d_labels, n);
+        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, P.as<int32_t>(), src, d_labels, n);
         MH_HIP(hipGetLastError());
         MH_HIP(hipStreamSynchronize(s));
         return MHIP_OK;

@@ -49,7 +49,11 @@ constexpr uint32_t TAINT32 = 1u << 31;
 constexpr int R_SHIFT = 13;
 constexpr uint32_t A_MASK = 0x1fffu, R_MASK = 0xfffu, SENT13 = A_MASK;
 constexpr uint16_t NO_EXIT = 0xffffu;
-constexpr int CPT = AT * AT / 256;        // cells per thread
+#ifndef ACC_ATN
+#define ACC_ATN 256
+#endif
+constexpr int ATN = ACC_ATN;              // threads per tile
+constexpr int CPT = AT * AT / ATN;        // cells per thread
 constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simple path
 // phase-2 node word: an exit cell can be fed by every entry of its tile (hundreds), so the pending field is wider
 constexpr int G_SHIFT = 44;
@@ -102,7 +106,10 @@ template <bool FINAL, bool WIDE>
 // Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
 // final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
 // they never receive and are never written here.
-__global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
+#ifdef ACC_WAVES
+__attribute__((amdgpu_waves_per_eu(ACC_WAVES, ACC_WAVES)))
+#endif
+__global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
                                                         int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot, int halo_zero)
 {
     static_assert(WIDE || !FINAL, "phase 3 sums are 64-bit");
@@ -125,12 +132,12 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     __shared__ __attribute__((aligned(16))) uint8_t win[(AT + 2) * FS];
     __shared__ uint64_t inflow_l[FINAL ? NODE_STRIDE : 1];
     __shared__ uint32_t arrived_l[FINAL ? NODE_STRIDE : 1];
-    if (FINAL) {  // what phase 2 delivered to my perimeter cells: one coalesced read per array
+    if (FINAL && tid < NODE_STRIDE) {  // what phase 2 delivered to my perimeter cells: one coalesced read per array
         inflow_l[tid] = nd.inflow[(int64_t)tile * NODE_STRIDE + tid];
         arrived_l[tid] = nd.arrived[(int64_t)tile * NODE_STRIDE + tid];
     }
     const bool wide = (W % 16) == 0 && c0 + AT <= W;   // c0 is a multiple of 64: chunks are 16-byte aligned in global memory
-    for (int q = tid; q < (AT + 2) * 6; q += 256) {
+    for (int q = tid; q < (AT + 2) * 6; q += ATN) {
         const int wr = q / 6, k = q - wr * 6;
         const int64_t rr = r0 + wr - 1;
         const bool row_in = rr >= 0 && rr < H;
@@ -173,12 +180,12 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     }
     __syncthreads();
 
-    // my CPT cells: i = tid + 256 j (consecutive lanes = consecutive LDS words)
+    // my CPT cells: i = tid + ATN j (consecutive lanes = consecutive LDS words)
     sum_t sreg[CPT];      // my cells' sums as of the last barrier (what I push)
     uint32_t preg[CPT];   // ... and their A | R << 13
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
-        const int i = tid + 256 * j;
+        const int i = tid + ATN * j;
         const int r = i / AT, c = i - r * AT;
         const bool inside = (r0 + r) < H && (c0 + c) < W;
         const int slot = perim_slot(r, c);
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
         bool mine = false;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + ATN * j;
             if ((preg[j] & A_MASK) != SENT13) {
                 const uint32_t w = FINAL ? (got[j] & A_MASK) : got[j];   // A_{k+1} | R_{k+1}
                 P[i] = (ptr_t)w;
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     if (FINAL) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + ATN * j;
             const int r = i / AT, c = i - r * AT;
             if ((r0 + r) < H && (c0 + c) < W && !halo_row(r0 + r)) {
                 const sum_t s = S[i];
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(256) void accum_tile_kernel(const uint8_t *__restri
     if (nd.halo_first) {
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + ATN * j;
             const int r = i / AT, c = i - r * AT;
             if (!((r0 + r) < H && (c0 + c) < W && halo_row(r0 + r))) continue;
             const uint32_t pw = P[i];
@@ -470,15 +477,15 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
     // the local sums of phase 1 fit 32 bits unless halo cells bring the neighbouring band's flux in (the final pass of a row band)
     if ((fixed_top || fixed_bot) && !halo_zero)
-        hipLaunchKernelGGL((accum_tile_kernel<false, true>), dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+        hipLaunchKernelGGL((accum_tile_kernel<false, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else
-        hipLaunchKernelGGL((accum_tile_kernel<false, false>), dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+        hipLaunchKernelGGL((accum_tile_kernel<false, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     hipLaunchKernelGGL(accum_link_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     if (d_exit_map)
         hipLaunchKernelGGL(accum_band_exit_kernel, dim3((unsigned)cdiv(2 * W, 256)), dim3(256), 0, s, nd, H, W, ntc, ntiles, fixed_top, fixed_bot, d_exit_map);
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
-    hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
 #ifdef MH_PROFILE_ACCUM

@@ -100,8 +100,8 @@ __device__ unsigned long long g_accum_prof[2][8];
 #endif
 
 // ---- the tile kernel (phase 1 when FINAL == false, phase 3 when FINAL == true) ------------------------------
-// WIDE: 64-bit sums (phase 3 always; phase 1 only in the final pass of a row band, where the halo cells are sources of the
-// neighbouring band's flux)
+// WIDE: 64-bit sums (a row band's final pass, where the halo cells are sources of the neighbouring band's flux -- sums of the
+// whole raster -- and any raster of 2**31 cells or more; everything else stays below 2**31 in every sum)
 template <bool FINAL, bool WIDE>
 // Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
 // final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
@@ -112,7 +112,6 @@ __attribute__((amdgpu_waves_per_eu(ACC_WAVES, ACC_WAVES)))
 __global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
                                                         int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot, int halo_zero)
 {
-    static_assert(WIDE || !FINAL, "phase 3 sums are 64-bit");
     using sum_t = typename std::conditional<WIDE, unsigned long long, uint32_t>::type;
     using ptr_t = typename std::conditional<FINAL, uint16_t, uint32_t>::type;
     constexpr sum_t TAINT_S = WIDE ? (sum_t)TAINT : (sum_t)TAINT32;
@@ -485,7 +484,11 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
         hipLaunchKernelGGL(accum_band_exit_kernel, dim3((unsigned)cdiv(2 * W, 256)), dim3(256), 0, s, nd, H, W, ntc, ntiles, fixed_top, fixed_bot, d_exit_map);
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
-    hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    // final values are at most H * W without halo sources: 32-bit sums (half the LDS, cheaper atomics) below 2**31 cells
+    if (!(fixed_top || fixed_bot) && H * W < (int64_t)0x7fffffff)
+        hipLaunchKernelGGL((accum_tile_kernel<true, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    else
+        hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
     MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
 #ifdef MH_PROFILE_ACCUM

@@ -394,17 +394,21 @@ __global__ __launch_bounds__(256) void accum_graph_walk_kernel(Nodes nd, int64_t
     const uint64_t s0 = nd.gstate[x];
     if (!(s0 & SRC)) return;
     uint64_t total = s0 & G_SUM;
+    // the walk is a chain of dependent round trips (a river crosses hundreds of tiles): the links of the next node are fetched
+    // while its pending count comes back, one round trip per step instead of two
+    int32_t e = nd.dst[x], nx = nd.next[x];
     for (;;) {
-        const int32_t e = nd.dst[x];
         atomicAdd(reinterpret_cast<unsigned long long *>(&nd.inflow[e]), (unsigned long long)total);
         atomicAdd(&nd.arrived[e], 1u);
-        const int32_t nx = nd.next[x];
         if (nx < 0) break;
+        const int32_t e2 = nd.dst[nx], nx2 = nd.next[nx];
         const uint64_t delta = total - G_ONE;
         const uint64_t now = atomicAdd(reinterpret_cast<unsigned long long *>(&nd.gstate[nx]), (unsigned long long)delta) + delta;
         if ((now >> G_SHIFT) & G_PEND) break;
         total = now & G_SUM;
         x = nx;
+        e = e2;
+        nx = nx2;
     }
 }
 

@@ -144,11 +144,22 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
         __syncthreads();
         const int64_t tr = tile / g.ntc, tc = tile - tr * g.ntc;
         const int64_t col = tc * 256 + threadIdx.x;
-        for (int rr = 0; rr < TR; ++rr) {
-            const int64_t i = (tr * TR + rr) * g.W + col;
-            const bool valid = col < g.W && i < g.n;
-            int32_t l = valid ? lab[i] : -1;
-            const float v = valid ? data[i] : 0.0f;
+        for (int r4 = 0; r4 < TR; r4 += 4) {
+        int32_t lq[4];           // four rows' loads in flight
+        float dq[4];
+        bool vq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = (tr * TR + r4 + u) * g.W + col;
+            vq[u] = col < g.W && i < g.n;
+            lq[u] = vq[u] ? lab[i] : -1;
+            dq[u] = vq[u] ? data[i] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int32_t l = lq[u];
+            const float v = dq[u];
+            const bool valid = vq[u];
             if (valid && (l < 0 || l > nlab)) {
                 atomicOr(bad, 1u);
                 l = -1;
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
                 }
             }
         }
+        }   // four rows
         __syncthreads();
         for (int k = threadIdx.x; k < STATS_TS; k += 256)
             if (keys[k] >= 0) to_global(keys[k], tmin[k], tmax[k], tsum[k], (unsigned long long)tcnt[k]);
@@ -364,15 +376,26 @@ __global__ __launch_bounds__(256) void arg_packed_kernel(const double *__restric
     const int lane = threadIdx.x & 63;
     uint64_t bkey = 0;  // background (label 0), kept in registers
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nloop = cdiv(n, stride) * stride;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nloop; i += stride) {
+    const int64_t nloop = cdiv(n, 4 * stride) * 4 * stride;
+    for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < nloop; i4 += 4 * stride) {
+    int32_t lq[4];       // four strides' loads in flight
+    double dq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = i4 + u * stride;
+        lq[u] = i < n ? lab[i] : -1;
+        dq[u] = i < n ? data[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = i4 + u * stride;
         const bool valid = i < n;
-        int32_t l = valid ? lab[i] : -1;
+        int32_t l = lq[u];
         if (valid && (l < 0 || l > nlab)) {
             atomicOr(bad, 1u);
             l = -1;
         }
-        const double v = valid ? data[i] : 0.0;
+        const double v = dq[u];
         const bool isint = v >= 0.0 && v < 4294967296.0 && (double)(uint32_t)v == v;   // false for NaN
         if (valid && !isint) atomicOr(notint, 1u);
         uint64_t k = ((uint64_t)(uint32_t)v << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
@@ -389,6 +412,7 @@ __global__ __launch_bounds__(256) void arg_packed_kernel(const double *__restric
             else if (k > key[l]) atomicMax(reinterpret_cast<unsigned long long *>(&key[l]), (unsigned long long)k);
         }
     }
+    }   // four strides
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint64_t ob = __shfl_xor(bkey, o);
@@ -454,26 +478,36 @@ __global__ __launch_bounds__(256) void count_kernel(const int32_t *__restrict__ 
         __syncthreads();
         const int64_t tr = tile / g.ntc, tc = tile - tr * g.ntc;
         const int64_t col = tc * 256 + threadIdx.x;
-        for (int rr = 0; rr < TR; ++rr) {
-            const int64_t i = (tr * TR + rr) * g.W + col;
-            const bool valid = col < g.W && i < g.n;
-            int32_t l = valid ? lab[i] : -1;
-            if (valid && (l < 0 || l > nlab)) {
-                atomicOr(bad, 1u);
-                l = -1;
+        static_assert(TR % 4 == 0, "rows in batches of four");
+        for (int r4 = 0; r4 < TR; r4 += 4) {
+            int32_t lq[4];       // four rows' loads in flight
+            bool vq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (tr * TR + r4 + u) * g.W + col;
+                vq[u] = col < g.W && i < g.n;
+                lq[u] = vq[u] ? lab[i] : -1;
             }
-            if (__all(l <= 0)) {
-                bcnt += l == 0;
-                continue;
-            }
-            const bool ok = l >= 0;
-            const int len = run_length_from(l, lane, ok);
-            if (is_run_head(l, lane, ok) && ok) {
-                if (l == 0) bcnt += (unsigned long long)len;
-                else {
-                    const int h = table_slot<COUNT_TS>(keys, l);
-                    if (h >= 0) atomicAdd(&tcnt[h], (unsigned int)len);
-                    else atomicAdd(&counts[l], (unsigned long long)len);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int32_t l = lq[u];
+                if (vq[u] && (l < 0 || l > nlab)) {
+                    atomicOr(bad, 1u);
+                    l = -1;
+                }
+                if (__all(l <= 0)) {
+                    bcnt += l == 0;
+                    continue;
+                }
+                const bool ok = l >= 0;
+                const int len = run_length_from(l, lane, ok);
+                if (is_run_head(l, lane, ok) && ok) {
+                    if (l == 0) bcnt += (unsigned long long)len;
+                    else {
+                        const int h = table_slot<COUNT_TS>(keys, l);
+                        if (h >= 0) atomicAdd(&tcnt[h], (unsigned int)len);
+                        else atomicAdd(&counts[l], (unsigned long long)len);
+                    }
                 }
             }
         }

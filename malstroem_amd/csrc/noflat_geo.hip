@@ -574,29 +574,35 @@ __device__ __forceinline__ void round_body(const GeoArgs &a)
 __global__ __launch_bounds__(256, 2) void ng_first_kernel(GeoArgs a) { round_body<true>(a); }
 __global__ __launch_bounds__(256, 2) void ng_round_kernel(GeoArgs a) { round_body<false>(a); }
 
-// ---- the marks of one round -> the tile list of the next (one workgroup; clears the marks) ------------------------------------
-// The mark bytes are read as 64-bit words (the array is padded to a multiple of 8 bytes); the order of the list is irrelevant,
-// so a slot range comes from one LDS atomic per thread that found something.
-__global__ __launch_bounds__(1024) void ng_compact_kernel(unsigned long long *mark8, int nwords, int *list, uint32_t *count)
+// ---- the marks of one round -> the tile list of the next (clears the marks) --------------------------------------------------
+// The mark bytes are read as 64-bit words (the array is padded to a multiple of 8 bytes), one word per thread; the order of the
+// list is irrelevant: a workgroup counts its tiles in LDS and takes its range of the list with one global atomic on the round's
+// counter (zero before: a round's counter is written by nobody else in mark mode).  One workgroup over the whole array took
+// 45 us when most tiles were marked (the first rounds) and 10 us when few were.
+__global__ __launch_bounds__(256) void ng_compact_kernel(unsigned long long *mark8, int nwords, int *list, uint32_t *count)
 {
-    __shared__ uint32_t n_l;
+    __shared__ uint32_t n_l, base_l;
     if (threadIdx.x == 0) n_l = 0;
     __syncthreads();
-    for (int w = threadIdx.x; w < nwords; w += 1024) {
-        const unsigned long long v = mark8[w];
-        if (v) {
-            mark8[w] = 0;
-            unsigned k = 0;
+    const int w = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const unsigned long long v = w < nwords ? mark8[w] : 0ull;
+    unsigned k = 0;
+    uint32_t o = 0;
+    if (v) {
+        mark8[w] = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) k += ((v >> (8 * j)) & 0xffull) ? 1u : 0u;
-            uint32_t o = atomicAdd(&n_l, k);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if ((v >> (8 * j)) & 0xffull) list[o++] = 8 * w + j;
-        }
+        for (int j = 0; j < 8; ++j) k += ((v >> (8 * j)) & 0xffull) ? 1u : 0u;
+        o = atomicAdd(&n_l, k);
     }
     __syncthreads();
-    if (threadIdx.x == 0) *count = n_l;
+    if (threadIdx.x == 0) base_l = n_l ? atomicAdd(count, n_l) : 0u;
+    __syncthreads();
+    if (v) {
+        o += base_l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((v >> (8 * j)) & 0xffull) list[o++] = 8 * w + j;
+    }
 }
 
 // ---- G = F + u * D -------------------------------------------------------------------------------------------------------
@@ -800,8 +806,8 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
         }
         // the marks of the last mark-mode round become the list of this one
         if (!m.light || m.round == m.light_from)
-            hipLaunchKernelGGL(ng_compact_kernel, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(m.d_mark), (int)((m.nt + 7) / 8),
-                               m.d_list, m.d_any + m.round);
+            hipLaunchKernelGGL(ng_compact_kernel, dim3((unsigned)(((m.nt + 7) / 8 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<unsigned long long *>(m.d_mark),
+                               (int)((m.nt + 7) / 8), m.d_list, m.d_any + m.round);
         if (m.light) {
             const bool odd = ((m.round - m.light_from) & 1) != 0;
             a.append = 1;

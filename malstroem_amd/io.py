@@ -12,13 +12,20 @@ Format: GeoTIFF, single band, classic or BigTIFF, little or big endian, strips o
 (``tiled=yes, compress=deflate, bigtiff=if_safer, predictor=2``, io.py:112,129-139), which is also what the writer here
 produces.  GDAL itself is not needed (and not present in this image).  The CRS travels as the raw GeoKey tags of the file it
 was read from; WKT strings cannot be translated without GDAL and are refused by the writer.
+
+Vector side: ``VectorWriter`` / ``VectorReader`` keep the constructor and the ``write_geojson_features`` /
+``read_geojson_features`` methods of the reference (io.py:160-330) but know ONE format, a GeoJSON FeatureCollection per layer
+(``<datasource>/<layername>.geojson``) -- what the tools hand to each other between the stages of ``complete``.  OGR formats
+stay with the reference's own classes, which the tools accept just as well.
 """
+import json
+import os
 import struct
 import zlib
 
 import numpy as np
 
-__all__ = ["RasterReader", "RasterWriter", "GeoKeys"]
+__all__ = ["RasterReader", "RasterWriter", "GeoKeys", "VectorReader", "VectorWriter"]
 
 _TYPE_FMT = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 7: "B", 8: "h", 9: "i", 10: "ii", 11: "f", 12: "d", 16: "Q", 17: "q", 18: "Q"}
 _TAG_WIDTH, _TAG_HEIGHT, _TAG_BITS, _TAG_COMPRESSION, _TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
@@ -345,3 +352,71 @@ class RasterWriter(object):
             fh.write(struct.pack("<I", ifd))
         fh.close()
         self._fh = None
+
+
+def _layer_path(datasource, layername):
+    if datasource.lower().endswith((".geojson", ".json")):
+        return datasource
+    return os.path.join(datasource, "%s.geojson" % layername)
+
+
+class VectorWriter(object):
+    """Features of one layer as a GeoJSON FeatureCollection file.  Constructor and ``write_geojson_features`` as in the
+    reference (io.py:160-296); ``driver`` must be 'GeoJSON' (or None), ``fields`` / ``geomtype`` / ``dsco`` / ``lco`` are
+    kept as attributes and otherwise unused.  ``datasource`` is a directory (created on first write) or a ``.geojson`` path."""
+
+    def __init__(self, driver, datasource, layername, fields, geomtype, crs, dsco=(), lco=()):
+        if driver not in (None, "GeoJSON", "geojson"):
+            raise NotImplementedError("malstroem_amd.io.VectorWriter writes GeoJSON only (OGR driver %r needs GDAL)" % (driver,))
+        self.driver = "GeoJSON"
+        self.datasource = datasource
+        self.layername = layername
+        self.fields = list(fields) if fields else []
+        self.geomtype = geomtype
+        self.crs = crs
+        self.dsco = list(dsco)
+        self.lco = list(lco)
+
+    @property
+    def filepath(self):
+        return _layer_path(self.datasource, self.layername)
+
+    def write_geojson_features(self, geojsonfeatures):
+        """A sequence of GeoJSON features or a FeatureCollection dict (io.py:251-277)."""
+        if not isinstance(geojsonfeatures, dict) or geojsonfeatures.get('type', None) == 'Feature':
+            geojsonfeatures = dict(type="FeatureCollection", features=list(geojsonfeatures))
+        feats = []
+        for f in geojsonfeatures["features"]:
+            g = dict(type="Feature", geometry=f.get("geometry"), properties=f.get("properties", {}))
+            if "id" in f:
+                g["id"] = f["id"]
+            feats.append(g)
+        path = self.filepath
+        d = os.path.dirname(path)
+        if d and not os.path.isdir(d):
+            os.makedirs(d)
+        with open(path, "w") as fh:
+            json.dump(dict(type="FeatureCollection", name=self.layername, features=feats), fh, default=_json_scalar)
+
+    def close(self):
+        pass
+
+
+def _json_scalar(o):
+    if isinstance(o, np.generic):
+        return o.item()
+    if isinstance(o, np.ndarray):
+        return o.tolist()
+    raise TypeError("%r is not JSON serializable" % type(o))
+
+
+class VectorReader(object):
+    """Reads the features a ``VectorWriter`` wrote (reference io.py:299-330: ``read_geojson_features``)."""
+
+    def __init__(self, datasource, layername=None):
+        self.datasource = datasource
+        self.layername = layername
+
+    def read_geojson_features(self):
+        with open(_layer_path(self.datasource, self.layername)) as fh:
+            return json.load(fh)["features"]

@@ -2,11 +2,12 @@
 
   * 16384 x 65536 (1.07 G cells, the band size of the 65536^2 run on 4 GPUs): the undivided chain on one context against
     the same raster cut into 4 bands (one band context each, threads over ThreadComm) -- bit for bit, raster by raster.
-  * 36864 x 65536 (2.42 G cells > 2**31: no single context can hold it, int32 cell indices) as 4 bands: size-independent
+  * 65536 x 65536 (4.29 G cells > 2**31: no single context can hold it, int32 cell indices; BASELINE configs[3] at FULL size,
+    the raster of `bench.py --gpus N`) as 4 bands of 16384 rows sharing the one GPU (91 % of its 288 GB): size-independent
     properties across the band seams -- the fill / no-flats fixed-point equations, D8, the accumulation balance, label
     numbering in scipy order across bands (new labels appear as running maximum + 1), watersheds following the flow, and
     pour-point records with GLOBAL rows that point at cells of their own bluespot holding the reported value.
-The DEM is bench.py's two-octave 65536-wide surface (top rows of it).  These two tests move ~100 GB between host and device
+The DEM is bench.py's two-octave 65536-wide surface (top rows of it).  These two tests move ~150 GB between host and device
 and take a few minutes; everything else about bands is covered at small sizes in test_gpu_bands.py.
 """
 import sys
@@ -81,8 +82,8 @@ def test_16384x65536_undivided_equals_four_bands(source):
                 p.close()
 
 
-def test_36864x65536_bands_beyond_the_int32_cell_domain(source):
-    H, nb = 36864, 4
+def test_65536x65536_as_four_bands_on_one_gpu(source):
+    H, nb = 65536, 4
     assert H * W > 2 ** 31
 
     def work(p, comm, rec):

@@ -28,6 +28,11 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 const char *get_error() { return g_err; }
+const char *dev_env(const char *name)
+{
+    static const bool on = [] { const char *e = getenv("MHIP_DEVELOPER"); return e && e[0] == '1'; }();
+    return on ? getenv(name) : nullptr;
+}
 
 // ---- caching device allocator -------------------------------------------------------------------
 // Freed blocks are kept per (device, rounded size) and handed out again; callers only release a block after
@@ -446,6 +451,7 @@ struct mhip_ctx {
     FillRun *run[2] = {nullptr, nullptr};   // resumable fill (plain, no-flats) in band mode
     GeoRun *geo = nullptr;                  // ... and the geodesic no-flats fill
     PfRun *pf = nullptr;                    // ... and the tiled priority-flood (plain fill)
+    bool pf_done = false;                   // the flood's raster is written and proven (mhip_ctx_fill_certify); run[0] may follow it
     DevBuf nodir_cnt;                       // interior NODIR cells of FLOWDIR, counted by the D8 kernel (the watersheds' fast-path test)
     bool nodir_valid = false;
     int device = 0, rank = 0, nranks = 1;
@@ -1030,9 +1036,10 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
     MH_TRY(ctx_raster(c, which));
     if (kind == 0) {
         // the tiled priority-flood first: the band's whole local solve happens here, the loop that follows only trades edge rows
-        static const bool force_iter = [] { const char *e = getenv("MHIP_FILL"); return e && std::string(e) == "iterative"; }();
+        const bool force_iter = [] { const char *e = dev_env("MHIP_FILL"); return e && std::string(e) == "iterative"; }();   // (development: engine selection for A/B runs and tests)
         delete c->pf;
         c->pf = nullptr;
+        c->pf_done = false;
         if (!force_iter) {
             PfRun *p = new PfRun();
             p->dem = c->r[MHIP_R_DEM].as<float>();
@@ -1110,10 +1117,27 @@ int mhip_ctx_noflat_verify(mhip_ctx *c, int32_t *ok)
     return MHIP_OK;
 }
 
+// the plain fill of a band continues on the iterative schedule from the surface it has (an upper bound of the result)
+static int ctx_attach_iterative_fill(mhip_ctx *c)
+{
+    FillRun *f = c->run[0] = new FillRun();
+    f->noflat = false;
+    f->dem = c->r[MHIP_R_DEM].as<float>();
+    f->out = c->r[MHIP_R_FILLED].p;
+    f->H = c->H; f->W = c->W;
+    f->fixed_top = c->ht; f->fixed_bot = c->hb;
+    f->rounds_per_batch = 16;
+    return f->attach(c->stream);
+}
+
 int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
 {
-    MH_ARG(c && active && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_batch needs ctx_fill_begin");
+    MH_ARG(c && active && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && (c->pf || c->pf_done))), "ctx_fill_batch needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
+    if (kind == 0 && !c->pf && !c->run[0]) {   // flood finished and proven: nothing to do
+        *active = 0;
+        return MHIP_OK;
+    }
     if (kind == 0 && c->pf) {
         const int rc = c->pf->batch(c->stream);
         *active = 0;
@@ -1142,9 +1166,28 @@ int mhip_ctx_fill_batch(mhip_ctx *c, int kind, int32_t *active)
 
 int mhip_ctx_fill_certify(mhip_ctx *c, int kind, int32_t *changed)
 {
-    MH_ARG(c && changed && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_certify needs ctx_fill_begin");
+    MH_ARG(c && changed && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && (c->pf || c->pf_done))), "ctx_fill_certify needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
-    if (kind == 0 && c->pf) {   // nothing to certify: the flood is not a worklist schedule
+    if (kind == 0 && c->pf) {
+        // The flood is quiescent on every band (the caller voted): write the raster and prove it (check.hip) -- K3 is a worklist
+        // schedule too.  A band whose surface fails the proof continues with the iterative schedule from that surface (an upper
+        // bound of the result); its neighbours follow when their halo rows move (mhip_ctx_fill_halo_changed below).
+        bool violated = false;
+        FillStats st;
+        MH_TRY(c->pf->finish(c->stream, nullptr, &st, &violated));
+        delete c->pf;
+        c->pf = nullptr;
+        c->fill_st = st;
+        c->fill_rounds = st.rounds;
+        c->pf_done = true;
+        *changed = 0;
+        if (violated) {
+            MH_TRY(ctx_attach_iterative_fill(c));
+            *changed = 1;
+        }
+        return MHIP_OK;
+    }
+    if (kind == 0 && c->pf_done && !c->run[0]) {   // proven, and nothing has touched the halo rows since
         *changed = 0;
         return MHIP_OK;
     }
@@ -1156,26 +1199,36 @@ int mhip_ctx_fill_certify(mhip_ctx *c, int kind, int32_t *changed)
 
 int mhip_ctx_fill_halo_changed(mhip_ctx *c, int kind, int side)
 {
-    MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)) && (side == 0 || side == 1), "ctx_fill_halo_changed needs ctx_fill_begin");
+    MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && (c->pf || c->pf_done))) && (side == 0 || side == 1), "ctx_fill_halo_changed needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
     if (kind == 0 && c->pf) return c->pf->halo_changed(side, c->stream);
+    // a neighbour repaired its surface after this band's flood was finished: follow on the iterative schedule
+    if (kind == 0 && !c->run[0]) MH_TRY(ctx_attach_iterative_fill(c));
     return c->run[kind]->activate_row(side, c->stream);
 }
 
 int mhip_ctx_fill_end(mhip_ctx *c, int kind)
 {
-    MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && c->pf)), "ctx_fill_end needs ctx_fill_begin");
+    MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && (c->pf || c->pf_done))), "ctx_fill_end needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
     FillStats st;
-    if (kind == 0 && c->pf) {
+    if (kind == 0 && c->pf) {          // (a caller that skipped the certification: no proof either)
         MH_TRY(c->pf->finish(c->stream, nullptr, &st));
         delete c->pf;
         c->pf = nullptr;
+    } else if (kind == 0 && !c->run[0]) {
+        st = c->fill_st;               // finished and proven by mhip_ctx_fill_certify
     } else {
         MH_TRY(c->run[kind]->finish(c->stream, &st));
         delete c->run[kind];
         c->run[kind] = nullptr;
+        if (kind == 0 && c->pf_done) {   // flood + repair
+            st.rounds += c->fill_st.rounds;
+            st.visits += c->fill_st.visits;
+            st.algorithm = 4;
+        }
     }
+    if (kind == 0) c->pf_done = false;
     if (kind) { c->noflat_rounds = st.rounds; c->noflat_st = st; c->have[MHIP_R_NOFLAT] = true; }
     else {
         c->fill_rounds = st.rounds; c->fill_st = st; c->have[MHIP_R_FILLED] = true;
@@ -1469,7 +1522,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_ARG((mask & ~(MHIP_STAGE_FLOWDIR | MHIP_STAGE_ACCUM)) == 0,
                "this stage runs through the band entry points on a row band (mhip_ctx_fill_*, mhip_ctx_band_*)");
     }
-    static const bool serial_env = [] { const char *e = getenv("MHIP_SERIAL"); return e && e[0] == '1'; }();
+    static const bool serial_env = [] { const char *e = dev_env("MHIP_SERIAL"); return e && e[0] == '1'; }();
     const int side_a = mask & (MHIP_STAGE_NOFLAT | MHIP_STAGE_FLOWDIR | MHIP_STAGE_ACCUM);
     const int side_b = mask & (MHIP_STAGE_LABEL | MHIP_STAGE_WATERSHED);
     const bool overlap = side_a && side_b && !serial_env;
@@ -1586,7 +1639,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     const int rc_e = shdg_fut.get();
     if (rc_a == MHIP_OK) rc_a = [&]() -> int {
         MH_TRY(rc_e);
-        static const int label_start = [] { const char *e = getenv("MHIP_LABEL_START"); return e ? atoi(e) : 2; }();   // 0: with the no-flats fill, 1: at its tail, 2: after it
+        static const int label_start = [] { const char *e = dev_env("MHIP_LABEL_START"); return e ? atoi(e) : 2; }();   // 0: with the no-flats fill, 1: at its tail, 2: after it
         if (label_start == 0) tail_hook.fire(s);
         if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, /*shdg_done=*/true, label_start == 1 ? &tail_hook : nullptr));
         if (mask & MHIP_STAGE_FLOWDIR) {

@@ -422,7 +422,7 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
     MH_TRY(counts.alloc(sizeof(uint32_t) * (size_t)nb));
     MH_TRY(total.alloc(sizeof(unsigned long long)));
     int32_t *parent = d_tmp;
-    static const bool global_uf = [] { const char *e = getenv("MHIP_CCL"); return e && std::string(e) == "global"; }();
+    static const bool global_uf = [] { const char *e = dev_env("MHIP_CCL"); return e && std::string(e) == "global"; }();
     if (global_uf) {   // the round-1 schedule: every union and every flatten / rank step over all cells through global memory
         hipLaunchKernelGGL((ccl_init_kernel<T>), dim3(g256), dim3(256), 0, s, d_data, parent, n, W);
         hipLaunchKernelGGL(ccl_merge_kernel, dim3(g256), dim3(256), 0, s, parent, H, W);

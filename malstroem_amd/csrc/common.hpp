@@ -13,6 +13,9 @@ namespace mh {
 // ---- error plumbing --------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 const char *get_error();
+// Development knobs and test hooks (engine selection for A/B runs, debug prints, fault injection for the liveness tests of the
+// run-time checks) are read ONLY when MHIP_DEVELOPER=1 is set: a stray variable in a user's environment never steers the product.
+const char *dev_env(const char *name);
 
 #define MH_HIP(expr)                                                                             \
     do {                                                                                         \
@@ -141,8 +144,11 @@ struct FillRun {
 void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_t ncells_global);
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st, float *d_depths = nullptr,
                    bool *depths_done = nullptr);
+// check.hip: *d_flag (zeroed by the caller) = 1 when `filled` is not a fixed point of the plain fill with border == dem
+int fill_check_f32_dev(const float *d_dem, const float *d_filled, int64_t H, int64_t W, int fixed_top, int fixed_bot, hipStream_t s,
+                       unsigned int *d_flag);
 // pflood.hip
-int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st);
+int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st, bool *violated = nullptr);
 // pflood.hip: the exact tiled priority-flood, resumable for row bands (whose halo rows of `out` carry the neighbours' current
 // estimates of their filled edge rows; this band's own edge rows in `out` are kept current for them)
 struct PfRun {
@@ -159,7 +165,9 @@ struct PfRun {
     int begin(hipStream_t s);                     // MHIP_ELIMIT: not applicable (capacity, band alignment): run the iterative schedule
     int halo_changed(int side, hipStream_t s);
     int batch(hipStream_t s);                     // MHIP_ELIMIT as above
-    int finish(hipStream_t s, float *d_depths, FillStats *st);
+    // writes the raster, then proves it (check.hip); *violated: the surface is not the fixed point (it still is an upper bound of
+    // it): the caller lets the iterative schedule finish the job (FillRun::attach + certify)
+    int finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated = nullptr);
     int solve(hipStream_t s);
     int pack(hipStream_t s, int row0, int nrows);
     int publish_edges(hipStream_t s);

@@ -563,7 +563,12 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
         // Lane k (k < 9) owns neighbour tile k, so the returning atomics of all directions are in flight together.
         // topN/botN: halo-row cells (bit = column 0..63) that would drop; leftT/rightT: halo-column cells (bit = row).
         // Bits 1..62 belong to the edge neighbour, bits 0 / 63 are the corner cells of the diagonal neighbours.
-        // A neighbour tile inside my own macro tile is a sibling: it has seen my edges unless the exchange was capped.
+        // A neighbour tile inside my own macro tile is a sibling.  Its probe bit counts like any other neighbour's: a sibling has seen
+        // my EDGE cells unless the exchange was capped, but my corner cell reaches the DIAGONAL sibling only through the halo lanes
+        // of the two edge siblings, one iteration later -- and the loop ends after ONE quiet iteration.  (Until round 3 a
+        // sibling was re-queued only when capped: a corner that dropped in iteration 0 of a visit whose iteration 1 was quiet
+        // never reached the diagonal sibling's corner cell -- the one cell of 1.07 G of DESIGN 4.2; tools/fill_protocol_model.py
+        // reproduces it.)
         const uint64_t INNER = ((1ull << TI) - 1) << 1, C0 = 1ull, C63 = 1ull << (WN - 1);
         const bool top = (topN & INNER) != 0, bot = (botN & INNER) != 0, left = (leftT & INNER) != 0, right = (rightT & INNER) != 0;
         const bool tl = ((topN | leftT) & C0) != 0, tr = (topN & C63) || (rightT & C0);
@@ -574,7 +579,7 @@ __device__ __forceinline__ void visit_macro(const RoundArgs &a, const float *__r
             const int p = ti + lane / 3 - 1, q = tj + lane % 3 - 1;
             if (p >= 0 && p < ntr && q >= 0 && q < ntc) {
                 const int t = MACRO ? (p >> 1) * a.mtc + (q >> 1) : p * ntc + q, sh = t % NSHARD;
-                const bool want = t == macro ? capped : ((bits >> lane) & 1u) != 0;
+                const bool want = (((bits >> lane) & 1u) != 0) | (t == macro && capped);
                 // the mark word carries one bit per tile of the macro tile: which of them has a reason to run
                 if (want && atomicOr(&a.mark_nxt[t], MACRO ? 1u << ((p & 1) * 2 + (q & 1)) : 1u) == 0u)
                     a.list_nxt[(size_t)sh * a.shard_cap + atomicAdd(&a.count_nxt[sh], 1u)] = t;
@@ -1022,7 +1027,9 @@ static int fill_run_to_convergence(FillRun &f, hipStream_t s, FillStats *st)
     bool active = false;
     MH_TRY(f.begin(s, &active));
     while (active) MH_TRY(f.batch(s, &active));
-    for (bool changed = true; changed;) MH_TRY(f.certify(s, &changed));   // until a full sweep changes nothing
+    // until a full sweep changes nothing.  (MHIP_FILL_NOCERTIFY, development: the raw schedule, for the tests that pin its protocol)
+    if (!dev_env("MHIP_FILL_NOCERTIFY"))
+        for (bool changed = true; changed;) MH_TRY(f.certify(s, &changed));
     return f.finish(s, st);
 }
 
@@ -1033,14 +1040,34 @@ static int fill_run_to_convergence(FillRun &f, hipStream_t s, FillStats *st)
 // the iterative path leaves it to the caller.
 int fill_plain_dev(const float *d_dem, float *d_out, int64_t H, int64_t W, hipStream_t s, FillStats *st, float *d_depths, bool *depths_done)
 {
-    static const bool force_iter = [] { const char *e = getenv("MHIP_FILL"); return e && std::string(e) == "iterative"; }();
+    const bool force_iter = [] { const char *e = dev_env("MHIP_FILL"); return e && std::string(e) == "iterative"; }();   // (development: engine selection for A/B runs and tests)
     if (depths_done) *depths_done = false;
     if (!force_iter && H >= 3 && W >= 3) {
-        const int rc = fill_plain_pflood_dev(d_dem, d_out, d_depths, H, W, s, st);
-        if (rc == MHIP_OK) {
+        bool violated = false;
+        const int rc = fill_plain_pflood_dev(d_dem, d_out, d_depths, H, W, s, st, &violated);
+        if (rc == MHIP_OK && !violated) {
             if (depths_done) *depths_done = d_depths != nullptr;
             if (st) st->algorithm = 1;
             return MHIP_OK;
+        }
+        if (rc == MHIP_OK) {
+            // the flood's surface failed its proof (check.hip): it is an upper bound of the result all the same, so the iterative
+            // schedule starts from it -- certify() queues the tiles that can still move -- instead of from +inf
+            FillStats st_flood = st ? *st : FillStats();
+            FillRun h;
+            h.noflat = false; h.dem = d_dem; h.out = d_out; h.H = H; h.W = W;
+            MH_TRY(h.attach(s));
+            for (bool changed = true; changed;) MH_TRY(h.certify(s, &changed));
+            FillStats st_rel;
+            MH_TRY(h.finish(s, &st_rel));
+            if (st) {
+                *st = st_flood;
+                st->algorithm = 4;     // flood + repair
+                st->rounds += st_rel.rounds;
+                st->visits += st_rel.visits;
+                st->cycles += st_rel.cycles;
+            }
+            return MHIP_OK;         // (the depths are left to the caller: *depths_done stays false)
         }
         if (rc != MHIP_ELIMIT) return rc;
     }
@@ -1091,7 +1118,7 @@ int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, dou
         MH_TRY(h.finish(s, &st_rel));
         bool ok = false;
         MH_TRY(noflat_verify_dev(d_dem, d_out, H, W, sh, dg, s, &ok));
-        if (getenv("MHIP_NG_DEBUG"))
+        if (dev_env("MHIP_NG_DEBUG"))
             fprintf(stderr, "[noflat hybrid] relaxation: %d certification sweeps, %d rounds, %lld visits; verified: %d\n", sweeps, st_rel.rounds,
                     (long long)st_rel.visits, (int)ok);
         if (ok) {

@@ -827,9 +827,9 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
 int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
 {
     Impl &m = *impl;
-    static const bool off = [] { const char *e = getenv("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
-    m.debug = getenv("MHIP_NG_DEBUG") != nullptr;
-    if (getenv("MHIP_NG_MAXCYC")) m.maxcyc = atoi(getenv("MHIP_NG_MAXCYC"));        // tuning knob (development)
+    static const bool off = [] { const char *e = dev_env("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
+    m.debug = dev_env("MHIP_NG_DEBUG") != nullptr;
+    if (dev_env("MHIP_NG_MAXCYC")) m.maxcyc = atoi(dev_env("MHIP_NG_MAXCYC"));        // tuning knob (development)
     *applicable = false;
     *active = false;
     if (off || !filled || H < 3 || W < 3) return MHIP_OK;
@@ -907,9 +907,9 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
 int GeoRun::batch(hipStream_t s, bool *active)
 {
     Impl &m = *impl;
-    static const bool no_light = getenv("MHIP_NG_NOLIGHT") != nullptr;   // development knob
+    static const bool no_light = dev_env("MHIP_NG_NOLIGHT") != nullptr;   // development knob
     // rounds per host read-back; MHIP_NG_BATCH (tests): a small batch makes small rasters reach the self-listing tail rounds too
-    const char *eb = getenv("MHIP_NG_BATCH");
+    const char *eb = dev_env("MHIP_NG_BATCH");
     const int nb = eb && atoi(eb) >= 1 && atoi(eb) <= BATCH ? atoi(eb) : BATCH;
     for (;;) {
         if (m.round + BATCH > MAXR) {
@@ -950,7 +950,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     Impl &m = *impl;
     const int64_t n = H * W;
     partial = m.irregular != 0 && allow_partial;
-    if (getenv("MHIP_NG_CORRUPT") && W > 8)   // test hook (tests/test_gpu_noflat_geodesic.py): wrong distances in the middle row -- the check
+    if (dev_env("MHIP_NG_CORRUPT") && W > 8)   // test hook (tests/test_gpu_noflat_geodesic.py): wrong distances in the middle row -- the check
         MH_HIP(hipMemsetAsync(dist + (H / 2) * W + 1, 0x01, 4 * (size_t)(W - 2), s));   // below has to catch them and send the raster to the relaxation
     if (!partial)
         hipLaunchKernelGGL(ng_finish_kernel, dim3((unsigned)((W + 4 * TI - 1) / (4 * TI)), (unsigned)((H + FRB - 1) / FRB)), dim3(256), 0, s, filled, dist, dem,

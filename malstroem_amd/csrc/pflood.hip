@@ -1129,7 +1129,7 @@ int PfRun::solve(hipStream_t s)
         MH_HIP(hipMemcpyAsync(&h_flag, m.a.flags, 4, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
         if (h_flag) return MHIP_ELIMIT;
-        if (getenv("MHIP_PF_DEBUG")) {
+        if (dev_env("MHIP_PF_DEBUG")) {
             fprintf(stderr, "[pf_solve] rounds %d..%d appended work:", m.round, m.round + PF_BATCH - 1);
             for (int k = 0; k < PF_BATCH; ++k) fprintf(stderr, " %u", h_cnt[k]);
             fprintf(stderr, "\n");
@@ -1288,7 +1288,7 @@ int PfRun::batch(hipStream_t s)
 }
 
 // the final level of every basin, then the raster (a band's halo rows stay as the neighbour left them)
-int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st)
+int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
 {
     Impl &m = *impl;
     hipLaunchKernelGGL(pf_final_kernel, dim3((unsigned)m.ntiles), dim3(256), 0, s, m.a);
@@ -1296,6 +1296,17 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st)
     hipLaunchKernelGGL(pf_apply_kernel, dim3((unsigned)cdiv(groups, 256)), dim3(256), 0, s, m.a, out, d_depths);
     MH_HIP(hipGetLastError());
     m.launches += 2;
+    // The run-time proof (check.hip): K3 is a worklist schedule (marks + list appends wake neighbouring blocks); a wake lost there, or
+    // a fault in any of K1..K4, leaves a surface that is not a fixed point.  One streaming pass over dem + filled (8 B per cell).
+    unsigned int h_viol = 0;
+    if (violated) {
+        const bool poke = dev_env("MHIP_PF_CORRUPT") != nullptr;    // test hook: one interior cell raised after the flood
+        if (poke && H > 8 && W > 8) hipLaunchKernelGGL(pf_fill_f32_kernel, dim3(1), dim3(1), 0, s, out + (H / 2) * W + W / 2, (int64_t)1, 3.0e38f);
+        MH_HIP(hipMemsetAsync(m.a.flags + 1, 0, 4, s));
+        MH_TRY(fill_check_f32_dev(dem, out, H, W, fixed_top, fixed_bot, s, m.a.flags + 1));
+        MH_HIP(hipMemcpyAsync(&h_viol, m.a.flags + 1, 4, hipMemcpyDeviceToHost, s));
+        m.launches += 1;
+    }
 #ifdef PF_PROFILE
     {
         unsigned long long h_prof[24];
@@ -1333,6 +1344,7 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st)
     } else {
         MH_HIP(hipStreamSynchronize(s));   // the workspace goes back to the pool now
     }
+    if (violated) *violated = h_viol != 0;
     m.ws.release();
     return MHIP_OK;
 }
@@ -1340,12 +1352,12 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st)
 
 // Exact tiled priority-flood on one raster.  Returns MHIP_ELIMIT (without touching d_out) when a per-tile capacity was
 // exceeded: the caller then runs the iterative schedule.
-int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st)
+int fill_plain_pflood_dev(const float *d_dem, float *d_out, float *d_depths, int64_t H, int64_t W, hipStream_t s, FillStats *st, bool *violated)
 {
     PfRun f;
     f.dem = d_dem; f.out = d_out; f.H = H; f.W = W;
     MH_TRY(f.begin(s));
-    return f.finish(s, d_depths, st);
+    return f.finish(s, d_depths, st, violated);
 }
 
 }  // namespace mh

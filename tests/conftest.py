@@ -4,6 +4,9 @@ from pathlib import Path
 
 import pytest
 
+# development knobs / fault-injection hooks of the library are only read when this is set (csrc/common.hpp: dev_env)
+os.environ.setdefault("MHIP_DEVELOPER", "1")
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

@@ -262,3 +262,15 @@ def test_rccl_inside_the_library_single_rank():
     lab, nref = oracle.connected_components(oracle.depths(filled, dem))
     assert n == nref and np.array_equal(got["labels"], lab)
     assert out["pour"] is not None
+
+
+@pytest.mark.parametrize("nbands,h,w", [(2, 700, 450), (3, 640, 390)])
+def test_band_flood_is_proven_and_repaired_across_bands(monkeypatch, nbands, h, w):
+    """The flood of every band is proven when the bands are quiescent (mhip_ctx_fill_certify: check.hip).  MHIP_PF_CORRUPT raises one
+    cell in the middle of every band afterwards: each band has to notice, continue on the iterative schedule from its surface
+    (fill_algorithm 4), trade edge rows again until everything is quiet -- and the chain still matches the oracle bit for bit."""
+    monkeypatch.setenv("MHIP_PF_CORRUPT", "1")
+    dem = fbm(h, w, beta=2.0, seed=31)
+    out = run_bands(dem, nbands)
+    check_bands_against_oracle(dem, out)
+    assert all(o["engines"][0] == 4 for o in out), [o["engines"] for o in out]

@@ -255,3 +255,23 @@ def test_priority_flood_and_its_fallback_give_the_same_fill(alg):
         want = oracle.fill_terrain(dem)
         assert np.array_equal(got, want)
         assert np.array_equal(dep, oracle.depths(want, dem))
+
+
+def test_the_flood_proof_is_live(alg, monkeypatch):
+    """Every plain fill by the tiled priority-flood is proven at run time (check.hip: the reference's update evaluated at every
+    cell of the result).  MHIP_PF_CORRUPT raises one interior cell after the flood: the check has to see it, the iterative
+    schedule repairs the surface from there (fill_algorithm 4 = flood + repair) and the oracle's bits come out."""
+    from malstroem_amd.pipeline import HydroPipeline
+    dem = fbm(420, 380, beta=2.0, seed=21)
+    want = oracle.fill_terrain(dem)
+    for corrupt, algorithm in ((False, 1), (True, 4)):
+        if corrupt:
+            monkeypatch.setenv("MHIP_PF_CORRUPT", "1")
+        with HydroPipeline(dem.shape) as pipe:
+            pipe.upload("dem", dem)
+            pipe.run("fill")
+            pipe.sync()
+            assert pipe.get_int("fill_algorithm") == algorithm
+            assert np.array_equal(pipe.download("filled"), want)
+            assert np.array_equal(pipe.download("depths"), oracle.depths(want, dem))
+    assert np.array_equal(alg.fill.fill_terrain(dem), want)      # (stage function, hook still set)

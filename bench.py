@@ -184,7 +184,7 @@ class BandWorker(threading.Thread):
     def __init__(self, comm, shape, device, rccl, dem_rows_fn, gate):
         super(BandWorker, self).__init__(daemon=True)
         self.comm, self.shape, self.device, self.rccl, self.dem_rows_fn, self.gate = comm, shape, device, rccl, dem_rows_fn, gate
-        self.error, self.pipe, self.timings, self.stop = None, None, {}, False
+        self.error, self.pipe, self.timings, self.host_ms, self.stop = None, None, {}, {}, False
 
     def run(self):
         from malstroem_amd.distributed import BandPipeline
@@ -202,9 +202,12 @@ class BandWorker(threading.Thread):
             if self.error is None:
                 try:
                     tm = {}
-                    self.pipe.run_chain(records=True, fetch_own=False, overlap=os.environ.get("MALSTROEM_BAND_OVERLAP", "1") != "0", timings=tm)
+                    self.pipe.host_ms = {}
+                    self.pipe.run_chain(records=True, fetch_own=False, overlap=True, timings=tm)
                     for k, v in tm.items():
                         self.timings[k] = self.timings.get(k, 0.0) + v
+                    for k, v in self.pipe.host_ms.items():      # thread CPU time of the host-only sections (boundary systems)
+                        self.host_ms[k] = self.host_ms.get(k, 0.0) + v
                 except Exception as e:
                     traceback.print_exc()
                     self.error = e
@@ -262,7 +265,8 @@ def main():
         from malstroem_amd.distributed import HybridComm, SingleComm
         k = nbands // world
         proc_comm = TorchComm() if world > 1 else SingleComm()
-        rccl = k == 1 and world > 1 and world <= ndev and os.environ.get("MALSTROEM_BAND_TRANSPORT", "rccl") != "host"
+        host_rows_asked = os.environ.get("MALSTROEM_BAND_TRANSPORT", "rccl") == "host"     # explicit override: rows through the host communicator
+        rccl = k == 1 and world > 1 and world <= ndev and not host_rows_asked
         comms = [proc_comm] if k == 1 else HybridComm.world(proc_comm, k)
         gate = threading.Barrier(k + 1)
         workers = [BandWorker(c, (n, n), device, rccl, src.rows, gate) for c in comms]
@@ -270,6 +274,15 @@ def main():
             w.start()
         gate.wait()
         used_rccl = bool(workers[0].pipe is not None and workers[0].pipe.rccl)
+        rccl_ranks = world if used_rccl else 0
+        if rccl and not used_rccl:
+            # one band per GPU and the rows are NOT on RCCL: what a scaling run would measure is the host communicator.  Refuse
+            # (MALSTROEM_BAND_TRANSPORT=host asks for that configuration explicitly and is reported as such).
+            if rank == 0:
+                print("bench.py: RCCL is not carrying the band rows (%s); set MALSTROEM_BAND_TRANSPORT=host to measure the host path on purpose"
+                      % (workers[0].pipe.rccl_error if workers[0].pipe is not None else "band setup failed"), file=sys.stderr)
+            for w in workers:
+                w.error = w.error or RuntimeError("RCCL transport unavailable")
         rccl_note = ""
         if rccl and not used_rccl and workers[0].pipe is not None:
             rccl_note = " (RCCL setup failed: %s)" % workers[0].pipe.rccl_error
@@ -329,7 +342,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     for w in workers:
-        w.timings = {}
+        w.timings, w.host_ms = {}, {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -351,7 +364,16 @@ def main():
     if band_mode:
         for s in stage_names:
             stage_ms[s] = max(w.timings.get(s, 0.0) for w in workers) / args.steps   # host wall clock per stage, slowest band of this rank
-        info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands}
+        host_serial = {}
+        for w in workers:
+            for k2, v in w.host_ms.items():
+                host_serial[k2] = max(host_serial.get(k2, 0.0), v / args.steps)
+        info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands,
+                "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side),
+                # thread CPU time per step of the host-only sections of the boundary systems (label / accumulation / watershed
+                # seams), maximum over the bands of rank 0: what does not shrink with the number of GPUs
+                "host_serial_ms": {k2: round(v, 2) for k2, v in sorted(host_serial.items())},
+                "host_serial_ms_total": round(sum(host_serial.values()), 2)}
     else:
         for s in stage_names:
             stage_ms[s] /= args.steps
@@ -389,7 +411,7 @@ def main():
         out = {
             "metric": ("Mcells/s fill->D8 on %d^2 f32 DEM" if config2 else "Mcells/s fill->D8->accum->label on %d^2 f32 DEM") % n,
             "value": round(value, 2), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if band_mode else "weak",
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if band_mode else "single",
             "vs_baseline": None,
             "dtype": "f32 fill / f64 no-flats+D8+accum / u8 flowdir / i32 labels", "data": "synthetic",
             "config": {"workload": "%dx%d float32 DEM (%s): %s" % (n, n, src.recipe, chain),

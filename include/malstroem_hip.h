@@ -140,6 +140,9 @@ int mhip_rain_events(int64_t n, const int64_t *down_index, const double *wshed_a
  *   chains are followed to their end, a cycle resolves to 0 (_flow.pyx:276-314 leaves such cells unassigned). */
 int mhip_band_forest_solve(int64_t n, const int64_t *parent, double *val);
 int mhip_band_ws_resolve(int64_t n, int64_t *vals);
+/* classes of an undirected graph (n nodes, m edges a[k] -- b[k]): cls[i] = smallest node of i's class (the label merge across
+ * band seams works on the seam pairs the bands publish) */
+int mhip_band_union_find(int64_t n, int64_t m, const int64_t *a, const int64_t *b, int64_t *cls);
 
 /* ---- device-resident pipeline (DemTool / BluespotTool sequences, reference dem.py:53-93,
  *      bluespots.py:138-216): one upload, all stages in HBM, downloads only for the writers. ------- */
@@ -172,13 +175,23 @@ int mhip_ctx_create(mhip_ctx **out, int64_t H, int64_t W, int device);
  * joins the communicator (ncclCommInitRank: a COLLECTIVE call over all nranks bands).  With nccl_unique_id == NULL the
  * context has no communicator and the launcher moves the edge rows itself (mhip_ctx_get_edge_row / _set_halo_row). */
 int mhip_comm_unique_id(void *id128);
+/* 1 when librccl and every symbol the band transport needs can be loaded (no device call, no collective): every rank votes on
+ * this BEFORE any rank enters mhip_ctx_create_band with an id -- ncclCommInitRank would wait for a rank that cannot join */
+int mhip_comm_available(void);
 int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t row0, int64_t H_local,
                          int device, int rank, int nranks, const void *nccl_unique_id);
-int mhip_ctx_has_comm(mhip_ctx *ctx);        /* 1 if the context owns an RCCL communicator */
+int mhip_ctx_has_comm(mhip_ctx *ctx);        /* 0: no RCCL communicator, 1: one, 2: also the side communicator */
+/* A second communicator over the same bands (ncclCommInitRank with another id from mhip_comm_unique_id: a COLLECTIVE call) for the
+ * thread between mhip_ctx_side_begin / _end: the labelling branch trades its seam rows over RCCL next to the main thread's halo
+ * exchanges, and two threads must not interleave operations on one communicator. */
+int mhip_ctx_comm_add_side(mhip_ctx *ctx, const void *nccl_unique_id);
 /* Neighbour exchange over RCCL (ncclGroupStart / ncclSend + ncclRecv per neighbour / ncclGroupEnd on the context's stream,
  * straight out of the raster's edge rows; band neighbours are xGMI peers): the rows that arrive are compared with and
  * stored into the halo rows on the device; changed[0] / changed[1] = the top / bottom halo row changed. */
 int mhip_ctx_exchange_halo(mhip_ctx *ctx, int which, int32_t *changed);
+/* the same exchange into host buffers (W elements each, NULL where there is no neighbour) without touching the halo rows: what the
+ * boundary systems of labelling / accumulation / watersheds need of a neighbour -- its edge row next to this band's own halo row */
+int mhip_ctx_exchange_edge_rows(mhip_ctx *ctx, int which, void *host_from_up, void *host_from_down);
 /* max over all bands of one value (ncclAllReduce): ends the fill / accumulation loops ("is anybody still active") */
 int mhip_ctx_allreduce_max(mhip_ctx *ctx, double value, double *out);
 int mhip_ctx_destroy(mhip_ctx *ctx);
@@ -241,6 +254,17 @@ int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int
 int mhip_ctx_band_relabel_sparse(mhip_ctx *ctx, int64_t nlocal, int64_t offset, const int32_t *dropped, const int32_t *target,
                                  int64_t ndropped, int64_t nlabels_global);
 /* watersheds on a band: local pointer jumping with pseudo labels on the halo rows, then a boundary LUT */
+/* the bluespot filter on a band (bluespots.py:165-172 as a rank relabel): labels in [lo, hi] (numbered by this band) -> lut[l - lo]
+ * (0 = dropped); a label another band numbered -> fnew[k] where fid[k] == l (fid sorted, unique); nlabels_new = the global count */
+int mhip_ctx_band_relabel_range(mhip_ctx *ctx, int64_t lo, int64_t hi, const int32_t *lut, const int32_t *fid, const int32_t *fnew, int64_t nf,
+                                int64_t nlabels_new);
+/* One leg of net.next_downstream_label (net.py:142-169) on a band.  cells_rc: GLOBAL (row, col) of n walkers standing on owned rows;
+ * src_label[i] >= 0: the walker's source label (it came from another band), -1 or src_label == NULL: its start cell's label.
+ * out_status: 0 ended without a label, 1 found out_label, 2 stepped onto a neighbour's row at out_exit_rc (GLOBAL row, col) -- the
+ * launcher hands it to that band.  Geometry (GLOBAL linear indices) in two passes: lengths, then offsets + out_cells. */
+int mhip_ctx_band_trace(mhip_ctx *ctx, const int64_t *cells_rc, const int32_t *src_label, int64_t n, int use_background, int32_t background,
+                        int32_t *out_label, int32_t *out_status, int32_t *out_src, int64_t *out_exit_rc, int64_t *out_len, const int64_t *offsets,
+                        int64_t *out_cells);
 int mhip_ctx_band_watershed_local(mhip_ctx *ctx);
 int mhip_ctx_band_apply_neg_lut(mhip_ctx *ctx, int which, const int32_t *lut, int64_t n);
 /* Two host threads per band (the labelling branch next to no-flats fill -> D8 -> accumulation, like the stage DAG of
@@ -251,7 +275,8 @@ int mhip_ctx_side_begin(mhip_ctx *ctx);
 int mhip_ctx_side_end(mhip_ctx *ctx);
 /* per-label records over the OWNED rows of the band, indexed by GLOBAL label (reference bluespots.py:159-206 on one
  * raster).  which: 0 = label_stats of the depths (mhip_stat_record), 1 = np.bincount of the watersheds (int64), 2 = first
- * arg-max of the accumulated flow (mhip_index_record, rows are global raster rows).  _records computes nlabels_global + 1
+ * arg-max of the accumulated flow (mhip_index_record, rows are global raster rows), 3 = first arg-min of the no-flats surface (the
+ * pour points when no accumulated flow was asked for, bluespots.py:203-205; shares the buffer of 2).  _records computes nlabels_global + 1
  * entries and keeps them on the device; the launcher fetches the slice of the labels this band numbered (_fetch), the few
  * labels that cross a band boundary (_gather) and the non-zero watershed counts of labels outside [lo, hi] (_foreign_counts:
  * up to cap pairs, *nfound = how many exist) and merges them across bands */

@@ -33,7 +33,7 @@ SYMBOLS = [
     "mhip_ccl8_f32", "mhip_ccl8_u8", "mhip_relabel_keep", "mhip_keep_mask", "mhip_label_stats_f32", "mhip_label_stats_f64",
     "mhip_label_argmin_f64", "mhip_label_argmax_f64", "mhip_label_count", "mhip_label_max", "mhip_watersheds_i32",
     "mhip_trace_downstream_i32", "mhip_ctx_trace_downstream", "mhip_rain_events", "mhip_band_forest_solve", "mhip_band_ws_resolve",
-    "mhip_ctx_create", "mhip_comm_unique_id", "mhip_ctx_create_band", "mhip_ctx_destroy", "mhip_ctx_upload_dem",
+    "mhip_ctx_create", "mhip_comm_unique_id", "mhip_comm_available", "mhip_ctx_create_band", "mhip_ctx_destroy", "mhip_ctx_upload_dem",
     "mhip_ctx_upload", "mhip_ctx_download", "mhip_ctx_upload_rows", "mhip_ctx_download_rows", "mhip_ctx_run", "mhip_ctx_sync", "mhip_ctx_stage_ms",
     "mhip_ctx_kernel_ms", "mhip_ctx_get_i64", "mhip_ctx_get_f64", "mhip_ctx_raw_stats", "mhip_ctx_apply_keep",
     "mhip_ctx_stats", "mhip_ctx_watershed_counts", "mhip_ctx_pourpoints",
@@ -41,10 +41,10 @@ SYMBOLS = [
     "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_certify", "mhip_ctx_fill_end",
     "mhip_ctx_geo_begin", "mhip_ctx_geo_batch", "mhip_ctx_geo_halo_changed", "mhip_ctx_geo_end", "mhip_ctx_fill_attach", "mhip_ctx_noflat_verify",
-    "mhip_ctx_zero_raster", "mhip_ctx_band_accum_boundary", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_watershed_local",
+    "mhip_ctx_zero_raster", "mhip_ctx_band_accum_boundary", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_relabel_range", "mhip_ctx_band_trace", "mhip_ctx_band_watershed_local",
     "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_records", "mhip_ctx_band_fetch", "mhip_ctx_band_gather",
     "mhip_ctx_band_foreign_counts", "mhip_ctx_side_begin", "mhip_ctx_side_end",
-    "mhip_ctx_has_comm", "mhip_ctx_exchange_halo", "mhip_ctx_allreduce_max",
+    "mhip_ctx_has_comm", "mhip_ctx_exchange_halo", "mhip_ctx_exchange_edge_rows", "mhip_ctx_comm_add_side", "mhip_band_union_find", "mhip_ctx_allreduce_max",
 ]
 
 _lib = None

@@ -14,7 +14,7 @@ import numpy as np
 from .. import _lib
 from .dtypes import DTYPE_FLOWDIR, DTYPE_LABEL
 
-__all__ = ["next_downstream_label", "trace_downstream_labels", "pourpoint_network", "geometric_pourpoint_network"]
+__all__ = ["next_downstream_label", "trace_downstream_labels", "pourpoint_network", "geometric_pourpoint_network", "network_from_walks"]
 
 
 def _pourpoint_enumerator(pour_points):
@@ -152,13 +152,22 @@ def geometric_pourpoint_network(flowdir, labeled_bluespots, pour_points, backgro
     ``max_label``: largest bluespot label if the caller knows it (a resident pipeline does); else taken from the raster."""
     ids_cells = list(_pourpoint_enumerator(pour_points))
     labels, geoms = trace_downstream_labels(flowdir, labeled_bluespots, [c for _, c in ids_cells], background_label, True, pipeline)
-    upstream = OrderedDict()
-    for (pid, cell), down, geom in zip(ids_cells, labels, geoms):
-        upstream.setdefault(down, []).append(dict(id=pid, downstream_id=down, nodetype='pourpoint', pix=tuple(cell), geometry=geom))
     if max_label is None:
         max_label = pipeline.get_int("nlabels") if pipeline is not None else int(np.max(labeled_bluespots))
-    next_label = int(max_label) + 1
+    return network_from_walks([i for i, _ in ids_cells], [c for _, c in ids_cells], labels, geoms, int(max_label) + 1)
+
+
+def network_from_walks(ids, cells, labels, geoms, next_label):
+    """The node list of ``geometric_pourpoint_network`` from walks that have already been made (``labels[i]`` / ``geoms[i]``: what
+    ``next_downstream_label`` returned for pour point ``ids[i]`` at ``cells[i]``) -- the row-band path walks across the bands
+    (BandPipeline.trace_downstream) and hands the result to the same junction surgery (net.py:195-224).  ``next_label``: the
+    first free node id (largest bluespot label + 1)."""
+    upstream = OrderedDict()
+    for pid, cell, down, geom in zip(ids, cells, labels, geoms):
+        upstream.setdefault(down, []).append(dict(id=pid, downstream_id=down, nodetype='pourpoint', pix=(int(cell[0]), int(cell[1])),
+                                                  geometry=[(int(r), int(c)) for r, c in geom]))
     final = []
+    next_label = int(next_label)
     for nodes in upstream.values():
         next_label = _untangle(nodes, next_label, final)
     return final

@@ -36,20 +36,21 @@ def transform_cell_to_world(cell, transform):
     return x, y
 
 
-def assemble_pourpoints(transform, pp_pix, bluespot_stats, watershed_stats):
-    """GeoJSON-like pour point features, one per label incl. background 0 (bluespots.py:49-88)."""
+def assemble_pourpoints(transform, pp_pix, bluespot_stats, watershed_stats, first_id=0):
+    """GeoJSON-like pour point features, one per label incl. background 0 (bluespots.py:49-88).  ``first_id``: the label of the
+    first record (a row band assembles the features of the labels it numbered)."""
     cell_area = abs(transform[1]) * abs(transform[5])
     pour_points = []
-    for ix, (pix, bstat, wcount) in enumerate(zip(pp_pix, bluespot_stats, watershed_stats)):
+    for ix, (pix, bstat, wcount) in enumerate(zip(pp_pix, bluespot_stats, watershed_stats), int(first_id)):
         p = dict(bspot_id=ix, type="Feature")
         p['cell_row'] = int(pix['row'])
         p['cell_col'] = int(pix['col'])
         p['bspot_dmax'] = float(bstat['max'])
-        p['bspot_area'] = bstat['count'] * cell_area
-        p['bspot_vol'] = bstat['sum'] * cell_area
-        p['wshed_area'] = wcount * cell_area
-        p['bspot_fumm'] = 1000 * p['bspot_vol'] / p['wshed_area']
-        coord = transform_cell_to_world((pix['row'], pix['col']), transform)
+        p['bspot_area'] = float(bstat['count'] * cell_area)
+        p['bspot_vol'] = float(bstat['sum'] * cell_area)
+        p['wshed_area'] = float(wcount * cell_area)
+        p['bspot_fumm'] = float(np.float64(1000 * p['bspot_vol']) / np.float64(p['wshed_area']))
+        coord = transform_cell_to_world((int(pix['row']), int(pix['col'])), transform)
         pour_points.append(dict(id=ix, geometry=dict(type='Point', coordinates=list(coord)), properties=p))
     return pour_points
 

@@ -11,7 +11,10 @@ Outputs carry the reference's names: ``filled.tif``, ``flowdir.tif``, ``bs_depth
 """
 import ast
 import logging
+import operator
 import os
+
+import numpy as np
 
 from . import io
 from .bluespots import BluespotTool
@@ -33,7 +36,9 @@ def parse_filter(filter):
     parentheses); anything else raises like there.  The expression is validated on its syntax tree instead of by character
     stripping, then compiled once."""
     if not filter:
-        return lambda stats: True
+        keep_all = lambda stats: True
+        keep_all.vectorized = lambda stats: np.ones(len(stats["area"]), dtype=bool)
+        return keep_all
     try:
         tree = ast.parse(filter.strip(), mode="eval")
     except SyntaxError:
@@ -48,17 +53,51 @@ def parse_filter(filter):
 
     def filter_function(stats):
         return eval(code, {"__builtins__": {}}, {name: stats[key] for name, key in _FILTER_NAMES.items()})
+
+    _CMP = {ast.Gt: operator.gt, ast.GtE: operator.ge, ast.Lt: operator.lt, ast.LtE: operator.le, ast.Eq: operator.eq, ast.NotEq: operator.ne}
+
+    def vec(node, env):
+        if isinstance(node, ast.Expression):
+            return vec(node.body, env)
+        if isinstance(node, ast.BoolOp):
+            parts = [np.asarray(vec(v, env), dtype=bool) for v in node.values]
+            return (np.logical_and if isinstance(node.op, ast.And) else np.logical_or).reduce(np.broadcast_arrays(*parts))
+        if isinstance(node, ast.Compare):
+            left, out = vec(node.left, env), True
+            for op, right in zip(node.ops, node.comparators):
+                right = vec(right, env)
+                out = np.logical_and(out, _CMP[type(op)](left, right))
+                left = right
+            return out
+        if isinstance(node, ast.UnaryOp):
+            v = vec(node.operand, env)
+            return -v if isinstance(node.op, ast.USub) else +v
+        if isinstance(node, ast.Name):
+            return env[node.id]
+        return node.value
+
+    def vectorized(stats):
+        """the same predicate on arrays (``stats``: mapping with max / area / volume arrays): one boolean per bluespot -- what the
+        row-band path evaluates on the records of millions of labels instead of calling the function once per label"""
+        env = {name: np.asarray(stats[key]) for name, key in _FILTER_NAMES.items()}
+        n = len(env["area"])
+        return np.broadcast_to(np.asarray(vec(tree, env), dtype=bool), (n,)).copy()
+    filter_function.vectorized = vectorized
     return filter_function
 
 
-def process_all(dem, outdir, rain, accum=False, filter=None, vector=False, device=0, nodatasubst=-999):
-    """Quick option to run all processes (scripts/complete.py:37-117) on one MI355X.
+def process_all(dem, outdir, rain, accum=False, filter=None, vector=False, device=0, nodatasubst=-999, comm=None, backend_factory=None):
+    """Quick option to run all processes (scripts/complete.py:37-117) on one MI355X -- or, with ``comm`` (a
+    ``malstroem_amd.distributed.Comm`` of more than one rank; every rank calls this function), on the row bands of one DEM, one band per
+    rank: see ``_process_all_bands``.
 
     ``dem``: path of the DEM GeoTIFF (metres, square cells); ``outdir``: an existing empty directory; ``rain``: rain incidents
     in mm; ``accum``: also compute the accumulated flow (pour points then sit at its maximum, bluespots.py:195-200);
     ``filter``: bluespot filter expression.  Returns a dict with the paths written and the counts the reference logs."""
     if vector:
         raise NotImplementedError("vectorisation of bluespots / watersheds (GDAL polygonize) is outside malstroem_amd's hot path")
+    if comm is not None and comm.size > 1:
+        return _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasubst, backend_factory)
     if not os.path.isdir(outdir) or os.listdir(outdir):
         raise ValueError("outdir isn't an empty directory")
     outvector = os.path.join(outdir, 'vector')
@@ -101,3 +140,105 @@ def process_all(dem, outdir, rain, accum=False, filter=None, vector=False, devic
     RainTool(nodes_reader, events_writer, rain).process()
     return dict(outdir=outdir, vector=outvector, nlabels=nlabels, events=events_writer.filepath,
                 nodes=nodes_writer.filepath, streams=streams_writer.filepath, pourpoints=pourpoint_writer.filepath)
+
+
+def _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasubst, backend_factory):
+    """``complete`` on row bands (BASELINE configs[4]): every rank reads its rows of the DEM file, the band chain runs on the resident
+    bands (fills with halo exchange, D8, accumulation, labels merged across the seams), then -- what the reference does between its
+    tools through files -- on the bands directly: the bluespot filter (every rank decides about the labels it numbered), watersheds,
+    pour points (records merged across bands), the stream walk (walkers handed over at the seams) and, on rank 0, the junction
+    surgery, the rain events and all writing.  Returns the same dict as ``process_all`` on rank 0, ``None`` elsewhere."""
+    from .algorithms import dtypes, net
+    from .bluespots import assemble_pourpoints
+    from .distributed import BandPipeline
+    from .streams import nodes_to_features
+    root = comm.rank == 0
+    err = None
+    if root and (not os.path.isdir(outdir) or os.listdir(outdir)):
+        err = ValueError("outdir isn't an empty directory")
+    if comm.allreduce_max(1.0 if err else 0.0) > 0.0:
+        raise err or ValueError("outdir isn't an empty directory (rank 0)")
+    outvector = os.path.join(outdir, 'vector')
+    filter_function = parse_filter(filter)
+    reader = io.RasterReader(dem, nodatasubst=nodatasubst)
+    tr, crs = reader.transform, reader.crs
+    cell_area = abs(tr[1]) * abs(tr[5])
+    assert abs(abs(tr[1]) - abs(tr[5])) < 0.01 * abs(tr[1]), "Input cells must be square"
+    pipe = BandPipeline(comm, reader.shape, device=device, backend_factory=backend_factory)
+    try:
+        pipe.upload_dem(reader.read_window(pipe.row0, pipe.nrows).astype(dtypes.DTYPE_DTM, casting='same_kind', copy=False))
+        reader.close()
+
+        def write(name, filename, nodata=None):
+            w = io.RasterWriter(os.path.join(outdir, filename), tr, crs, nodata) if root else None
+            opened = False
+            for row0, rows in pipe.gather_rows(name):
+                if root:
+                    if not opened:
+                        w.open(pipe.H_W, rows.dtype)
+                        opened = True
+                    w.write_window(row0, rows)
+            if root:
+                w.close()
+        pipe.H_W = reader.shape
+        logger.info("Calculating filled DEM and bluespot depths")
+        pipe.fill()
+        write("filled", "filled.tif", nodatasubst)
+        write("depths", "bs_depths.tif")
+        logger.info("Calculating flow directions")
+        pipe.noflat()
+        pipe.flowdir()
+        write("flowdir", "flowdir.tif")
+        if accum:
+            logger.info("Calculating flow accumulation")
+            pipe.accum()
+            write("accum", "accum.tif")
+        logger.info("Calculating unfiltered bluespots")
+        nraw = pipe.label()
+        logger.info("Number of bluespots found before filtering: {}".format(nraw))
+
+        def keep(records):       # bluespots.py:23-46 on record arrays
+            stats = dict(max=records["max"], area=records["count"] * cell_area, volume=records["sum"] * cell_area)
+            if hasattr(filter_function, "vectorized"):
+                return filter_function.vectorized(stats)
+            return np.array([bool(filter_function(dict(min=r["min"], max=r["max"], sum=r["sum"], count=r["count"], volume=r["sum"] * cell_area,
+                                                       area=r["count"] * cell_area))) for r in records], dtype=bool)
+        nlabels = pipe.filter(keep)
+        logger.info("Number of bluespots left after filtering: {}".format(nlabels))
+        write("labels", "bluespots.tif", 0)
+        logger.info("Calculating watersheds and pour points")
+        pipe.watershed()
+        write("watersheds", "watersheds.tif", 0)
+        stats, counts, pour = pipe.stats(), pipe.watershed_counts(), pipe.pourpoints(use_accum=bool(accum))
+        # pour point features: every rank its own labels, rank 0 the background record (bluespots.py:49-88 emits index 0 as well)
+        lo = stats["first_label"]
+        feats = assemble_pourpoints(tr, pour["records"], stats["records"], counts["records"], first_id=lo)
+        if root:
+            feats = assemble_pourpoints(tr, [pour["background"]], [stats["background"]], [counts["background"]], first_id=0) + feats
+        feats = [f for part in comm.allgather(feats) for f in part]
+        pourpoint_writer = io.VectorWriter('GeoJSON', outvector, 'pourpoints', None, None, crs)
+        if root:
+            logger.info("Writing {} pour points".format(len(feats)))
+            pourpoint_writer.write_geojson_features(dict(type="FeatureCollection", features=feats))
+        # stream network: walkers start at every pour point (also the background's) and are handed over at the seams
+        pix = [(f['properties']['cell_row'], f['properties']['cell_col']) for f in feats]
+        labels_next, geoms = pipe.trace_downstream(pix, 0, geometry=True)
+    finally:
+        pipe.close()
+    if not root:
+        comm.allreduce_max(0.0)       # (rank 0 is writing: leave together)
+        return None
+    try:
+        ids = [f['properties']['bspot_id'] for f in feats]
+        nodes = net.network_from_walks(ids, pix, labels_next, geoms, next_label=nlabels + 1)
+        nodes_writer = io.VectorWriter('GeoJSON', outvector, 'nodes', None, None, crs)
+        streams_writer = io.VectorWriter('GeoJSON', outvector, 'streams', None, None, crs)
+        node_feats, stream_feats = nodes_to_features(nodes, feats, tr)
+        nodes_writer.write_geojson_features(node_feats)
+        streams_writer.write_geojson_features(stream_feats)
+        events_writer = io.VectorWriter('GeoJSON', outvector, 'events', None, None, crs)
+        RainTool(io.VectorReader(outvector, 'nodes'), events_writer, rain).process()
+    finally:
+        comm.allreduce_max(0.0)
+    return dict(outdir=outdir, vector=outvector, nlabels=nlabels, events=events_writer.filepath, nodes=nodes_writer.filepath,
+                streams=streams_writer.filepath, pourpoints=pourpoint_writer.filepath)

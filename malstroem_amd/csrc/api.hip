@@ -468,7 +468,8 @@ struct mhip_ctx {
     std::map<int, std::pair<hipEvent_t, hipEvent_t>> ev;
     std::map<int, bool> ev_valid;
     void *comm = nullptr;   // RCCL communicator over all bands (comm.hip); nullptr: the launcher moves the rows
-    DevBuf comm_stage, comm_word, comm_flags;
+    void *comm_b = nullptr; // a second one for the thread between mhip_ctx_side_begin / _end (two threads never share a communicator)
+    DevBuf comm_stage, comm_word, comm_flags, comm_stage_b;
     // second stream + fork/join events of the stage DAG (mhip_ctx_run)
     hipStream_t stream_b = nullptr, stream_c = nullptr;
     hipEvent_t ev_fork = nullptr, ev_flowdir = nullptr, ev_join = nullptr, ev_label = nullptr, ev_tail = nullptr;
@@ -503,6 +504,8 @@ static int ctx_events(mhip_ctx *c, int stage, hipEvent_t **a, hipEvent_t **b)
     *b = &it->second.second;
     return MHIP_OK;
 }
+
+int mhip_comm_available(void) { return comm_available(); }
 
 int mhip_comm_unique_id(void *id128)
 {
@@ -570,6 +573,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
     delete c->run[0];
     delete c->run[1];
     comm_destroy(c->comm);
+    comm_destroy(c->comm_b);
     delete c;
     return MHIP_OK;
 }
@@ -579,6 +583,16 @@ int mhip_ctx_destroy(mhip_ctx *c)
 // the context's side stream, next to the fills the main thread keeps launching on the main stream.
 static thread_local mhip_ctx *t_side_ctx = nullptr;
 static hipStream_t cs(mhip_ctx *c) { return (t_side_ctx == c && c->stream_b) ? c->stream_b : c->stream; }
+// ... and every RCCL call of that thread goes over the context's SECOND communicator (mhip_ctx_comm_add_side): the order of the
+// operations on one communicator must be the same on every rank, which two threads sharing one cannot promise
+static bool on_side(mhip_ctx *c) { return t_side_ctx == c; }
+
+int mhip_ctx_comm_add_side(mhip_ctx *c, const void *nccl_unique_id)
+{
+    MH_ARG(c && nccl_unique_id && c->comm && !c->comm_b, "ctx_comm_add_side(ctx, id) needs a band context with a communicator and no side communicator yet");
+    MH_HIP(hipSetDevice(c->device));
+    return comm_create(&c->comm_b, nccl_unique_id, c->rank, c->nranks);     // collective over all bands
+}
 
 int mhip_ctx_side_begin(mhip_ctx *c)
 {
@@ -769,6 +783,31 @@ int mhip_ctx_exchange_halo(mhip_ctx *c, int which, int32_t *changed)
     return MHIP_OK;
 }
 
+/* The same exchange WITHOUT touching the halo rows: the neighbours' edge rows of raster `which` arrive in host buffers (W elements
+ * each; NULL where there is no neighbour).  The boundary systems of labelling, accumulation and watersheds compare a neighbour's
+ * edge row with this band's own halo row: neighbour-to-neighbour traffic over RCCL instead of an all-gather of every band's rows. */
+int mhip_ctx_exchange_edge_rows(mhip_ctx *c, int which, void *host_from_up, void *host_from_down)
+{
+    MH_ARG(c && which >= 0 && which < MHIP_R_COUNT_, "ctx_exchange_edge_rows(ctx, which, from_up, from_down)");
+    void *comm = on_side(c) ? c->comm_b : c->comm;
+    MH_ARG(comm || c->nranks == 1, on_side(c) ? "this band context has no side communicator (mhip_ctx_comm_add_side)"
+                                              : "this band context has no RCCL communicator (created without an ncclUniqueId)");
+    if (!c->ht && !c->hb) return MHIP_OK;
+    MH_ARG(c->r[which].p, "raster has not been computed or uploaded");
+    MH_ARG((!c->ht || host_from_up) && (!c->hb || host_from_down), "ctx_exchange_edge_rows: a buffer per neighbour");
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = cs(c);
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    DevBuf &stage = on_side(c) ? c->comm_stage_b : c->comm_stage;
+    MH_TRY(stage.alloc(2 * rowb));
+    char *base = c->r[which].as<char>();
+    MH_TRY(comm_exchange_rows(comm, c->rank, c->nranks, base + rowb * c->ht, base + rowb * (c->ht + c->H_owned - 1), stage.p, rowb, s));
+    if (c->ht) MH_HIP(hipMemcpyAsync(host_from_up, stage.p, rowb, hipMemcpyDeviceToHost, s));
+    if (c->hb) MH_HIP(hipMemcpyAsync(host_from_down, stage.as<char>() + rowb, rowb, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
+}
+
 /* max of `value` over all bands (ends the fill / accumulation loops: "is anybody still active") */
 int mhip_ctx_allreduce_max(mhip_ctx *c, double value, double *out)
 {
@@ -788,7 +827,7 @@ int mhip_ctx_allreduce_max(mhip_ctx *c, double value, double *out)
     return MHIP_OK;
 }
 
-int mhip_ctx_has_comm(mhip_ctx *c) { return (c && c->comm) ? 1 : 0; }
+int mhip_ctx_has_comm(mhip_ctx *c) { return (c && c->comm) ? ((c->comm_b) ? 2 : 1) : 0; }
 
 int mhip_ctx_zero_raster(mhip_ctx *c, int which)
 {
@@ -867,6 +906,75 @@ int mhip_ctx_band_relabel_sparse(mhip_ctx *c, int64_t nlocal, int64_t offset, co
     return MHIP_OK;
 }
 
+/* the bluespot filter on a band (reference bluespots.py:165-172 == a rank relabel): labels in [lo, hi] (numbered by this band) ->
+ * lut[l - lo] (0 = dropped); a label numbered by another band -> fnew[k] where fid[k] == l (fid sorted); nlabels_new = the global count */
+int mhip_ctx_band_relabel_range(mhip_ctx *c, int64_t lo, int64_t hi, const int32_t *lut, const int32_t *fid, const int32_t *fnew, int64_t nf,
+                                int64_t nlabels_new)
+{
+    MH_ARG(c && c->have[MHIP_R_LABELS] && lo >= 1 && hi >= lo - 1 && hi < (int64_t)INT32_MAX && nf >= 0 && (hi < lo || lut) && (nf == 0 || (fid && fnew)) &&
+               nlabels_new >= 0, "ctx_band_relabel_range(ctx, lo, hi, lut, fid, fnew, nf, nlabels_new)");
+    for (int64_t k = 1; k < nf; ++k) MH_ARG(fid[k - 1] < fid[k], "ctx_band_relabel_range: foreign labels must be sorted and unique");
+    MH_HIP(hipSetDevice(c->device));
+    DevBuf d_lut, d_fid, d_fnew;
+    const size_t nl = (size_t)(hi - lo + 1);
+    MH_TRY(d_lut.alloc(4 * (nl + 1)));
+    MH_TRY(d_fid.alloc(4 * (size_t)(nf + 1)));
+    MH_TRY(d_fnew.alloc(4 * (size_t)(nf + 1)));
+    if (nl) MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * nl, hipMemcpyHostToDevice, cs(c)));
+    if (nf) {
+        MH_HIP(hipMemcpyAsync(d_fid.p, fid, 4 * (size_t)nf, hipMemcpyHostToDevice, cs(c)));
+        MH_HIP(hipMemcpyAsync(d_fnew.p, fnew, 4 * (size_t)nf, hipMemcpyHostToDevice, cs(c)));
+    }
+    MH_TRY(relabel_range_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, (int32_t)lo, (int32_t)hi, d_lut.as<int32_t>(), d_fid.as<int32_t>(),
+                             d_fnew.as<int32_t>(), (int32_t)nf, cs(c)));
+    MH_HIP(hipStreamSynchronize(cs(c)));
+    c->nlabels = c->nlabels_raw = nlabels_new;
+    c->labels_filtered = true;
+    return MHIP_OK;
+}
+
+/* one leg of the stream walk on a band (trace.hip: band_trace_kernel).  cells_rc: GLOBAL (row, col) of n walkers that stand on
+ * owned rows of this band; src_label[i] >= 0: the walker's source label (it came from another band), -1: its start cell's label.
+ * out_status: 0 ended without a label, 1 found out_label, 2 stepped onto a neighbour's row at out_exit_rc (GLOBAL).  Geometry
+ * (global linear indices) in two passes like mhip_ctx_trace_downstream: lengths first, then offsets + out_cells. */
+int mhip_ctx_band_trace(mhip_ctx *c, const int64_t *cells_rc, const int32_t *src_label, int64_t n, int use_background, int32_t background,
+                        int32_t *out_label, int32_t *out_status, int32_t *out_src, int64_t *out_exit_rc, int64_t *out_len, const int64_t *offsets,
+                        int64_t *out_cells)
+{
+    MH_ARG(c && n >= 0 && (n == 0 || cells_rc), "ctx_band_trace(ctx, cells, src, n, ...)");
+    MH_ARG(c->have[MHIP_R_FLOWDIR] && c->have[MHIP_R_LABELS], "ctx_band_trace needs flow directions and labels");
+    if (n == 0) return MHIP_OK;
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = cs(c);
+    DevBuf d_c, d_s, d_l, d_f, d_so, d_e, d_n, d_o, d_p;
+    MH_TRY(upload(d_c, cells_rc, (size_t)n * 16, s));
+    if (src_label) MH_TRY(upload(d_s, src_label, (size_t)n * 4, s));
+    MH_TRY(d_l.alloc((size_t)n * 4));
+    MH_TRY(d_f.alloc((size_t)n * 4));
+    MH_TRY(d_so.alloc((size_t)n * 4));
+    MH_TRY(d_e.alloc((size_t)n * 16));
+    MH_TRY(d_n.alloc((size_t)n * 8));
+    int64_t total = 0;
+    if (offsets && out_cells) {
+        total = offsets[n];
+        MH_ARG(total >= 0, "band_trace: offsets[n] must be the total path length");
+        MH_TRY(upload(d_o, offsets, (size_t)(n + 1) * 8, s));
+        MH_TRY(d_p.alloc((size_t)(total > 0 ? total : 1) * 8));
+    }
+    MH_TRY(band_trace_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->H, c->W, c->row0 - c->ht, c->ht, c->ht + c->H_owned,
+                          c->H_global, d_c.as<int64_t>(), src_label ? d_s.as<int32_t>() : nullptr, n, use_background, background, d_l.as<int32_t>(),
+                          d_f.as<int32_t>(), d_so.as<int32_t>(), d_e.as<int64_t>(), d_n.as<int64_t>(), total ? d_o.as<int64_t>() : nullptr,
+                          total ? d_p.as<int64_t>() : nullptr, s));
+    if (out_label) MH_HIP(hipMemcpyAsync(out_label, d_l.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (out_status) MH_HIP(hipMemcpyAsync(out_status, d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (out_src) MH_HIP(hipMemcpyAsync(out_src, d_so.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (out_exit_rc) MH_HIP(hipMemcpyAsync(out_exit_rc, d_e.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    if (out_len) MH_HIP(hipMemcpyAsync(out_len, d_n.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (total) MH_HIP(hipMemcpyAsync(out_cells, d_p.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(hipStreamSynchronize(s));
+    return MHIP_OK;
+}
+
 /* watersheds inside the band: halo rows are terminals carrying pseudo labels -(1+col) (top) / -(1+W+col) (bottom) */
 int mhip_ctx_band_watershed_local(mhip_ctx *c)
 {
@@ -928,11 +1036,11 @@ __global__ void foreign_counts_kernel(const int64_t *cnt, int64_t n, int64_t lo,
 }  // namespace
 
 static size_t band_record_size(int which) { return which == 0 ? sizeof(mhip_stat_record) : which == 1 ? 8 : sizeof(mhip_index_record); }
-static DevBuf &band_record_buf(mhip_ctx *c, int which) { return which == 0 ? c->stats : which == 1 ? c->ws_counts : c->pour; }
+static DevBuf &band_record_buf(mhip_ctx *c, int which) { return which == 0 ? c->stats : which == 1 ? c->ws_counts : c->pour; }   // (2 and 3 share a buffer)
 
 int mhip_ctx_band_records(mhip_ctx *c, int which)
 {
-    MH_ARG(c && which >= 0 && which <= 2 && c->have[MHIP_R_LABELS] && c->nlabels >= 0, "ctx_band_records(ctx, which) needs global labels");
+    MH_ARG(c && which >= 0 && which <= 3 && c->have[MHIP_R_LABELS] && c->nlabels >= 0, "ctx_band_records(ctx, which) needs global labels");
     MH_HIP(hipSetDevice(c->device));
     const int64_t off = c->W * c->ht, n = c->H_owned * c->W, nrec = c->nlabels + 1;
     DevBuf &buf = band_record_buf(c, which);
@@ -945,9 +1053,11 @@ int mhip_ctx_band_records(mhip_ctx *c, int which)
         MH_ARG(c->have[MHIP_R_WATERSHEDS], "watershed counts need the watersheds");
         MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, buf.as<int64_t>(), cs(c), c->W));
     } else {
-        MH_ARG(c->have[MHIP_R_ACCUM], "pour points need the accumulated flow");
-        MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
-                             true, buf.as<mhip_index_record>(), cs(c)));
+        // bluespots.py:195-206: the first arg-max of the accumulated flow (2), or the first arg-min of the no-flats surface (3)
+        const int src = which == 2 ? MHIP_R_ACCUM : MHIP_R_NOFLAT;
+        MH_ARG(c->have[src], which == 2 ? "pour points need the accumulated flow" : "pour points need the no-flats surface");
+        MH_TRY(label_arg_dev(c->r[src].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
+                             which == 2, buf.as<mhip_index_record>(), cs(c)));
         hipLaunchKernelGGL(global_rows_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, cs(c), buf.as<mhip_index_record>(), nrec,
                            c->row0);
         MH_HIP(hipGetLastError());
@@ -958,7 +1068,7 @@ int mhip_ctx_band_records(mhip_ctx *c, int which)
 /* records [first, first + count) of the last mhip_ctx_band_records(which) */
 int mhip_ctx_band_fetch(mhip_ctx *c, int which, int64_t first, int64_t count, void *out)
 {
-    MH_ARG(c && which >= 0 && which <= 2 && band_record_buf(c, which).p && first >= 0 && count >= 0 && first + count <= c->nlabels + 1 &&
+    MH_ARG(c && which >= 0 && which <= 3 && band_record_buf(c, which).p && first >= 0 && count >= 0 && first + count <= c->nlabels + 1 &&
                (out || count == 0), "ctx_band_fetch(ctx, which, first, count, out)");
     if (count == 0) return MHIP_OK;
     MH_HIP(hipSetDevice(c->device));
@@ -971,7 +1081,7 @@ int mhip_ctx_band_fetch(mhip_ctx *c, int which, int64_t first, int64_t count, vo
 /* records at the given labels (any order) */
 int mhip_ctx_band_gather(mhip_ctx *c, int which, const int64_t *ids, int64_t nids, void *out)
 {
-    MH_ARG(c && which >= 0 && which <= 2 && band_record_buf(c, which).p && nids >= 0 && ((ids && out) || nids == 0), "ctx_band_gather");
+    MH_ARG(c && which >= 0 && which <= 3 && band_record_buf(c, which).p && nids >= 0 && ((ids && out) || nids == 0), "ctx_band_gather");
     if (nids == 0) return MHIP_OK;
     for (int64_t k = 0; k < nids; ++k) MH_ARG(ids[k] >= 0 && ids[k] <= c->nlabels, "ctx_band_gather: label outside [0, nlabels]");
     MH_HIP(hipSetDevice(c->device));

@@ -65,3 +65,25 @@ extern "C" int mhip_band_ws_resolve(int64_t n, int64_t *vals)
     }
     return MHIP_OK;
 }
+
+// Connected classes of an undirected graph on nodes 0 .. n-1 given by m edges (a[k], b[k]): cls[i] = the smallest node of i's
+// class (the label merge of BandPipeline.label works on the few thousand seam pairs the bands publish, not on their rows).
+extern "C" int mhip_band_union_find(int64_t n, int64_t m, const int64_t *a, const int64_t *b, int64_t *cls)
+{
+    MH_ARG(n >= 0 && m >= 0 && (n == 0 || cls) && (m == 0 || (a && b)), "band_union_find(n, m, a, b, cls)");
+    for (int64_t i = 0; i < n; ++i) cls[i] = i;
+    auto find = [&](int64_t x) {
+        while (cls[x] != x) {
+            cls[x] = cls[cls[x]];
+            x = cls[x];
+        }
+        return x;
+    };
+    for (int64_t k = 0; k < m; ++k) {
+        MH_ARG(a[k] >= 0 && a[k] < n && b[k] >= 0 && b[k] < n, "band_union_find: node out of range");
+        const int64_t x = find(a[k]), y = find(b[k]);
+        if (x != y) cls[x < y ? y : x] = x < y ? x : y;      // the smaller node is the root
+    }
+    for (int64_t i = 0; i < n; ++i) cls[i] = find(i);
+    return MHIP_OK;
+}

@@ -93,6 +93,14 @@ int need_rccl(Rccl **out)
 
 }  // namespace
 
+// cheap probe (dlopen + symbols only): every rank votes on it BEFORE any rank enters ncclCommInitRank, which would wait for
+// a rank that cannot join
+int comm_available()
+{
+    Rccl *r;
+    return need_rccl(&r) == MHIP_OK ? 1 : 0;
+}
+
 int comm_unique_id(void *id128)
 {
     Rccl *r;
@@ -132,15 +140,30 @@ int comm_exchange_rows(void *comm, int rank, int nranks, const void *first_row, 
     const bool up = rank > 0, down = rank < nranks - 1;
     if (!up && !down) return MHIP_OK;
     MH_NCCL(r, r->GroupStart());
+    // every exit closes the group: a communicator left in group mode would swallow the next collective (the vote)
+    int first_err = kNcclSuccess;
+    const char *what = "";
+    auto step = [&](int e, const char *w) {
+        if (e != kNcclSuccess && first_err == kNcclSuccess) {
+            first_err = e;
+            what = w;
+        }
+    };
     if (up) {
-        MH_NCCL(r, r->Send(first_row, rowbytes, kNcclUint8, rank - 1, comm, s));
-        MH_NCCL(r, r->Recv(stage, rowbytes, kNcclUint8, rank - 1, comm, s));
+        step(r->Send(first_row, rowbytes, kNcclUint8, rank - 1, comm, s), "ncclSend to the band above");
+        if (first_err == kNcclSuccess) step(r->Recv(stage, rowbytes, kNcclUint8, rank - 1, comm, s), "ncclRecv from the band above");
     }
-    if (down) {
-        MH_NCCL(r, r->Send(last_row, rowbytes, kNcclUint8, rank + 1, comm, s));
-        MH_NCCL(r, r->Recv(static_cast<char *>(stage) + rowbytes, rowbytes, kNcclUint8, rank + 1, comm, s));
+    if (down && first_err == kNcclSuccess) {
+        step(r->Send(last_row, rowbytes, kNcclUint8, rank + 1, comm, s), "ncclSend to the band below");
+        if (first_err == kNcclSuccess)
+            step(r->Recv(static_cast<char *>(stage) + rowbytes, rowbytes, kNcclUint8, rank + 1, comm, s), "ncclRecv from the band below");
     }
-    MH_NCCL(r, r->GroupEnd());
+    const int end_err = r->GroupEnd();
+    if (first_err != kNcclSuccess || end_err != kNcclSuccess) {
+        const int e = first_err != kNcclSuccess ? first_err : end_err;
+        set_error("%s failed: %s", first_err != kNcclSuccess ? what : "ncclGroupEnd", r->GetErrorString ? r->GetErrorString(e) : "?");
+        return MHIP_ECOMM;
+    }
     return MHIP_OK;
 }
 

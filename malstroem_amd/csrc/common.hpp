@@ -234,6 +234,7 @@ int trace_downstream_dev(const uint8_t *d_fd, const int32_t *d_lab, int64_t H, i
                          hipStream_t s);
 // comm.hip (RCCL, opened at run time)
 int comm_unique_id(void *id128);
+int comm_available();
 int comm_create(void **comm, const void *id128, int rank, int nranks);
 void comm_destroy(void *comm);
 int comm_exchange_rows(void *comm, int rank, int nranks, const void *first_row, const void *last_row, void *stage, size_t rowbytes,
@@ -249,6 +250,11 @@ int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_
                 hipStream_t s);
 // label_ops.hip
 int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64_t n, hipStream_t s);
+int relabel_range_dev(int32_t *d_labels, int64_t n, int32_t lo, int32_t hi, const int32_t *d_lut, const int32_t *d_fid, const int32_t *d_fnew, int32_t nf,
+                      hipStream_t s);
+int band_trace_dev(const uint8_t *d_fd, const int32_t *d_lab, int64_t Hl, int64_t W, int64_t row_lo, int64_t own0, int64_t own1, int64_t Hg,
+                   const int64_t *d_cells, const int32_t *d_src, int64_t n, int use_bg, int32_t bg, int32_t *d_label, int32_t *d_status,
+                   int32_t *d_src_out, int64_t *d_exit, int64_t *d_len, const int64_t *d_offsets, int64_t *d_out_cells, hipStream_t s);
 int relabel_sparse_dev(int32_t *d_labels, int64_t n, int64_t nlocal, int32_t offset, const int32_t *d_dropped, const int32_t *d_target,
                        int32_t ndropped, hipStream_t s);
 int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask,

@@ -571,6 +571,28 @@ __global__ __launch_bounds__(256) void relabel_sparse_kernel(int32_t *lab, int64
     lab[i] = (lo < ndropped && dropped[lo] == l) ? target[lo] : offset + l - lo;
 }
 
+// labels in [lo, hi] (the labels this band numbered) go through a dense table, every other positive label (a bluespot numbered by
+// another band that reaches into this one: a short sorted list) through a binary search; a label found in neither becomes 0
+__global__ __launch_bounds__(256) void relabel_range_kernel(int32_t *lab, int64_t n, int32_t lo, int32_t hi, const int32_t *__restrict__ lut,
+                                                           const int32_t *__restrict__ fid, const int32_t *__restrict__ fnew, int32_t nf)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t l = lab[i];
+    if (l <= 0) return;
+    if (l >= lo && l <= hi) {
+        lab[i] = lut[l - lo];
+        return;
+    }
+    int32_t a = 0, b = nf;
+    while (a < b) {
+        const int32_t mid = (a + b) >> 1;
+        if (fid[mid] < l) a = mid + 1;
+        else b = mid;
+    }
+    lab[i] = (a < nf && fid[a] == l) ? fnew[a] : 0;
+}
+
 __global__ __launch_bounds__(256) void mask_kernel(const int32_t *__restrict__ lab, const uint8_t *__restrict__ keep,
                                                   int64_t nlab, int64_t n, uint8_t *mask, unsigned int *bad)
 {
@@ -730,6 +752,14 @@ int relabel_sparse_dev(int32_t *d_labels, int64_t n, int64_t nlocal, int32_t off
                        ndropped, bad.as<unsigned int>());
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "band_relabel_sparse");
+}
+
+int relabel_range_dev(int32_t *d_labels, int64_t n, int32_t lo, int32_t hi, const int32_t *d_lut, const int32_t *d_fid, const int32_t *d_fnew, int32_t nf,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(relabel_range_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, d_labels, n, lo, hi, d_lut, d_fid, d_fnew, nf);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
 }
 
 int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask, hipStream_t s)

@@ -18,8 +18,10 @@ package itself never imports it).  Without RCCL (one GPU shared by several bands
 tests) the rows travel through the ``Comm`` as host buffers.  The compute backend is ``HipBand`` (the C-ABI band context).
 """
 import ctypes
+import hashlib
+import hmac
+import json
 import os
-import pickle
 import queue
 import socket
 import struct
@@ -149,9 +151,109 @@ class ThreadComm(Comm):
         return ThreadComm(w, self.rank)
 
 
+# ---- wire format of SocketComm: data only.  Nothing that arrives on the socket is ever executed or imported (no pickle): a
+# message is a tree of None / bool / int / float / str / bytes / list / tuple / dict / numpy arrays and scalars (structured record
+# arrays included), written as one tag byte per node, little-endian lengths and the raw array bytes.
+def _pack(obj, out):
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)) and -(1 << 63) <= int(obj) < (1 << 63):
+        out.append(b"i" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"d" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, str):
+        b = obj.encode("utf-8")
+        out.append(b"s" + struct.pack("<q", len(b)) + b)
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"b" + struct.pack("<q", len(obj)) + bytes(obj))
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"l" if isinstance(obj, list) else b"t") + struct.pack("<q", len(obj)))
+        for o in obj:
+            _pack(o, out)
+    elif isinstance(obj, dict):
+        out.append(b"m" + struct.pack("<q", len(obj)))
+        for k, v in obj.items():
+            _pack(k, out)
+            _pack(v, out)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError("SocketComm: object arrays do not travel")
+        a = np.ascontiguousarray(obj)
+        head = json.dumps([a.dtype.descr if a.dtype.names else a.dtype.str, list(a.shape)]).encode("ascii")
+        out.append(b"a" + struct.pack("<qq", len(head), a.nbytes) + head)
+        out.append(a.tobytes())
+    else:
+        raise TypeError("SocketComm cannot send a %s" % type(obj).__name__)
+
+
+def _unpack(buf, pos=0):
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b"N":
+        return None, pos
+    if tag in (b"T", b"F"):
+        return tag == b"T", pos
+    if tag == b"i":
+        return struct.unpack_from("<q", buf, pos)[0], pos + 8
+    if tag == b"d":
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if tag in (b"s", b"b"):
+        n = struct.unpack_from("<q", buf, pos)[0]
+        raw = bytes(buf[pos + 8:pos + 8 + n])
+        if n < 0 or len(raw) != n:
+            raise ValueError("SocketComm: truncated message")
+        return (raw.decode("utf-8") if tag == b"s" else raw), pos + 8 + n
+    if tag in (b"l", b"t"):
+        n = struct.unpack_from("<q", buf, pos)[0]
+        pos += 8
+        items = []
+        for _ in range(n):
+            o, pos = _unpack(buf, pos)
+            items.append(o)
+        return (items if tag == b"l" else tuple(items)), pos
+    if tag == b"m":
+        n = struct.unpack_from("<q", buf, pos)[0]
+        pos += 8
+        d = {}
+        for _ in range(n):
+            k, pos = _unpack(buf, pos)
+            v, pos = _unpack(buf, pos)
+            d[k] = v
+        return d, pos
+    if tag == b"a":
+        nh, nb = struct.unpack_from("<qq", buf, pos)
+        pos += 16
+        descr, shape = json.loads(bytes(buf[pos:pos + nh]).decode("ascii"))
+        pos += nh
+        dtype = np.dtype([tuple(f) for f in descr]) if isinstance(descr, list) else np.dtype(descr)
+        if dtype.hasobject or nb != dtype.itemsize * int(np.prod(shape, dtype=np.int64)) or pos + nb > len(buf):
+            raise ValueError("SocketComm: malformed array")
+        a = np.frombuffer(buf, dtype=dtype, count=nb // dtype.itemsize if dtype.itemsize else 0, offset=pos).reshape(shape).copy()
+        return a, pos + nb
+    raise ValueError("SocketComm: unknown tag %r" % tag)
+
+
+def wire_dumps(obj):
+    out = []
+    _pack(obj, out)
+    return b"".join(out)
+
+
+def wire_loads(buf):
+    obj, pos = _unpack(memoryview(buf).tobytes() if not isinstance(buf, bytes) else buf, 0)
+    if pos != len(buf):
+        raise ValueError("SocketComm: trailing bytes")
+    return obj
+
+
 class SocketComm(Comm):
     """Control-plane transport over plain TCP sockets (stdlib only): rank 0 listens on (addr, port), every other rank
-    connects once; a collective is "send my pickled object to rank 0, receive the list of everybody's".  Messages are a
+    connects once; a collective is "send my object to rank 0, receive the list of everybody's" in the data-only wire format above
+    (never pickle: whoever reaches the port cannot make a rank execute anything).  The handshake carries the rank; rank 0 refuses
+    ranks outside 1 .. size-1 and duplicates.  With a shared secret (``secret=`` or MALSTROEM_COMM_SECRET in the launcher's
+    environment) every connection must answer an HMAC-SHA256 challenge first.  Messages are a
     few rows at most (the boundary systems of the label / watershed protocols, the 128-byte ncclUniqueId), so the star
     topology is not a bottleneck; the rows of the fills travel over RCCL, not through here.
 
@@ -159,8 +261,11 @@ class SocketComm(Comm):
 
     one_rank_per_device = True   # ranks are processes, by convention one per GPU: BandPipeline may put the rows on RCCL
 
-    def __init__(self, rank, size, addr="127.0.0.1", port=29517, timeout_s=300.0, _socks=None):
+    def __init__(self, rank, size, addr="127.0.0.1", port=29517, timeout_s=300.0, _socks=None, secret=None):
         self.rank, self.size, self._addr, self._port, self._timeout = int(rank), int(size), addr, int(port), float(timeout_s)
+        if secret is None:
+            secret = os.environ.get("MALSTROEM_COMM_SECRET")
+        self._secret = secret.encode("utf-8") if isinstance(secret, str) else secret
         self._lock = threading.Lock()
         self._nclones = 0
         if _socks is not None:
@@ -178,9 +283,19 @@ class SocketComm(Comm):
             try:
                 while len(self._peers) < self.size - 1:
                     conn, _ = srv.accept()
-                    conn.settimeout(self._timeout)
-                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    r = struct.unpack("<i", self._recv_exact(conn, 4))[0]
+                    try:
+                        conn.settimeout(self._timeout)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        nonce = os.urandom(32)
+                        conn.sendall(nonce)
+                        r = struct.unpack("<i", self._recv_exact(conn, 4))[0]
+                        mac = self._recv_exact(conn, 32)
+                        want = hmac.new(self._secret or b"", nonce + struct.pack("<i", r), hashlib.sha256).digest()
+                        if not (1 <= r < self.size) or r in self._peers or not hmac.compare_digest(mac, want):
+                            raise ConnectionError("SocketComm: connection refused (rank %d, duplicate or bad credentials)" % r)
+                    except (OSError, struct.error, ConnectionError):
+                        conn.close()        # a stray or hostile connection: drop it and keep listening for the real ranks
+                        continue
                     self._peers[r] = conn
             finally:
                 srv.close()
@@ -196,7 +311,9 @@ class SocketComm(Comm):
                         raise
                     time.sleep(0.05)
             self._hub.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            self._hub.sendall(struct.pack("<i", self.rank))
+            nonce = self._recv_exact(self._hub, 32)
+            me = struct.pack("<i", self.rank)
+            self._hub.sendall(me + hmac.new(self._secret or b"", nonce + me, hashlib.sha256).digest())
 
     @classmethod
     def from_env(cls, env=None):
@@ -232,13 +349,13 @@ class SocketComm(Comm):
                 parts = [None] * self.size
                 parts[0] = obj
                 for r, conn in self._peers.items():
-                    parts[r] = pickle.loads(self._recv_msg(conn))
-                blob = pickle.dumps(parts, protocol=pickle.HIGHEST_PROTOCOL)
+                    parts[r] = wire_loads(self._recv_msg(conn))
+                blob = wire_dumps(parts)
                 for conn in self._peers.values():
                     self._send_msg(conn, blob)
                 return parts
-            self._send_msg(self._hub, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
-            return pickle.loads(self._recv_msg(self._hub))
+            self._send_msg(self._hub, wire_dumps(obj))
+            return wire_loads(self._recv_msg(self._hub))
 
     def allreduce_max(self, value):
         return max(self.allgather(float(value)))
@@ -253,7 +370,7 @@ class SocketComm(Comm):
     def clone(self):
         """a second, independent set of connections on the next port (collective call)"""
         self._nclones += 1
-        return SocketComm(self.rank, self.size, self._addr, self._port + self._nclones, self._timeout)
+        return SocketComm(self.rank, self.size, self._addr, self._port + self._nclones, self._timeout, secret=self._secret)
 
     def close(self):
         for c in list(self._peers.values()) + ([self._hub] if self._hub else []):
@@ -331,7 +448,8 @@ class HipBand(object):
     def __init__(self, H_global, W, row0, nrows, device=0, rank=0, size=1, unique_id=None):
         """``unique_id``: the 128 bytes of rank 0's ``HipBand.new_unique_id()``; with it the context joins the RCCL
         communicator of all ``size`` bands (a collective call) and moves its halo rows itself."""
-        self.W, self.nrows = int(W), int(nrows)
+        self.W, self.nrows, self.row0, self.H_global = int(W), int(nrows), int(row0), int(H_global)
+        self.has_side_comm = False
         self._ctx = ctypes.c_void_p()
         uid = None
         if unique_id is not None:
@@ -340,7 +458,12 @@ class HipBand(object):
             uid = ctypes.create_string_buffer(bytes(unique_id), 128)
         _lib.call("mhip_ctx_create_band", ctypes.byref(self._ctx), _lib.i64(H_global), _lib.i64(W), _lib.i64(row0),
                   _lib.i64(nrows), int(device), int(rank), int(size), uid)
-        self.has_comm = bool(_lib.load().mhip_ctx_has_comm(self._ctx))
+        self.has_comm = int(_lib.load().mhip_ctx_has_comm(self._ctx)) >= 1
+
+    @staticmethod
+    def comm_available():
+        """can this process load librccl with every symbol the band transport needs?  (no device call, no collective)"""
+        return bool(_lib.load().mhip_comm_available())
 
     @staticmethod
     def new_unique_id():
@@ -354,6 +477,20 @@ class HipBand(object):
         changed = (ctypes.c_int32 * 2)(0, 0)
         _lib.call("mhip_ctx_exchange_halo", self._ctx, RASTERS[name], changed)
         return bool(changed[0]), bool(changed[1])
+
+    def exchange_edge_rows(self, name):
+        """RCCL neighbour exchange of raster ``name``'s edge rows into HOST arrays, halo rows untouched -> (from_up, from_down);
+        on the thread between side_begin / side_end it runs over the side communicator (add_side_comm)."""
+        dt = RASTER_DTYPE[RASTERS[name]]
+        up = np.empty(self.W, dtype=dt) if self.row0 > 0 else None
+        dn = np.empty(self.W, dtype=dt) if self.row0 + self.nrows < self.H_global else None
+        _lib.call("mhip_ctx_exchange_edge_rows", self._ctx, RASTERS[name], None if up is None else _lib.ptr(up), None if dn is None else _lib.ptr(dn))
+        return up, dn
+
+    def add_side_comm(self, unique_id):
+        """a second RCCL communicator for the labelling thread (collective call)"""
+        _lib.call("mhip_ctx_comm_add_side", self._ctx, ctypes.create_string_buffer(bytes(unique_id), 128))
+        self.has_side_comm = int(_lib.load().mhip_ctx_has_comm(self._ctx)) == 2
 
     def allreduce_max(self, value):
         out = ctypes.c_double(0.0)
@@ -497,6 +634,38 @@ class HipBand(object):
         _lib.call("mhip_ctx_band_relabel_sparse", self._ctx, _lib.i64(nlocal), _lib.i64(offset), _lib.ptr(d), _lib.ptr(t), _lib.i64(d.size),
                   _lib.i64(nlabels_global))
 
+    def relabel_range(self, lo, hi, lut, foreign_ids, foreign_new, nlabels_new):
+        """labels lo..hi -> lut[l - lo]; labels numbered by other bands (sorted ``foreign_ids``) -> ``foreign_new``"""
+        lut = np.ascontiguousarray(lut, dtype=np.int32)
+        fid = np.ascontiguousarray(foreign_ids, dtype=np.int32)
+        fnew = np.ascontiguousarray(foreign_new, dtype=np.int32)
+        _lib.call("mhip_ctx_band_relabel_range", self._ctx, _lib.i64(lo), _lib.i64(hi), _lib.ptr(lut), _lib.ptr(fid), _lib.ptr(fnew), _lib.i64(fid.size),
+                  _lib.i64(nlabels_new))
+
+    def trace(self, cells, src, background_label, geometry):
+        """one leg of the stream walk for walkers standing on this band's owned rows (global cells) ->
+        (label, status, src, exit_cells, geoms): status 0 ended, 1 found ``label``, 2 handed over at ``exit_cells``"""
+        cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int64).reshape(-1, 2))
+        n = cells.shape[0]
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        use_bg = background_label is not None
+        lab, status, src_out = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        exits, lens = np.zeros((n, 2), np.int64), np.zeros(n, np.int64)
+
+        def call(offsets, out_cells):
+            _lib.call("mhip_ctx_band_trace", self._ctx, _lib.ptr(cells), _lib.ptr(src), _lib.i64(n), int(use_bg),
+                      ctypes.c_int32(int(background_label) if use_bg else 0), _lib.ptr(lab), _lib.ptr(status), _lib.ptr(src_out), _lib.ptr(exits),
+                      _lib.ptr(lens), None if offsets is None else _lib.ptr(offsets), None if out_cells is None else _lib.ptr(out_cells))
+        call(None, None)
+        geoms = [None] * n
+        if geometry and n:
+            offsets = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(lens, out=offsets[1:])
+            flat = np.zeros(max(int(offsets[-1]), 1), dtype=np.int64)
+            call(offsets, flat)
+            geoms = [flat[int(offsets[i]):int(offsets[i + 1])] for i in range(n)]
+        return lab, status, src_out, exits, geoms
+
     def watershed_local(self):
         _lib.call("mhip_ctx_band_watershed_local", self._ctx)
 
@@ -517,7 +686,7 @@ class HipBand(object):
         _lib.call("mhip_ctx_side_end", self._ctx)
 
     # per-label records over the OWNED rows, indexed by global label; they stay on the device, the launcher fetches pieces
-    _REC_DTYPE = (STAT_DTYPE, np.dtype(np.int64), INDEX_DTYPE)      # which = 0 stats, 1 watershed counts, 2 pour points
+    _REC_DTYPE = (STAT_DTYPE, np.dtype(np.int64), INDEX_DTYPE, INDEX_DTYPE)      # which = 0 stats, 1 watershed counts, 2 / 3 pour points (arg-max accum / arg-min no-flats)
 
     def records_compute(self, which):
         _lib.call("mhip_ctx_band_records", self._ctx, int(which))
@@ -614,17 +783,30 @@ class BandPipeline(object):
             try:
                 uid = None
                 if rccl and comm.size > 1:
+                    # every rank first says whether it can load RCCL at all (a cheap probe, no collective inside): a rank that
+                    # cannot would return from the band creation at once while the others wait for it in ncclCommInitRank
+                    probe = getattr(factory, "comm_available", None)      # (stand-in backends without the probe: always available)
+                    if comm.allreduce_max(0.0 if (probe is None or probe()) else 1.0) > 0.0:
+                        raise RuntimeError("RCCL cannot be loaded on at least one rank")
                     try:
                         mine = getattr(factory, "new_unique_id", HipBand.new_unique_id)() if comm.rank == 0 else None
                     except Exception as e:
                         mine, err = None, e
-                    uid = comm.allgather(mine)[0]          # every rank takes part, whatever happened on rank 0
+                    mine2 = None
+                    if mine is not None:                    # a second id: the labelling thread gets a communicator of its own
+                        try:
+                            mine2 = getattr(factory, "new_unique_id", HipBand.new_unique_id)()
+                        except Exception:
+                            mine2 = None
+                    uid, uid2 = comm.allgather((mine, mine2))[0]          # every rank takes part, whatever happened on rank 0
                     if uid is None:
                         raise err or RuntimeError("rank 0 could not create an ncclUniqueId")
                 kw = dict(unique_id=uid) if uid is not None else {}
                 self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size, **kw)
                 if uid is not None:                          # one collective before anything depends on the communicator
                     self.band.allreduce_max(float(comm.rank))
+                    if uid2 is not None and hasattr(self.band, "add_side_comm"):
+                        self.band.add_side_comm(uid2)
             except Exception as e:
                 err = err or e
             if comm.allreduce_max(1.0 if err is not None else 0.0) == 0.0:
@@ -639,6 +821,8 @@ class BandPipeline(object):
             self.rccl_error = repr(err) if err is not None else "RCCL setup failed on another rank"
             rccl = False
         self.rccl = bool(getattr(self.band, "has_comm", False))
+        self.rccl_side = self.rccl and bool(getattr(self.band, "has_side_comm", False))
+        self.host_ms = {}      # thread CPU time of the host-serial sections (boundary systems), by stage: see _host()
         self.has_up = comm.rank > 0
         self.has_down = comm.rank < comm.size - 1
         self.exchanges = {"fill": 0, "noflat": 0}
@@ -661,6 +845,22 @@ class BandPipeline(object):
             raise err if err is not None else RuntimeError("another band failed in this stage")
         return m > 0.0
 
+    def _cvote(self, err=None):
+        """Vote on a rank-local failure on the CALLING thread's communicator before the next collective of that thread: either
+        every rank goes on or every rank raises -- a rank that raised alone would leave the others waiting for it."""
+        if self._cur_comm().allreduce_max(1.0 if err is not None else 0.0) > 0.0:
+            raise err if err is not None else RuntimeError("another band failed in this stage")
+
+    def _local(self, fn, *args):
+        """run a band-local step, then vote on it (see _cvote)"""
+        err, out = None, None
+        try:
+            out = fn(*args)
+        except Exception as e:
+            err = e
+        self._cvote(err)
+        return out
+
     def _swap_edges(self, name):
         """Neighbours trade edge rows of raster ``name``; returns which of my halo rows changed (top, bottom)."""
         b = self.band
@@ -672,6 +872,35 @@ class BandPipeline(object):
         ch_top = b.set_halo_row(name, 0, from_up) if self.has_up else False
         ch_bot = b.set_halo_row(name, 1, from_down) if self.has_down else False
         return ch_top, ch_bot
+
+    def _neighbour_rows(self, name):
+        """(from_up, from_down): the neighbours' edge rows of raster ``name`` as host arrays, my halo rows untouched.  Over RCCL
+        when the band owns a communicator for the calling thread, else through the thread's host communicator."""
+        b = self.band
+        on_side = getattr(self._tls, "comm", None) is not None
+        if (self.rccl_side if on_side else self.rccl) and hasattr(b, "exchange_edge_rows"):
+            return b.exchange_edge_rows(name)
+        to_up = b.get_edge_row(name, 0) if self.has_up else None
+        to_down = b.get_edge_row(name, 1) if self.has_down else None
+        return self._cur_comm().exchange_rows(to_up, to_down)
+
+    class _HostSection(object):
+        """``with self._host("label"):`` charges the thread CPU time of a host-only section to ``host_ms[stage]`` (CPU time, not
+        wall clock: several bands of one process take turns on the GIL in the one-GPU rehearsals)"""
+        def __init__(self, owner, stage):
+            self.owner, self.stage = owner, stage
+
+        def __enter__(self):
+            import time
+            self.t0 = time.thread_time()
+
+        def __exit__(self, *exc):
+            import time
+            self.owner.host_ms[self.stage] = self.owner.host_ms.get(self.stage, 0.0) + (time.thread_time() - self.t0) * 1e3
+            return False
+
+    def _host(self, stage):
+        return BandPipeline._HostSection(self, stage)
 
     def upload_dem(self, dem_band):
         """``dem_band``: this rank's owned rows (nrows x W float32).  DEM halo rows are fetched from the neighbours."""
@@ -723,9 +952,14 @@ class BandPipeline(object):
 
     def short_and_diag(self):
         """fill.minimum_safe_short_and_diag on the GLOBAL raster (reference fill.py:235-250)."""
-        mn, mx, _ = self.band.dem_minmax()
-        amax = np.float32(max(self.comm.allgather(float(mx))))
-        amin = np.float32(min(self.comm.allgather(float(mn))))
+        mn, mx, has_nan = self.band.dem_minmax()
+        parts = self.comm.allgather((float(mn), float(mx), bool(has_nan)))
+        amax = np.float32(max(p[1] for p in parts))
+        amin = np.float32(min(p[0] for p in parts))
+        if any(p[2] for p in parts):
+            # np.amax / np.amin propagate NaN (fill.py:246-249), and so does the one-context path (reduce.hip): a NaN cell in ANY
+            # band makes short and diag NaN on every band
+            amax = amin = np.float32("nan")
         maxval = np.float64(max(abs(amax), abs(amin)))
         nextval = np.nextafter(maxval, np.float64(float('inf')))
         short = (nextval - maxval) * 1024
@@ -793,160 +1027,245 @@ class BandPipeline(object):
 
     def flowdir(self):
         """D8 on the no-flats surface, edges outward; afterwards the flow-direction halo rows are valid too."""
-        self.band.run_flowdir()
+        self._local(self.band.run_flowdir)
         self._swap_edges("flowdir")
 
     def accum(self):
-        """flow.accumulated_flow over all bands in two local passes and one all-gather, however often the rivers cross the
-        seams.  Pass 1 (``accum_boundary``) accumulates every band's OWN cells and finds, for each cell of a neighbour's edge
-        row that flows into the band, the edge cell through which that flux leaves the band again; with it the values of all
-        seam-crossing cells form a forest  x[e] = own[e] + sum(x[k] for the k that leave through e)  which every rank solves
-        identically (``solve_band_accum``); pass 2 is the local accumulation with the solved halo rows as known sources."""
-        b, W = self.band, self.W
+        """flow.accumulated_flow over all bands in two local passes, one neighbour exchange and one SMALL all-gather, however
+        often the rivers cross the seams.  Pass 1 (``accum_boundary``) accumulates every band's OWN cells and finds, for each
+        cell of a neighbour's edge row that flows into the band, the edge cell through which that flux leaves the band again
+        (-1: it stays).  Neighbours trade the own-contribution edge rows (RCCL); only the PASS-THROUGH pairs
+        (entering halo cell -> leaving edge cell, with their own contributions) are gathered: they form the forest
+        x[e] = own[e] + sum(x[k] for the k that leave through e), solved identically on every rank (``mhip_band_forest_solve``); every
+        other seam cell carries its own contribution.  Pass 2 is the local accumulation with the halo rows as known sources."""
+        b, W, me = self.band, self.W, self.comm.rank
         self.exchanges["accum"] = 0
-        err, info = None, None
-        try:
-            exit_map = b.accum_boundary()
-            info = dict(a0=(b.get_edge_row("accum", 0), b.get_edge_row("accum", 1)), exit=exit_map)
-        except Exception as e:
-            err = e
-        self._vote(False, err)
-        allinfo = self._cur_comm().allgather(info)
+
+        def local_part():
+            ex = b.accum_boundary()
+            return ex, b.get_edge_row("accum", 0), b.get_edge_row("accum", 1)
+        exit_map, own_first, own_last = self._local(local_part)
+        nbr_up, nbr_dn = self._neighbour_rows("accum")
         self.exchanges["accum"] += 1
-        try:
-            top, bot = solve_band_accum(allinfo, W)[self.comm.rank]
+        with self._host("accum"):
+            own_edge = np.concatenate([own_first, own_last]).astype(np.float64)
+            ch, pa, oc, op = [], [], [], []
+            # node (band, side, column) = (2 * band + side) * W + column; side 0 = first owned row, 1 = last owned row
+            for halo, nbr, base in ((exit_map[:W], nbr_up, (2 * (me - 1) + 1) * W), (exit_map[W:], nbr_dn, (2 * (me + 1)) * W)):
+                if nbr is None:
+                    continue
+                k = np.flatnonzero(halo >= 0)
+                e = halo[k].astype(np.int64)
+                ch.append(base + k)
+                pa.append(2 * me * W + e)
+                oc.append(np.asarray(nbr, dtype=np.float64)[k])
+                op.append(own_edge[e])
+            cat = lambda parts, dt: np.concatenate(parts).astype(dt) if parts else np.zeros(0, dt)
+            mine = (cat(ch, np.int64), cat(pa, np.int64), cat(oc, np.float64), cat(op, np.float64))
+        parts = self._cur_comm().allgather(mine)
+        with self._host("accum"):
+            C = np.concatenate([p[0] for p in parts])
+            P = np.concatenate([p[1] for p in parts])
+            m = C.size
+            top = None if nbr_up is None else np.asarray(nbr_up, dtype=np.float64).copy()
+            bot = None if nbr_dn is None else np.asarray(nbr_dn, dtype=np.float64).copy()
+            if m:
+                nodes, inv = np.unique(np.concatenate([C, P]), return_inverse=True)
+                val = np.zeros(nodes.size, np.float64)
+                val[inv[:m]] = np.concatenate([p[2] for p in parts])
+                val[inv[m:]] = np.concatenate([p[3] for p in parts])
+                parent = np.full(nodes.size, -1, np.int64)
+                parent[inv[:m]] = inv[m:]
+                val = np.ascontiguousarray(val)
+                _lib.call("mhip_band_forest_solve", _lib.i64(nodes.size), _lib.ptr(parent), _lib.ptr(val))
+                for row, base in ((top, (2 * (me - 1) + 1) * W), (bot, (2 * (me + 1)) * W)):
+                    if row is not None:
+                        lo, hi = np.searchsorted(nodes, [base, base + W])
+                        row[nodes[lo:hi] - base] = val[lo:hi]
+
+        def second_pass():
             if self.has_up:
                 b.set_halo_row("accum", 0, top)
             if self.has_down:
                 b.set_halo_row("accum", 1, bot)
             b.run_accum()
-        except Exception as e:
-            err = e
-        self._vote(False, err)
+        self._local(second_pass)
 
     def label(self):
         """label.connected_components over all bands with scipy's numbering (order of first raster pixel).
 
-        Every band labels its local raster (owned + halo rows); the four boundary rows of every band are gathered,
-        the cross-band equivalences are solved identically on every rank, and each band rewrites its labels through
-        a LUT.  Returns the global number of labels."""
-        import scipy.sparse
-        import scipy.sparse.csgraph
-        b, comm, W = self.band, self._cur_comm(), self.W
+        Every band labels its local raster (owned + halo rows).  Neighbours trade their edge rows of LOCAL labels (RCCL); a band
+        compares each halo row (its own labels) with the neighbour's labels of the same raster row and publishes one
+        (mine, theirs) pair per run -- a few thousand pairs where the rows hold 65536 cells -- together with its phantoms (local
+        components made of halo cells only).  The pairs of all bands are gathered once; every rank finds the classes (union-find,
+        ``mhip_band_union_find``) and derives the numbering of EVERY band from them, so no further exchange is needed; each band
+        rewrites its labels on the device.  Returns the global number of labels."""
+        b, comm, W, R, me = self.band, self._cur_comm(), self.W, self.comm.size, self.comm.rank
         lap = _Lap("label", comm.rank)
-        nloc = b.ccl_local()
-        lap.lap("ccl_local")
-        rows = dict(nloc=nloc, first=b.get_edge_row("labels", 0), last=b.get_edge_row("labels", 1),
-                    top=b.get_edge_row("labels", 2) if self.has_up else None,
-                    bot=b.get_edge_row("labels", 3) if self.has_down else None)
-        lap.lap("edge rows")
-        allrows = comm.allgather(rows)
-        lap.lap("allgather")
-        R = comm.size
+
+        def local_part():
+            n = b.ccl_local()
+            return n, dict(first=b.get_edge_row("labels", 0), last=b.get_edge_row("labels", 1),
+                           top=b.get_edge_row("labels", 2) if self.has_up else None,
+                           bot=b.get_edge_row("labels", 3) if self.has_down else None)
+        nloc, rows = self._local(local_part)
+        lap.lap("ccl_local + edge rows")
+        nbr_up, nbr_dn = self._neighbour_rows("labels")      # the neighbour's LAST row above / FIRST row below, in ITS labels
+        lap.lap("neighbour rows")
         key = lambda r, lab: (np.int64(r) << 32) | lab.astype(np.int64)
-        # equivalences between band r and r+1: r.last == (r+1).top and r.bot == (r+1).first, cell by cell -- one edge per RUN of
-        # equal (a, c) pairs along the row (the cells of a run repeat the same edge; everything below then works on a few
-        # thousand edges instead of 2 W per seam: at W = 65536 and 8 bands this merge was 350 ms of host time on every rank)
-        ea, eb = [], []
-        for r in range(R - 1):
-            up, dn = allrows[r], allrows[r + 1]
-            for a, c in ((up["last"], dn["top"]), (up["bot"], dn["first"])):
-                m = (a > 0) & (c > 0)
-                if a.size > 1:
-                    m[1:] &= (a[1:] != a[:-1]) | (c[1:] != c[:-1])
-                ea.append(key(r, a[m]))
-                eb.append(key(r + 1, c[m]))
-        ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
-        eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
-        nodes, inv = np.unique(np.concatenate([ea, eb]), return_inverse=True)
-        nn = nodes.size
-        if nn:
-            g = scipy.sparse.coo_matrix((np.ones(ea.size, np.int8), (inv[:ea.size], inv[ea.size:])), shape=(nn, nn))
-            ncls, cls = scipy.sparse.csgraph.connected_components(g, directed=False)
-        else:
-            ncls, cls = 0, np.zeros(0, np.int64)
-        node_rank = (nodes >> 32).astype(np.int64)
-        node_lab = (nodes & 0xffffffff).astype(np.int64)
-        # phantom = local component made of halo cells only (no owned cell): in a halo row but not in the adjacent owned row
+
         def run_values(row):
             """the distinct positive labels of a row, from its run starts (a row holds far fewer runs than cells)"""
             keep = row > 0
             if row.size > 1:
                 keep[1:] &= row[1:] != row[:-1]
             return np.unique(row[keep])
-        phantom = np.zeros(nn, bool)
-        bounds = np.searchsorted(node_rank, np.arange(R + 1))     # `nodes` is sorted by (rank, label): rank r = one slice
-        for r in range(R):
-            rr = allrows[r]
-            sl = slice(int(bounds[r]), int(bounds[r + 1]))
-            for halo, edge in ((rr["top"], rr["first"]), (rr["bot"], rr["last"])):
+
+        with self._host("label"):
+            ea, eb, ph = [], [], []
+            for halo, edge, nbr, r_nbr in ((rows["top"], rows["first"], nbr_up, me - 1), (rows["bot"], rows["last"], nbr_dn, me + 1)):
                 if halo is None:
                     continue
-                ph = np.setdiff1d(run_values(halo), run_values(edge), assume_unique=True)
-                if ph.size:
-                    phantom[sl] |= np.isin(node_lab[sl], ph, assume_unique=True)
-        # class owner = smallest rank with a real member; representative = smallest local label of the owner's members
-        big = np.int64(1) << 62
-        score = np.where(phantom, big, (node_rank << 32) | node_lab)
-        rep_score = np.full(ncls, big, np.int64)
-        np.minimum.at(rep_score, cls, score)
-        is_rep = score == rep_score[cls]
-        # ---- my numbering: all local labels except the DROPPED ones (phantoms and non-representative class members) keep
-        # their order; kept local label l becomes offset + l - #(dropped labels < l).  Only the (short) dropped list is
-        # ever materialised: the band's labels are rewritten on the device (relabel_sparse).
-        mine = node_rank == comm.rank
-        dropped = np.unique(node_lab[mine & ~is_rep]).astype(np.int64)
-        n_own = int(nloc - dropped.size)
-        offsets = np.concatenate([[0], np.cumsum(comm.allgather(n_own))])
-        off = int(offsets[comm.rank])
-        newlab = lambda l: off + l - np.searchsorted(dropped, l)      # for kept local labels l
-        # owners publish the global label of the classes they own; members look it up
-        my_reps = mine & is_rep
-        published = comm.allgather((cls[my_reps], newlab(node_lab[my_reps])))
-        class_label = np.zeros(ncls, np.int64)
-        for ids, labs in published:
-            class_label[ids] = labs
-        members = mine & ~is_rep
-        target = np.zeros(dropped.size, np.int64)                        # phantoms own no cell here: any value
-        target[np.searchsorted(dropped, node_lab[members])] = class_label[cls[members]]
-        # global labels with cells in more than one band (same array on every rank): their records need a merge
-        real = ~phantom
-        pairs = np.unique(cls[real].astype(np.int64) * R + node_rank[real]) if real.any() else np.zeros(0, np.int64)   # (class, rank)
-        ranks_per_class = np.bincount(pairs // R, minlength=ncls) if ncls else np.zeros(0, np.int64)
-        self.shared_labels = np.unique(class_label[np.flatnonzero(ranks_per_class > 1)]).astype(np.int64)
-        self.nlabels = int(offsets[-1])
-        self.label_range = (int(offsets[comm.rank]) + 1, int(offsets[comm.rank + 1]))
+                nbr = np.asarray(nbr)
+                m = (halo > 0) & (nbr > 0)          # one pair per RUN of equal (mine, theirs) along the row
+                if W > 1:
+                    m[1:] &= (halo[1:] != halo[:-1]) | (nbr[1:] != nbr[:-1])
+                ea.append(key(me, halo[m]))
+                eb.append(key(r_nbr, nbr[m]))
+                # phantom = a local component without an owned cell: in the halo row but not in the adjacent owned row
+                ph.append(np.setdiff1d(run_values(halo), run_values(edge), assume_unique=True))
+            cat = lambda parts: np.concatenate(parts).astype(np.int64) if parts else np.zeros(0, np.int64)
+            mine = dict(nloc=int(nloc), ea=cat(ea), eb=cat(eb), ph=np.unique(cat(ph)))
+        allp = comm.allgather(mine)
+        lap.lap("allgather")
+        with self._host("label"):
+            EA = np.concatenate([p["ea"] for p in allp])
+            EB = np.concatenate([p["eb"] for p in allp])
+            phk = np.concatenate([key(r, p["ph"]) for r, p in enumerate(allp)])      # phantoms may touch no foreground above / below:
+            nodes, inv = np.unique(np.concatenate([EA, EB, phk]), return_inverse=True)   # they are nodes all the same (dropped labels)
+            nn = nodes.size
+            root = np.zeros(nn, np.int64)
+            if nn:
+                ia, ib = np.ascontiguousarray(inv[:EA.size]), np.ascontiguousarray(inv[EA.size:2 * EA.size])
+                _lib.call("mhip_band_union_find", _lib.i64(nn), _lib.i64(EA.size), _lib.ptr(ia), _lib.ptr(ib), _lib.ptr(root))
+            _, cls = np.unique(root, return_inverse=True)
+            ncls = int(cls.max()) + 1 if nn else 0
+            node_rank = (nodes >> 32).astype(np.int64)
+            node_lab = (nodes & 0xffffffff).astype(np.int64)
+            phantom = np.isin(nodes, phk, assume_unique=False)
+            # class owner = smallest rank with a real member; representative = smallest local label of the owner's members
+            big = np.int64(1) << 62
+            score = np.where(phantom, big, nodes)
+            rep_score = np.full(ncls, big, np.int64)
+            np.minimum.at(rep_score, cls, score)
+            is_rep = score == rep_score[cls]
+            # ---- the numbering of every band: all local labels except the DROPPED ones (phantoms and non-representative class
+            # members) keep their order; kept local label l becomes offset + l - #(dropped labels < l).  `nodes` is sorted by
+            # (rank, label), so the dropped labels of a rank are a sorted slice.
+            bounds = np.searchsorted(node_rank, np.arange(R + 1))
+            drop_of = [node_lab[bounds[r]:bounds[r + 1]][~is_rep[bounds[r]:bounds[r + 1]]] for r in range(R)]
+            n_own = [allp[r]["nloc"] - drop_of[r].size for r in range(R)]
+            offsets = np.concatenate([[0], np.cumsum(n_own)]).astype(np.int64)
+            # global label of a class = the new label of its representative, computed from the representative's band's numbering
+            reps = np.flatnonzero(is_rep)
+            rr, rl = node_rank[reps], node_lab[reps]
+            class_label = np.zeros(ncls, np.int64)
+            newl = np.zeros(reps.size, np.int64)
+            for r in range(R):
+                sel = rr == r
+                if sel.any():
+                    newl[sel] = offsets[r] + rl[sel] - np.searchsorted(drop_of[r], rl[sel])
+            class_label[cls[reps]] = newl
+            dropped = drop_of[me].astype(np.int64)
+            off = int(offsets[me])
+            mine_sl = slice(int(bounds[me]), int(bounds[me + 1]))
+            members = ~is_rep[mine_sl]               # (phantoms included: my halo cells then carry the neighbour's global label)
+            target = np.zeros(dropped.size, np.int64)
+            target[np.searchsorted(dropped, node_lab[mine_sl][members])] = class_label[cls[mine_sl][members]]
+            # global labels with cells in more than one band (same array on every rank): their records need a merge
+            real = ~phantom
+            pairs = np.unique(cls[real].astype(np.int64) * R + node_rank[real]) if real.any() else np.zeros(0, np.int64)   # (class, rank)
+            ranks_per_class = np.bincount(pairs // R, minlength=ncls) if ncls else np.zeros(0, np.int64)
+            self.shared_labels = np.unique(class_label[np.flatnonzero(ranks_per_class > 1)]).astype(np.int64)
+            self.nlabels = int(offsets[-1])
+            self.label_range = (int(offsets[me]) + 1, int(offsets[me + 1]))
+            self.label_offsets = offsets
         lap.lap("merge (host)")
-        b.relabel_sparse(nloc, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels)
+        self._local(b.relabel_sparse, nloc, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels)
         lap.lap("relabel_sparse")
         lap.report()
         return self.nlabels
 
     def watershed(self):
-        """flow.watersheds_from_labels over all bands: local pointer jumping with pseudo labels on the halo rows, then the
-        boundary system (2 rows per band) is solved identically on every rank and applied as a LUT."""
-        b, comm, W = self.band, self._cur_comm(), self.W
-        b.watershed_local()
-        rows = comm.allgather((b.get_edge_row("watersheds", 0), b.get_edge_row("watersheds", 1)))
-        R = comm.size
-        # node(r, s, c) = (2r + s) * W + c for the first (s=0) / last (s=1) owned row of band r
-        vals = np.concatenate([np.concatenate(p) for p in rows]).astype(np.int64)
-        for r in range(R):
-            for s_ in (0, 1):
-                seg = vals[(2 * r + s_) * W:(2 * r + s_ + 1) * W]
-                neg = seg < 0
-                idx = -seg[neg] - 1
-                up = idx < W          # pseudo label of band r's top halo = last owned row of band r-1
-                tgt = np.where(up, (2 * (r - 1) + 1) * W + idx, (2 * (r + 1)) * W + (idx - W))
-                seg[neg] = -(tgt + 1)
-        vals = np.ascontiguousarray(vals)
-        _lib.call("mhip_band_ws_resolve", _lib.i64(vals.size), _lib.ptr(vals))   # chains followed to their end; a flow cycle across bands: 0
-        lut = np.zeros(2 * W, np.int64)
-        if self.has_up:
-            lut[:W] = vals[(2 * (comm.rank - 1) + 1) * W:(2 * (comm.rank - 1) + 2) * W]
-        if self.has_down:
-            lut[W:] = vals[(2 * (comm.rank + 1)) * W:(2 * (comm.rank + 1) + 1) * W]
-        b.apply_neg_lut("watersheds", lut.astype(np.int32))
+        """flow.watersheds_from_labels over all bands: local pointer jumping with pseudo labels on the halo rows (a cell whose path
+        leaves the band through halo column k carries -(1 + k), bottom halo: -(1 + W + k)), then the pseudo labels are resolved
+        through the neighbours' edge rows.  Neighbours trade their edge rows (RCCL): most paths end at a label right there.  What
+        is left are paths that bounce back or cross a whole band; only the edge cells on such paths are gathered -- a cell is
+        published when the neighbour points at it or when its own target is unresolved as well -- and every rank follows the
+        chains to their end (``mhip_band_ws_resolve``; a flow cycle across bands stays unassigned like in _flow.pyx:276-314)."""
+        b, comm, W, me = self.band, self._cur_comm(), self.W, self.comm.rank
+        lap = _Lap("watershed", comm.rank)
+
+        def local_part():
+            b.watershed_local()
+            return b.get_edge_row("watersheds", 0), b.get_edge_row("watersheds", 1)
+        first, last = self._local(local_part)
+        lap.lap("watershed_local + edge rows")
+        nbr_up, nbr_dn = self._neighbour_rows("watersheds")      # the neighbour's LAST row above / FIRST row below
+        lap.lap("neighbour rows")
+        with self._host("watershed"):
+            up64 = None if nbr_up is None else np.asarray(nbr_up).astype(np.int64)
+            dn64 = None if nbr_dn is None else np.asarray(nbr_dn).astype(np.int64)
+            mine = np.concatenate([first, last]).astype(np.int64)        # index e = side * W + column; node (me, side, column) = 2 me W + e
+            neg = np.flatnonzero(mine < 0)
+            idx = -mine[neg] - 1
+            to_up = idx < W
+            tgt_node = np.where(to_up, (2 * (me - 1) + 1) * W + idx, (2 * (me + 1)) * W + (idx - W))
+            tgt_val = np.zeros(neg.size, np.int64)
+            if up64 is not None:
+                tgt_val[to_up] = up64[idx[to_up]]
+            if dn64 is not None:
+                tgt_val[~to_up] = dn64[idx[~to_up] - W]
+            entry = np.where(tgt_val >= 0, tgt_val, -(tgt_node + 1))
+            pointed = np.zeros(2 * W, bool)
+            if up64 is not None:        # their pseudo labels >= W point at their bottom halo = my first row
+                j = -up64[up64 < 0] - 1
+                pointed[j[j >= W] - W] = True
+            if dn64 is not None:        # their pseudo labels < W point at their top halo = my last row
+                j = -dn64[dn64 < 0] - 1
+                pointed[W + j[j < W]] = True
+            pub = pointed[neg] | (tgt_val < 0)
+            mine_pub = ((2 * me * W + neg[pub]).astype(np.int64), entry[pub].astype(np.int64))
+        parts = comm.allgather(mine_pub)
+        with self._host("watershed"):
+            N = np.concatenate([p[0] for p in parts])
+            V = np.concatenate([p[1] for p in parts])
+            order = np.argsort(N)
+            N, V = N[order], V[order]
+            ptr = V < 0
+            if ptr.any():
+                t = -V[ptr] - 1
+                pos = np.searchsorted(N, t)
+                ok = (pos < N.size) & (N[np.minimum(pos, max(N.size - 1, 0))] == t) if N.size else np.zeros(t.size, bool)
+                V[ptr] = np.where(ok, -(pos + 1), 0)          # (a target nobody published: nobody needs it either)
+                V = np.ascontiguousarray(V)
+                _lib.call("mhip_band_ws_resolve", _lib.i64(V.size), _lib.ptr(V))
+            lut = np.zeros(2 * W, np.int64)
+            for row, base, sl in ((up64, (2 * (me - 1) + 1) * W, slice(0, W)), (dn64, (2 * (me + 1)) * W, slice(W, 2 * W))):
+                if row is None:
+                    continue
+                r = row.copy()
+                k = np.flatnonzero(r < 0)
+                if k.size:
+                    pos = np.searchsorted(N, base + k)
+                    pos_c = np.minimum(pos, max(N.size - 1, 0))
+                    found = (pos < N.size) & (N[pos_c] == base + k) if N.size else np.zeros(k.size, bool)
+                    r[k] = np.where(found, V[pos_c] if N.size else 0, 0)
+                lut[sl] = r
+        lap.lap("seam system (host + allgather)")
+        self._local(b.apply_neg_lut, "watersheds", lut.astype(np.int32))
+        lap.lap("apply_neg_lut")
+        lap.report()
 
     # ---- per-label records (reference bluespots.py:159-206 on one raster).  Every rank returns the records of the labels
     # IT numbered (``label_range``, complete after the merge) plus the background record; a label or a watershed that
@@ -961,14 +1280,13 @@ class BandPipeline(object):
         band's own labels stays on the device, like the records of the single-GPU pipeline until somebody asks for them)"""
         b, (lo, hi) = self.band, self.label_range
         lap = _Lap("records %d" % which, self.comm.rank)
-        b.records_compute(which)
-        lap.lap("compute")
         ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
-        g = b.records_gather(which, ids)
-        lap.lap("gather %d" % ids.size)
+        g = self._local(lambda: (b.records_compute(which), b.records_gather(which, ids))[1])
+        lap.lap("compute + gather %d" % ids.size)
         parts = self._cur_comm().allgather(g)
         lap.lap("allgather")
-        m = merge(parts)
+        with self._host("records"):
+            m = merge(parts)
         lap.lap("merge")
         lap.report()
         if not fetch_own:
@@ -994,10 +1312,15 @@ class BandPipeline(object):
         """label.label_count(watersheds): cells per watershed.  A watershed may reach into any band, so every rank publishes
         its non-zero counts of labels it did not number (a sparse handful) and adds what the others found of its own."""
         b, (lo, hi) = self.band, self.label_range
-        b.records_compute(1)
-        own = b.records_fetch(1, lo, hi - lo + 1) if fetch_own else None
-        fid, fval = b.foreign_counts(lo, hi)
-        bg = int(b.records_fetch(1, 0, 1)[0])
+        def local_part():
+            b.records_compute(1)
+            own_ = b.records_fetch(1, lo, hi - lo + 1) if fetch_own else None
+            fid_, fval_ = b.foreign_counts(lo, hi)
+            return own_, fid_, fval_, int(b.records_fetch(1, 0, 1)[0])
+        lap = _Lap("watershed_counts", self.comm.rank)
+        own, fid, fval, bg = self._local(local_part)
+        lap.lap("compute + fetch + foreign %d" % fid.size)
+        lap.report()
         total0 = 0
         for r, (ids, vals, c0) in enumerate(self._cur_comm().allgather((fid, fval, bg))):
             total0 += c0
@@ -1006,17 +1329,124 @@ class BandPipeline(object):
                 np.add.at(own, ids[mine] - lo, vals[mine])
         return {"first_label": lo, "records": own, "background": np.int64(total0)}
 
-    def pourpoints(self, fetch_own=True):
-        """label.label_max_index(accum, labels): value, row, col of the first raster cell with the largest accumulated
-        flow per bluespot (rows are global)."""
+    def pourpoints(self, fetch_own=True, use_accum=True):
+        """label.label_max_index(accum, labels) -- or label.label_min_index(no-flats surface, labels) when no accumulated flow
+        was asked for (reference bluespots.py:195-206): value, row, col of the first raster cell with the extreme value per
+        bluespot (rows are global)."""
         def merge(parts):
             m = parts[0].copy()
             for p in parts[1:]:
-                # strict '>' with the first raster position on ties: bands are in raster order, so an earlier band wins ties
-                better = (p["value"] > m["value"]) | ((m["row"] < 0) & (p["row"] >= 0))
+                # strict comparison with the first raster position on ties: bands are in raster order, an earlier band wins ties
+                better = (p["value"] > m["value"]) if use_accum else (p["value"] < m["value"])
+                better |= (m["row"] < 0) & (p["row"] >= 0)
+                better &= p["row"] >= 0
                 m[better] = p[better]
             return m
-        return self._merged(2, merge, fetch_own)
+        return self._merged(2 if use_accum else 3, merge, fetch_own)
+
+    # ---- the bluespot filter on bands (reference bluespots.py:23-46, 165-172)
+    def filter(self, keep_of_records):
+        """Keeps the bluespots for which ``keep_of_records(stats_records_of_my_labels) -> bool array`` holds and renumbers the rest
+        1..n in raster order (the reference relabels the kept mask with a second connected_components run, which numbers the
+        kept bluespots in the same order).  Every rank decides about the labels IT numbered (their records are complete after
+        the merge), the kept counts give the new numbering, and a bluespot that reaches into other bands is looked up in a
+        short published list.  Returns the new global number of labels."""
+        b, comm, me = self.band, self._cur_comm(), self.comm.rank
+        lo, hi = self.label_range
+        st = self.stats(fetch_own=True)
+        with self._host("filter"):
+            keep = np.asarray(keep_of_records(st["records"]), dtype=bool)
+            if keep.shape != (hi - lo + 1,):
+                raise ValueError("the filter must return one boolean per record")
+            nkept = int(keep.sum())
+        counts = comm.allgather(nkept)
+        with self._host("filter"):
+            off = int(np.sum(counts[:me]))
+            lut = np.where(keep, off + np.cumsum(keep), 0).astype(np.int64)            # new label of my label lo + i
+            sh = self.shared_labels
+            mine_sh = sh[(sh >= lo) & (sh <= hi)]
+            pub = (mine_sh.astype(np.int64), lut[mine_sh - lo].astype(np.int64))
+        published = comm.allgather(pub)
+        with self._host("filter"):
+            ids = np.concatenate([p[0] for p in published])
+            new = np.concatenate([p[1] for p in published])
+            order = np.argsort(ids)
+            ids, new = ids[order], new[order]
+            foreign = (ids < lo) | (ids > hi)
+            self.nlabels = int(np.sum(counts))
+            self.label_range = (off + 1, off + nkept)
+            self.shared_labels = np.unique(new[new > 0]).astype(np.int64)
+        self._local(b.relabel_range, lo, hi, lut.astype(np.int32), ids[foreign].astype(np.int32), new[foreign].astype(np.int32), self.nlabels)
+        return self.nlabels
+
+    # ---- the stream walk across bands (reference net.py:142-169; one leg per band: csrc/trace.hip band_trace_kernel)
+    def trace_downstream(self, cells, background_label=None, geometry=False):
+        """``next_downstream_label`` for many cells of the GLOBAL raster.  Every rank passes the same ``cells`` (global (row, col),
+        e.g. the merged pour points); a walker is started by the band that owns its cell, walks while it stays on that band's
+        rows and is handed to the neighbour when it steps across a seam (one small all-gather per hop: walker id, source label,
+        cell), until no walker is left.  Returns ``(labels, geoms)`` like ``algorithms.net.trace_downstream_labels`` -- the same
+        on every rank: ``labels[i]`` int or None, ``geoms[i]`` a list of (row, col) (empty unless ``geometry``)."""
+        b, comm, W, me = self.band, self._cur_comm(), self.W, self.comm.rank
+        cells = np.asarray(list(cells), dtype=np.int64).reshape(-1, 2)
+        n = cells.shape[0]
+        owned = lambda rows: (rows >= self.row0) & (rows < self.row0 + self.nrows)
+        ids = np.flatnonzero(owned(cells[:, 0]))
+        cur_cells, cur_src = cells[ids], np.full(ids.size, -1, np.int32)
+        results = {}           # walker id -> (label or None)
+        legs = []              # (walker id, hop number, cells of that leg)
+        hop = 0
+        while True:
+            def leg():
+                return b.trace(cur_cells, cur_src, background_label, geometry) if ids.size else (np.zeros(0, np.int32),) * 3 + (np.zeros((0, 2), np.int64), [])
+            lab, status, src_out, exits, geoms = self._local(leg)
+            for k, wid in enumerate(ids.tolist()):
+                if geometry:
+                    legs.append((wid, hop, geoms[k]))
+                if status[k] == 1:
+                    results[wid] = int(lab[k])
+                elif status[k] == 0:
+                    results[wid] = None
+            go = status == 2
+            handed = comm.allgather((ids[go].astype(np.int64), src_out[go].astype(np.int32), exits[go].astype(np.int64)))
+            all_ids = np.concatenate([h[0] for h in handed])
+            if all_ids.size == 0:
+                break
+            all_src = np.concatenate([h[1] for h in handed])
+            all_ex = np.concatenate([h[2] for h in handed]).reshape(-1, 2)
+            take = owned(all_ex[:, 0])
+            ids, cur_src, cur_cells = all_ids[take], all_src[take], all_ex[take]
+            hop += 1
+            if hop > self.H * self.W:       # (a walker bouncing forever between two bands: a flow cycle across a seam)
+                for wid in all_ids.tolist():
+                    results.setdefault(wid, None)
+                break
+        merged = comm.allgather((results, legs if geometry else []))
+        labels = [None] * n
+        parts = {}
+        for res, lg in merged:
+            for wid, l in res.items():
+                labels[int(wid)] = l
+            for wid, h, cells_ in lg:
+                parts.setdefault(int(wid), []).append((int(h), cells_))
+        geoms = [[] for _ in range(n)]
+        if geometry:
+            for wid, pieces in parts.items():
+                flat = np.concatenate([c for _, c in sorted(pieces, key=lambda t: t[0])]) if pieces else np.zeros(0, np.int64)
+                rows, cols = np.divmod(flat, W)
+                geoms[wid] = list(zip(rows.tolist(), cols.tolist()))
+        return labels, geoms
+
+    def gather_rows(self, name, max_rows=1024):
+        """The raster ``name`` of the whole DEM, band after band in pieces of ``max_rows`` rows: yields (row0, rows) on rank 0 and
+        (row0, None) on the other ranks (every rank iterates in step: one collective per piece)."""
+        comm = self._cur_comm()
+        extents = comm.allgather((self.row0, self.nrows))
+        mine = self.band.download(name) if self.nrows else None
+        for r, (r0, nr) in enumerate(extents):
+            for a in range(0, nr, int(max_rows)):
+                piece = mine[a:a + int(max_rows)] if r == self.comm.rank else None
+                got = comm.allgather(piece)[r]
+                yield r0 + a, (got if self.comm.rank == 0 else None)
 
     # ---- the whole chain with the stage DAG of mhip_ctx_run: labelling (+ stats) on a second host thread, a second
     # communicator and the band's side stream, next to no-flats fill -> D8 -> accumulation
@@ -1036,7 +1466,7 @@ class BandPipeline(object):
         out = {"stats": None, "counts": None, "pour": None}
         if overlap and not hasattr(self, "_comm_b"):
             self._comm_b = self.comm.clone()
-        err = []
+        err, err_side = [], []      # failures of the main thread / of the labelling thread
 
         def label_branch():
             try:
@@ -1047,14 +1477,14 @@ class BandPipeline(object):
                 if records:
                     out["stats"] = timed("label", lambda: self.stats(fetch_own))
             except Exception as e:      # re-raised on the main thread
-                err.append(e)
+                err_side.append(e)
             finally:
                 self._tls.comm = None
                 if hasattr(self.band, "side_end"):
                     try:
                         self.band.side_end()
                     except Exception as e:
-                        err.append(e)
+                        err_side.append(e)
 
         def ws_branch():
             try:
@@ -1065,14 +1495,14 @@ class BandPipeline(object):
                 if records:
                     out["counts"] = timed("watershed", lambda: self.watershed_counts(fetch_own))
             except Exception as e:
-                err.append(e)
+                err_side.append(e)
             finally:
                 self._tls.comm = None
                 if hasattr(self.band, "side_end"):
                     try:
                         self.band.side_end()
                     except Exception as e:
-                        err.append(e)
+                        err_side.append(e)
 
         if not overlap:
             timed("noflat", self.noflat)
@@ -1093,10 +1523,12 @@ class BandPipeline(object):
         import sys
         old_switch = sys.getswitchinterval()
         sys.setswitchinterval(1e-4)
+        flowdir_failed = []
+
         def together(main_steps, side):
-            """main_steps on this thread next to `side` on a second one; failures on either thread of ANY rank are voted
-            on (host communicator) after the join, so that all ranks raise together instead of one rank leaving the others
-            inside their next collective"""
+            """main_steps on this thread next to `side` on a second one.  Every stage votes on its rank-local failures before its
+            next collective (_cvote / _vote), so a failure surfaces on EVERY rank at the same point of the same thread; the vote
+            after the join makes all ranks raise together whichever thread it was."""
             th = threading.Thread(target=side)
             th.start()
             try:
@@ -1106,35 +1538,37 @@ class BandPipeline(object):
                 err.append(e)
             finally:
                 th.join()
-            if self.comm.allreduce_max(1.0 if err else 0.0) > 0.0:
-                raise err[0] if err else RuntimeError("another band failed in this phase of the chain")
+            if self.comm.allreduce_max(1.0 if (err or err_side) else 0.0) > 0.0:
+                raise (err + err_side)[0] if (err or err_side) else RuntimeError("another band failed in this phase of the chain")
 
         try:
-            if os.environ.get("MALSTROEM_BAND_LABEL_START", "noflat") == "fill":
-                together([("noflat", self.noflat), ("flowdir", self.flowdir)], label_branch)
-                together([("accum", self.accum)], ws_branch)
-            else:
-                # like the single-GPU DAG (csrc/api.hip, measured there): the no-flats fill has the GPU to itself -- its many small
-                # launches queue behind the labelling's long workgroups otherwise -- then labelling + watersheds (the latter
-                # need labels and flow directions) run next to D8 + accumulation
-                timed("noflat", self.noflat)
-                if self.comm.allreduce_max(0.0) > 0.0:      # (keeps the bands in step before the two-thread phase)
-                    raise RuntimeError("another band failed in the no-flats fill")
-                flow_ready = threading.Event()
+            # like the single-GPU DAG (csrc/api.hip, measured there): the no-flats fill has the GPU to itself -- its many small
+            # launches queue behind the labelling's long workgroups otherwise -- then labelling + watersheds (the latter
+            # need labels and flow directions) run next to D8 + accumulation
+            timed("noflat", self.noflat)
+            if self.comm.allreduce_max(0.0) > 0.0:      # (keeps the bands in step before the two-thread phase)
+                raise RuntimeError("another band failed in the no-flats fill")
+            flow_ready = threading.Event()
 
-                def flowdir_then_signal():
-                    try:
-                        self.flowdir()
-                    finally:
-                        flow_ready.set()
+            def flowdir_then_signal():
+                try:
+                    self.flowdir()
+                except Exception:
+                    flowdir_failed.append(True)     # (the same on every rank: flowdir() votes before it raises)
+                    raise
+                finally:
+                    flow_ready.set()
 
-                def side():
-                    label_branch()
-                    flow_ready.wait()
-                    if not err:
-                        ws_branch()
+            def side():
+                label_branch()
+                flow_ready.wait()
+                # whether the watershed branch runs is a COLLECTIVE decision on the side communicator: the facts it rests on
+                # (label failed, flowdir failed) are the same on every rank, the vote makes sure of it
+                bad = 1.0 if (err_side or flowdir_failed) else 0.0
+                if self._comm_b.allreduce_max(bad) == 0.0:
+                    ws_branch()
 
-                together([("flowdir", flowdir_then_signal), ("accum", self.accum)], side)
+            together([("flowdir", flowdir_then_signal), ("accum", self.accum)], side)
         finally:
             sys.setswitchinterval(old_switch)
         if records:

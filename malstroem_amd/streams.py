@@ -35,23 +35,28 @@ class StreamTool(object):
         else:
             nodes = net.pourpoint_network(flowdir, labeled, pourpoints_pix, 0, pipeline=self.pipeline)
         self.logger.info("Writing {} nodes".format(len(nodes)))
-        pp_index = {pp['properties']['bspot_id']: pp for pp in pourpoints}
-        geojson_nodes = []
-        for n in nodes:
-            props = dict(nodeid=n['id'], dstrnodeid=n['downstream_id'], nodetype=n['nodetype'], cell_row=n['pix'][0], cell_col=n['pix'][1],
-                         bspot_id=None, bspot_area=0.0, bspot_vol=0.0, wshed_area=0.0)      # defaults of a junction node
-            ppoint = pp_index.get(n['id'], None)
-            if ppoint:
-                for key in ('bspot_id', 'bspot_area', 'bspot_vol', 'wshed_area'):
-                    props[key] = ppoint['properties'][key]
-            coord = transform_cell_to_world(n['pix'], transform)
-            geojson_nodes.append(dict(id=n['id'], geometry=dict(type='Point', coordinates=list(coord)), properties=props))
+        geojson_nodes, streams = nodes_to_features(nodes, pourpoints, transform)
         self.output_nodes.write_geojson_features(geojson_nodes)
         if self.output_streams:
-            streams = []
-            for n in nodes:
-                if n['geometry']:
-                    coords = [transform_cell_to_world(c, transform) for c in n['geometry']]
-                    streams.append(dict(id=n['id'], geometry=dict(type='LineString', coordinates=list(coords)),
-                                        properties=dict(nodeid=n['id'], dstrnodeid=n['downstream_id'])))
             self.output_streams.write_geojson_features(streams)
+
+
+def nodes_to_features(nodes, pourpoints, transform):
+    """(node features, stream features) of the reference's StreamTool output (streams.py:77-124): a node carries the bluespot
+    attributes of its pour point (defaults for a junction), a stream the path from the node to the next one downstream."""
+    pp_index = {pp['properties']['bspot_id']: pp for pp in pourpoints}
+    geojson_nodes, streams = [], []
+    for n in nodes:
+        props = dict(nodeid=n['id'], dstrnodeid=n['downstream_id'], nodetype=n['nodetype'], cell_row=n['pix'][0], cell_col=n['pix'][1],
+                     bspot_id=None, bspot_area=0.0, bspot_vol=0.0, wshed_area=0.0)      # defaults of a junction node
+        ppoint = pp_index.get(n['id'], None)
+        if ppoint:
+            for key in ('bspot_id', 'bspot_area', 'bspot_vol', 'wshed_area'):
+                props[key] = ppoint['properties'][key]
+        coord = transform_cell_to_world(n['pix'], transform)
+        geojson_nodes.append(dict(id=n['id'], geometry=dict(type='Point', coordinates=list(coord)), properties=props))
+        if n.get('geometry'):
+            coords = [transform_cell_to_world(c, transform) for c in n['geometry']]
+            streams.append(dict(id=n['id'], geometry=dict(type='LineString', coordinates=list(coords)),
+                                properties=dict(nodeid=n['id'], dstrnodeid=n['downstream_id'])))
+    return geojson_nodes, streams

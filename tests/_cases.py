@@ -115,3 +115,10 @@ def meander_flowdir(h, w, seed):
     rng = np.random.default_rng(seed)
     fd = rng.choice(np.array([1, 2, 3, 0, 4], np.uint8), size=(h, w), p=[0.3, 0.2, 0.3, 0.1, 0.1])
     return fd.astype(np.uint8)
+
+
+def zigzag_flowdir(h, w, seed):
+    """Every cell flows to the right, straight or diagonally (codes 1, 2, 3 at random): acyclic, and a path crosses a row seam
+    every few cells, bouncing back and forth between neighbouring bands."""
+    rng = np.random.default_rng(seed)
+    return rng.choice(np.array([1, 2, 3], np.uint8), size=(h, w), p=[0.4, 0.2, 0.4]).astype(np.uint8)

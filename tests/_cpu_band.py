@@ -27,8 +27,31 @@ class CpuBand(object):
         self.kind_state = {}
 
     def close(self):
-        if self._comm is not None:
-            self._comm.close()
+        for c in (self._comm, getattr(self, "_comm_side", None)):
+            if c is not None:
+                c.close()
+
+    # stand-ins for the side communicator / side stream bracket of the library (mhip_ctx_comm_add_side, mhip_ctx_side_begin)
+    has_side_comm = False
+
+    def add_side_comm(self, unique_id):
+        import struct
+        from malstroem_amd.distributed import SocketComm
+        self._comm_side = SocketComm(self.rank, self.size, "127.0.0.1", struct.unpack("<i", unique_id[:4])[0], timeout_s=120)
+        self.has_side_comm = True
+
+    def side_begin(self):
+        import threading
+        self._side_thread = threading.get_ident()
+
+    def side_end(self):
+        self._side_thread = None
+
+    def exchange_edge_rows(self, name):
+        import threading
+        comm = self._comm_side if getattr(self, "_side_thread", None) == threading.get_ident() else self._comm
+        has_up, has_down = self.rank > 0, self.rank < self.size - 1
+        return comm.exchange_rows(self.get_edge_row(name, 0) if has_up else None, self.get_edge_row(name, 1) if has_down else None)
 
     def fill_certify(self, kind):
         if getattr(self, "_attached", False):      # attached to an upper bound: the first "certification" is the relaxation itself
@@ -43,7 +66,8 @@ class CpuBand(object):
         import os
         import struct
         port = int(os.environ.get("CPUBAND_COMM_PORT", "0")) or (31000 + os.getpid() % 2000)
-        return struct.pack("<i", port) + bytes(124)
+        CpuBand._ids = getattr(CpuBand, "_ids", 0) + 1          # (every id = another port: the side communicator is a second one)
+        return struct.pack("<i", port + 3 * (CpuBand._ids - 1)) + bytes(124)
 
     def exchange_halo(self, name):
         has_up, has_down = self.rank > 0, self.rank < self.size - 1
@@ -345,6 +369,55 @@ class CpuBand(object):
         lut[0] = 0
         self.relabel(lut, nlabels_global)
 
+    def relabel_range(self, lo, hi, lut, foreign_ids, foreign_new, nlabels_new):
+        lab = self.r["labels"]
+        out = np.zeros_like(lab)
+        own = (lab >= lo) & (lab <= hi)
+        out[own] = np.asarray(lut, dtype=np.int64)[lab[own] - lo]
+        other = (lab > 0) & ~own
+        fid, fnew = np.asarray(foreign_ids, dtype=np.int64), np.asarray(foreign_new, dtype=np.int64)
+        pos = np.searchsorted(fid, lab[other])
+        ok = (pos < fid.size) & (fid[np.minimum(pos, max(fid.size - 1, 0))] == lab[other]) if fid.size else np.zeros(int(other.sum()), bool)
+        out[other] = np.where(ok, fnew[np.minimum(pos, max(fid.size - 1, 0))] if fid.size else 0, 0)
+        lab[...] = out
+        self.nlabels_global = int(nlabels_new)
+
+    def trace(self, cells, src, background_label, geometry):
+        fd, lab = self.r["flowdir"], self.r["labels"]
+        DR = [-1, -1, 0, 1, 1, 1, 0, -1]
+        DC = [0, 1, 1, 1, 0, -1, -1, -1]
+        row_lo, own0, own1 = self.row0 - self.ht, self.ht, self.ht + self.nrows
+        n = len(cells)
+        out_lab, status, src_out = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        exits, geoms = np.full((n, 2), -1, np.int64), []
+        for i in range(n):
+            gr, c = int(cells[i][0]), int(cells[i][1])
+            r = gr - row_lo
+            s_ = int(src[i])
+            g = []
+            if 0 <= gr < self.Hg and 0 <= c < self.W and own0 <= r < own1:
+                if s_ < 0:
+                    s_ = int(lab[r, c])
+                for _ in range(self.Hg * self.W):
+                    g.append((r + row_lo) * self.W + c)
+                    l = int(lab[r, c])
+                    if l != s_ and (background_label is None or l != background_label):
+                        status[i], out_lab[i] = 1, l
+                        break
+                    k = int(fd[r, c])
+                    if k > 7:
+                        break
+                    r, c = r + DR[k], c + DC[k]
+                    if not (0 <= r + row_lo < self.Hg and 0 <= c < self.W):
+                        break
+                    if not (own0 <= r < own1):
+                        status[i] = 2
+                        exits[i] = (r + row_lo, c)
+                        break
+            src_out[i] = s_
+            geoms.append(np.asarray(g, dtype=np.int64))
+        return out_lab, status, src_out, exits, (geoms if geometry else [None] * n)
+
     def watershed_local(self):
         ws = self._raster("watersheds")
         ws[...] = self.r["labels"]
@@ -394,7 +467,8 @@ class CpuBand(object):
         elif which == 1:
             rec = np.bincount(self._owned("watersheds").ravel(), minlength=n + 1).astype(np.int64)
         else:
-            rec = oracle.label_max_index(self._owned("accum"), self._owned("labels"), n)
+            rec = (oracle.label_max_index(self._owned("accum"), self._owned("labels"), n) if which == 2 else
+                   oracle.label_min_index(self._owned("noflat"), self._owned("labels"), n))
             rec["row"] = np.where(rec["row"] >= 0, rec["row"] + self.row0, rec["row"])
         self._rec = getattr(self, "_rec", {})
         self._rec[which] = rec

@@ -110,6 +110,78 @@ def test_vector_layers_round_trip(tmp_path):
         VectorWriter('ESRI shapefile', str(tmp_path), 'x', None, None, None)
 
 
+def check_outputs(outdir, res, fx, want, flt):
+    from malstroem_amd.io import RasterReader, VectorReader
+    assert res["nlabels"] == KNOWN[flt][0]
+    for name, ref in (("filled", fx["filled"]), ("bs_depths", fx["depths"]), ("flowdir", fx["flowdir_noflats"]),
+                      ("bluespots", want["labels"]), ("watersheds", want["ws"])):
+        with RasterReader(str(outdir / (name + ".tif"))) as r:
+            a = r.read()
+            assert a.dtype == ref.dtype and np.array_equal(a, ref), name
+    events = VectorReader(res["vector"], "events").read_geojson_features()
+    assert len(events) == KNOWN[flt][1]                                                    # tests/test_commandline.py:28,47
+    pps = VectorReader(res["vector"], "pourpoints").read_geojson_features()
+    assert [p["properties"]["bspot_id"] for p in pps] == list(range(KNOWN[flt][0] + 1))
+    assert [(p["properties"]["cell_row"], p["properties"]["cell_col"]) for p in pps] == list(zip(want["pp"]["row"].tolist(), want["pp"]["col"].tolist()))
+    nodes = VectorReader(res["vector"], "nodes").read_geojson_features()
+    assert [(f["properties"]["nodeid"], f["properties"]["dstrnodeid"], f["properties"]["nodetype"]) for f in nodes] == \
+        [(n["id"], n["downstream_id"], n["nodetype"]) for n in want["nodes"]]
+    streams = VectorReader(res["vector"], "streams").read_geojson_features()
+    assert len(streams) == sum(1 for n in want["nodes"] if n["geometry"])
+    for f in events:
+        p = f["properties"]
+        for mm in RAIN:
+            e = want["events"][mm][p["nodeid"]]
+            for k in ("rainv", "spillv", "v", "pctv"):
+                assert p["%s_%g" % (k, mm)] == e[k], (p["nodeid"], k, mm)                   # rain.py:67,86-87
+
+
+def run_band_complete(tmp_path, fx, flt, nbands, backend_factory=None):
+    """`complete` on `nbands` row bands (threads over ThreadComm): -> (outdir, result of rank 0)"""
+    import threading
+    from malstroem_amd.complete import process_all
+    from malstroem_amd.distributed import ThreadComm
+    from malstroem_amd.io import RasterWriter
+    src = str(tmp_path / "dtm.tif")
+    RasterWriter(src, tuple(float(v) for v in fx["geotransform"]), None, nodata=-9999.0).write(fx["dtm"])
+    outdir = tmp_path / ("out%d" % nbands)
+    outdir.mkdir()
+    res, err = [None] * nbands, []
+
+    def work(comm):
+        try:
+            res[comm.rank] = process_all(src, str(outdir), RAIN, filter=flt, comm=comm, backend_factory=backend_factory)
+        except Exception as e:      # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            err.append(e)
+
+    threads = [threading.Thread(target=work, args=(c,), daemon=True) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(900) for t in threads]
+    assert not err and not any(t.is_alive() for t in threads), err
+    assert all(r is None for r in res[1:])
+    return outdir, res[0]
+
+
+@pytest.mark.parametrize("flt,nbands", [(CLI_FILTER, 2), (None, 3)])
+def test_complete_on_row_bands_cpu_stand_in(tmp_path, fx, oracle_chain, flt, nbands):
+    """BASELINE configs[4] in miniature, protocol only (CpuBand computes with the oracle): the filtered chain on 2 and 3 bands --
+    filter on the owner ranks, pour points from merged band records, walkers handed over at the seams, junction surgery and rain
+    events on rank 0 -- reproduces the reference's end-to-end answers and every value of the undivided oracle chain."""
+    from _cpu_band import CpuBand
+    outdir, res = run_band_complete(tmp_path, fx, flt, nbands, backend_factory=CpuBand)
+    check_outputs(outdir, res, fx, oracle_chain["cases"][flt], flt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flt,nbands", [(CLI_FILTER, 2), (CLI_FILTER, 3), (None, 4)])
+def test_complete_on_row_bands(tmp_path, fx, oracle_chain, flt, nbands):
+    """the same on the device: one band context per thread on one MI355X"""
+    outdir, res = run_band_complete(tmp_path, fx, flt, nbands)
+    check_outputs(outdir, res, fx, oracle_chain["cases"][flt], flt)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("flt", list(KNOWN))
 def test_complete_from_the_dem_file_to_the_rain_events(tmp_path, fx, oracle_chain, flt):

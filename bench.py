@@ -114,13 +114,11 @@ class DemSource(object):
         return out
 
 
-KERNEL_OF_STAGE = {"fill": "fill stage kernels (see stages.fill)", "noflat": "ng_first_kernel + ng_round_kernel (one launch per round) + ng_compact_kernel + ng_finish_kernel",
-                   "flowdir": "d8_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "depths + ccl_* + stats_kernel",
+KERNEL_OF_STAGE = {"fill": "pf_tile_kernel", "noflat": "ng_round_kernel", "flowdir": "d8s_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "depths + ccl_* + stats_kernel",
                    "watershed": "ws_* + count_kernel", "pourpoints": "arg_packed_kernel"}
-# FETCH_SIZE under-counts wide coalesced streaming reads by 2 on gfx950 (MI355X_MICROARCH.md, HBM section): the correction
-# applies per kernel, by its load width (16 B per lane), not to the tile loads (4 / 8 B per lane) of the fills
-FETCH_X2 = ("d8_kernel", "depths_kernel", "minmax_kernel", "pf_apply_kernel", "noflat_seed_kernel", "ng_assemble_kernel")
-STAGE_KERNELS = {"flowdir": ("d8_kernel",), "fill": ("fill_round_kernel<float", "pf_"), "noflat": ("fill_round_kernel<double", "noflat_", "ng_"),
+# FETCH_SIZE reports half of the bytes of a coalesced streaming read on gfx950 whatever the load width (calibrated per run on kernels
+# with known reads: tools/pmc_traffic.py); the committed table carries the corrected figure (`fetch_bytes_per_cell`)
+STAGE_KERNELS = {"flowdir": ("d8_kernel", "d8s_kernel"), "fill": ("fill_round_kernel<float", "pf_"), "noflat": ("fill_round_kernel<double", "noflat_", "ng_"),
                  "accum": ("accum_",), "label": ("ccl_", "stats_", "depths_kernel"), "watershed": ("ws_", "count_kernel"),
                  "pourpoints": ("arg_",)}
 
@@ -135,8 +133,7 @@ def pmc_traffic(stage, n):
     tot = 0.0
     for row in json.loads(path.read_text()):
         if row["kernel"].startswith(STAGE_KERNELS[stage]):
-            fcorr = 2.0 if row["kernel"].startswith(FETCH_X2) else 1.0
-            tot += (row["fetch_size_kb"] * fcorr + row["write_size_kb"]) * 1024.0
+            tot += (row["fetch_size_kb"] * 2.0 + row["write_size_kb"]) * 1024.0
     if tot == 0.0:
         return None
     return {"hbm_bytes_per_stage": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "source": "profiles/" + path.name}
@@ -258,6 +255,7 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     stage_ms = {s: 0.0 for s in stage_names}
+    hot_ms, hot_launches = {"fill": 0.0, "noflat": 0.0}, {"fill": 0, "noflat": 0}
     pipe, workers, gate = None, [], None
     parallelism = "1 GPU, one device context"
     if band_mode:
@@ -332,6 +330,9 @@ def main():
             if record:
                 for s in stage_names:
                     stage_ms[s] += pipe.stage_ms(s)
+                for s in ("fill", "noflat"):      # the stage's dominant kernel, HIP events around its launches inside the library
+                    hot_ms[s] += pipe.get_float(s + "_hot_ms")
+                    hot_launches[s] = pipe.get_int(s + "_hot_launches")
 
     def barrier():
         if pipe is not None:
@@ -408,6 +409,25 @@ def main():
         chain = "fill -> no-flats fill -> D8" if config2 else ("fill+depths -> no-flats fill -> D8 -> accumulation -> CCL+label_stats -> "
                                                                "watersheds+label_count -> pour points")
         launches_key = {"fill": "fill_launches" if "fill_launches" in info else "fill_rounds", "noflat": "noflat_rounds"}.get(dominant, "")
+
+        def kernel_detail(stage):
+            """the dominant KERNEL of the dominant stage: its own device time (HIP events around its launches, live in this run) and
+            its own HBM bytes (the committed PMC table of the same command), next to the stage figure"""
+            if band_mode or stage not in hot_ms or hot_ms[stage] <= 0.0:
+                return None
+            kms = hot_ms[stage] / args.steps
+            out_ = {"name": KERNEL_OF_STAGE[stage], "launches_per_step": hot_launches[stage], "ms_per_step": round(kms, 3),
+                    "avg_launch_us": round(1e3 * kms / max(hot_launches[stage], 1), 1), "timed_by": "HIP events around the launches, on their stream"}
+            tables = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
+            if n == 16384 and tables:
+                for row in json.loads(tables[-1].read_text()):
+                    if row["kernel"].startswith(KERNEL_OF_STAGE[stage]):
+                        own = (2.0 * row["fetch_size_kb"] + row["write_size_kb"]) * 1024.0
+                        out_.update({"hbm_bytes_per_step": round(own), "hbm_bytes_per_cell": round(own / cells, 2),
+                                     "achieved_GBs": round(own / (kms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "traffic_source": "profiles/" + tables[-1].name})
+                        break
+            return out_
         out = {
             "metric": ("Mcells/s fill->D8 on %d^2 f32 DEM" if config2 else "Mcells/s fill->D8->accum->label on %d^2 f32 DEM") % n,
             "value": round(value, 2), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -417,6 +437,7 @@ def main():
             "config": {"workload": "%dx%d float32 DEM (%s): %s" % (n, n, src.recipe, chain),
                        "parallelism": parallelism, "dem_generation_s": round(t_gen, 1), **info},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE.get(dominant, dominant), "stage": dominant,
+                         "kernel_detail": kernel_detail(dominant),
                          "launches_per_step": info.get(launches_key, 1),
                          "achieved": stages[dominant]["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": stages[dominant]["frac_of_hbm_peak"], "traffic": pmc_traffic(dominant, n) if not band_mode else None,

@@ -1657,17 +1657,25 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
             c->ev_valid[st];   // creates the key
         }
     }
-    if (!c->stream_b) {
-        // LABEL only has to finish before the no-flats fill does: lowest priority; WATERSHED is on the critical path
+    // development knob MHIP_SIDE_CUMASK=<hex word>: the side streams may only use the CUs whose bit is set in the word (repeated
+    // over all 256 CUs) -- an experiment in letting the label branch run next to the latency-bound rounds of the no-flats fill
+    // without its long workgroups holding every CU
+    auto side_stream = [&](hipStream_t *st) -> int {
+        const char *m = dev_env("MHIP_SIDE_CUMASK");
+        if (m) {
+            uint32_t w[8];
+            for (uint32_t &x : w) x = (uint32_t)strtoul(m, nullptr, 16);
+            MH_HIP(hipExtStreamCreateWithCUMask(st, 8, w));
+            return MHIP_OK;
+        }
         int least = 0, greatest = 0;
         MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        MH_HIP(hipStreamCreateWithPriority(&c->stream_b, hipStreamNonBlocking, least));
-    }
-    if (!c->stream_c) {
-        int least = 0, greatest = 0;
-        MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        MH_HIP(hipStreamCreateWithPriority(&c->stream_c, hipStreamNonBlocking, least));
-    }
+        MH_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, least));
+        return MHIP_OK;
+    };
+    // LABEL only has to finish before the no-flats fill does: lowest priority; WATERSHED is on the critical path
+    if (!c->stream_b) MH_TRY(side_stream(&c->stream_b));
+    if (!c->stream_c) MH_TRY(side_stream(&c->stream_c));
     if (!c->ev_fork) {
         MH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_flowdir, hipEventDisableTiming));
@@ -1825,6 +1833,8 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "fill_tiles") *value = c->fill_st.tiles;
     else if (k == "fill_algorithm") *value = c->fill_st.algorithm;   // 0 iterative tile schedule, 1 tiled priority-flood
     else if (k == "fill_launches") *value = c->fill_st.rounds;
+    else if (k == "fill_hot_launches") *value = c->fill_st.hot_launches;
+    else if (k == "noflat_hot_launches") *value = c->noflat_st.hot_launches;
     else if (k == "noflat_algorithm") *value = c->noflat_st.algorithm;   // 0 float64 relaxation (fill.hip), 2 integer geodesic transform (noflat_geo.hip)
     else if (k == "noflat_visits") *value = c->noflat_st.visits;
     else if (k == "noflat_cycles") *value = c->noflat_st.cycles;
@@ -1843,6 +1853,8 @@ int mhip_ctx_get_f64(mhip_ctx *c, const char *key, double *value)
     const std::string k(key);
     if (k == "short") *value = c->sh;
     else if (k == "diag") *value = c->dg;
+    else if (k == "fill_hot_ms") *value = c->fill_st.hot_ms;          // pf_tile_kernel, HIP events around its launch
+    else if (k == "noflat_hot_ms") *value = c->noflat_st.hot_ms;      // the ng_round_kernel launches (span of the round loop)
     else {
         set_error("unknown key '%s'", key);
         return MHIP_EINVAL;

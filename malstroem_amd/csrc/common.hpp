@@ -111,6 +111,8 @@ struct FillStats {
     int64_t visits = 0;   // tile visits over all rounds
     int64_t cycles = 0;   // local (down, up, right, left) cycles over all visits
     int64_t tiles = 0;    // tiles in the raster
+    float hot_ms = 0;     // device time of the stage's dominant kernel, HIP events around its launches: pf_tile_kernel (one launch) /
+    int32_t hot_launches = 0;   // the ng_round_kernel launches (the span of the round loop: compaction launches and gaps included)
     int32_t algorithm = 0;  // 0: iterative tile schedule (fill.hip), 1: tiled priority-flood (pflood.hip; rounds = kernel launches),
                             // 2: integer geodesic transform (noflat_geo.hip)
 };

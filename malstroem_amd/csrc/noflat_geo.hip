@@ -768,6 +768,8 @@ struct GeoRun::Impl {
     uint8_t *d_mark = nullptr;
     int *d_list = nullptr, *d_list2 = nullptr, *d_amark = nullptr;
     int ntr = 0, ntc = 0, round = 0, used = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> span;   // around every batch of ng_round_kernel launches
+    int span_rounds = 0;
     bool light = false;          // the rounds from light_from on append to the next round's list themselves
     int light_from = 0;
     int64_t nt = 0;
@@ -787,10 +789,30 @@ __global__ void ng_mark_row_kernel(uint8_t *mark, int ti, int ntc)
 }  // namespace
 
 GeoRun::GeoRun() : impl(new Impl) {}
-GeoRun::~GeoRun() { delete impl; }
+GeoRun::~GeoRun()
+{
+    for (auto &e : impl->span) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    delete impl;
+}
 
 int GeoRun::launch_rounds(hipStream_t s, int nb)
 {
+    {   // HIP events around the batch: the device time of the round loop (bench.py: the stage's dominant kernel)
+        Impl &mm = *impl;
+        hipEvent_t e0, e1;
+        MH_HIP(hipEventCreate(&e0));
+        MH_HIP(hipEventCreate(&e1));
+        mm.span.emplace_back(e0, e1);
+        MH_HIP(hipEventRecord(e0, s));
+    }
+    struct CloseSpan {
+        Impl &m;
+        hipStream_t s;
+        ~CloseSpan() { (void)hipEventRecord(m.span.back().second, s); }
+    } close_span{*impl, s};
     Impl &m = *impl;
     GeoArgs a;
     a.H = H; a.W = W; a.ntr = m.ntr; a.ntc = m.ntc; a.nt = (int)m.nt; a.F = filled; a.d = dist; a.tab = m.d_tab; a.counters = m.d_cnt;
@@ -802,6 +824,7 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
         a.count = m.d_any + m.round;     // tiles of this round (round 0: every tile)
         if (!m.round) {
             hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), m.lds, s, a);
+            (void)hipEventRecord(m.span.back().first, s);      // (the span counts the rounds after the classification)
             continue;
         }
         // the marks of the last mark-mode round become the list of this one
@@ -967,6 +990,12 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
         st->rounds = m.used;
         st->tiles = m.nt;
         st->algorithm = partial ? 3 : 2;
+        for (auto &e : m.span) {     // (the stream has been synchronised above)
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) st->hot_ms += ms;
+            else (void)hipGetLastError();
+        }
+        st->hot_launches = m.used > 0 ? m.used - 1 : 0;      // (round 0 is ng_first_kernel)
         for (int k = 0; k < 64; ++k) {
             st->visits += (int64_t)h_all[C_STATS + 2 * k];
             st->cycles += (int64_t)h_all[C_STATS + 2 * k + 1];

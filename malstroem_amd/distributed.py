@@ -744,7 +744,8 @@ def solve_band_accum(info, W):
     return [(val[b - 1, 1] if b > 0 else None, val[b + 1, 0] if b < R - 1 else None) for b in range(R)]
 
 
-_PROF = os.environ.get("MALSTROEM_BAND_PROFILE") is not None    # development: wall clock of the steps inside label() / _merged()
+_DEV = os.environ.get("MHIP_DEVELOPER") == "1"      # development knobs are only read under MHIP_DEVELOPER=1 (like the library's dev_env)
+_PROF = _DEV and os.environ.get("MALSTROEM_BAND_PROFILE") is not None    # wall clock of the steps inside label() / _merged()
 
 
 class _Lap:
@@ -969,7 +970,7 @@ class BandPipeline(object):
     def noflat(self):
         """fill.fill_terrain_no_flats over all bands (needs fill())."""
         short, diag = self.short_and_diag()
-        if hasattr(self.band, "geo_begin") and os.environ.get("MALSTROEM_BAND_NOFLAT", "") != "relaxation" and self._noflat_geodesic(short, diag):
+        if hasattr(self.band, "geo_begin") and not (_DEV and os.environ.get("MALSTROEM_BAND_NOFLAT", "") == "relaxation") and self._noflat_geodesic(short, diag):
             return
         self._fill(1, "noflat", short, diag)
 

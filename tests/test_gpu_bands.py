@@ -309,3 +309,32 @@ def test_band_watersheds_resolve_paths_that_bounce_and_cross_whole_bands(name, h
     [t.join(600) for t in threads]
     assert all(o is not None for o in out)
     assert np.array_equal(np.concatenate(out), want), name
+
+
+def test_bands_with_a_nan_cell_follow_the_one_context_path():
+    """A NaN cell makes np.amax / np.amin -- and with them short and diag -- NaN (fill.py:246-249); the one-context path propagates it
+    (reduce.hip) and so do the bands now (the band path used to take a finite epsilon).  The plain fill ignores the NaN
+    cell like the reference (it never moves, never wins a minimum): the bands equal the undivided raster.  (With NaN epsilons the
+    no-flats fill is undefined in the reference -- its two variants disagree -- and does not converge here on either path.)"""
+    import malstroem_amd.algorithms as alg
+    from malstroem_amd.distributed import BandPipeline, ThreadComm
+    dem = fbm(300, 260, beta=2.0, seed=41)
+    dem[200, 100] = np.nan
+    sd = alg.fill.minimum_safe_short_and_diag(dem)
+    assert np.isnan(sd[0]) and np.isnan(sd[1])
+    want = alg.fill.fill_terrain(dem)
+    out = [None] * 3
+
+    def work(comm):
+        p = BandPipeline(comm, dem.shape, device=0)
+        p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+        p.fill()
+        out[comm.rank] = (p.download("filled"), p.short_and_diag())
+        p.close()
+
+    threads = [threading.Thread(target=work, args=(c,)) for c in ThreadComm.world(3)]
+    [t.start() for t in threads]
+    [t.join(600) for t in threads]
+    assert all(o is not None for o in out)
+    assert all(np.isnan(o[1][0]) and np.isnan(o[1][1]) for o in out)
+    assert np.array_equal(np.concatenate([o[0] for o in out]), want, equal_nan=True)

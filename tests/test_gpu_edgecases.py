@@ -275,3 +275,24 @@ def test_the_flood_proof_is_live(alg, monkeypatch):
             assert np.array_equal(pipe.download("filled"), want)
             assert np.array_equal(pipe.download("depths"), oracle.depths(want, dem))
     assert np.array_equal(alg.fill.fill_terrain(dem), want)      # (stage function, hook still set)
+
+
+@pytest.mark.parametrize("shape,beta,seed", [((300, 256), 2.0, 1), ((700, 512), 2.5, 2), ((130, 1024), 2.0, 3), ((64, 768), 1.5, 4), ((2, 256), 2.0, 5),
+                                             ((3, 512), 2.0, 6), ((1000, 1280), 3.0, 7)])
+def test_fused_apply_and_proof_on_widths_that_are_multiples_of_256(alg, shape, beta, seed):
+    """rasters whose width is a multiple of 256 take pf_apply_check_kernel (K4 and the run-time proof in one streaming pass)
+    instead of pf_apply_kernel + fill_check_kernel: same filled surface and depths, incl. NaN cells, -0.0 and tiny heights"""
+    from malstroem_amd.pipeline import HydroPipeline
+    dem = fbm(shape[0], shape[1], beta=beta, seed=seed)
+    if shape[0] > 60:
+        dem[shape[0] // 2, 17] = np.nan
+        dem[shape[0] // 3, 250:262] = -0.0
+    want = oracle.fill_terrain(dem)
+    with HydroPipeline(dem.shape) as pipe:
+        pipe.upload("dem", dem)
+        pipe.run("fill")
+        pipe.sync()
+        got, dep = pipe.download("filled"), pipe.download("depths")
+        assert pipe.get_int("fill_algorithm") in (0, 1)       # (4 = the proof failed and the surface was repaired: never here)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(dep, oracle.depths(want, dem), equal_nan=True)

@@ -1,9 +1,10 @@
 #!/bin/bash
-# on the GPU box (gpurun -- bash tools/collect_profiles.sh): the profile set of a round under gpurun_out/r02e/ -- PMC traffic table,
+# on the GPU box (gpurun -- bash tools/collect_profiles.sh): the profile set of a round under gpurun_out/<tag>/ (tag = first argument) -- PMC traffic table,
 # rocprofv3 kernel statistics and the bench lines DESIGN.md quotes; copy the results into profiles/ afterwards
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02e
+TAG=${1:-r03a}
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 cd $R
@@ -11,15 +12,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o f -- 
 echo "pmc fetch done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o w -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_w.log 2>&1
 echo "pmc write done"
-python3 tools/pmc_traffic.py $O/pmc_f/f_results.db $O/pmc_w/w_results.db 16384 > $O/r02e_pmc_hbm_traffic.json
-cp $O/r02e_pmc_hbm_traffic.json profiles/r02e_pmc_hbm_traffic.json
+python3 tools/pmc_traffic.py $O/pmc_f/f_results.db $O/pmc_w/w_results.db 16384 > $O/${TAG}_pmc_hbm_traffic.json
+cp $O/${TAG}_pmc_hbm_traffic.json profiles/${TAG}_pmc_hbm_traffic.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline > $O/prof.log 2>&1
-python3 tools/kernel_stats.py $O/prof/k_results.db > $O/r02e_kernel_stats.csv
+python3 tools/kernel_stats.py $O/prof/k_results.db > $O/${TAG}_kernel_stats.csv
 echo "kernel stats done"
-timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/r02e_bench16384.json
+timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/${TAG}_bench16384.json
 echo "bench done"
-timeout -k 10 300 python3 bench.py --beta 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02e_bench16384_beta3.json
-timeout -k 10 300 python3 bench.py --config 2 2>/dev/null | tail -1 > $O/r02e_bench4096_config2.json
-timeout -k 10 600 python3 bench.py --size 32768 --bands 4 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r02e_bench32768_4bands_1gpu.json
+timeout -k 10 300 python3 bench.py --beta 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench16384_beta3.json
+timeout -k 10 300 python3 bench.py --config 2 2>/dev/null | tail -1 > $O/${TAG}_bench4096_config2.json
+if [ -z "$QUICK" ]; then timeout -k 10 600 python3 bench.py --size 32768 --bands 4 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench32768_4bands_1gpu.json; fi
 rm -rf $O/pmc_f $O/pmc_w $O/prof
 ls -la $O

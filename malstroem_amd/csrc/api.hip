@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "common.hpp"
+#include <condition_variable>
+#include <functional>
 #include <future>
 #include <thread>
 
@@ -444,7 +446,56 @@ int mhip_trace_downstream_i32(const uint8_t *flowdir, const int32_t *labels, int
  * device-resident pipeline
  * ================================================================================================ */
 
+// One helper thread per context, started with the first request that overlaps its two branches and parked on a condition variable in
+// between: mhip_ctx_run used to create (and join) a std::thread per call.
+class SideThread {
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> task_;
+    bool busy_ = false, stop_ = false;
+
+public:
+    ~SideThread()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    void run(std::function<void()> f)      // the caller must wait() before the objects `f` refers to go away
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (!th_.joinable())
+            th_ = std::thread([this] {
+                std::unique_lock<std::mutex> l2(mu_);
+                for (;;) {
+                    cv_.wait(l2, [this] { return stop_ || (busy_ && task_); });
+                    if (stop_) return;
+                    std::function<void()> f2 = std::move(task_);
+                    task_ = nullptr;
+                    l2.unlock();
+                    f2();
+                    l2.lock();
+                    busy_ = false;
+                    cv_.notify_all();
+                }
+            });
+        task_ = std::move(f);
+        busy_ = true;
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return !busy_; });
+    }
+};
+
 struct mhip_ctx {
+    SideThread side;        // drives the label branch of mhip_ctx_run
     int64_t H = 0, W = 0;   // local raster: owned rows + halo rows
     int64_t H_global = 0, row0 = 0, H_owned = 0;
     int ht = 0, hb = 0;     // 1 if a halo row (copy of the neighbouring band's edge row) sits above / below the owned rows
@@ -1709,7 +1760,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     int rc_b = MHIP_OK;
     char err_b[512] = "";
     bool shdg_set = false, label_set = false;   // whatever happens on the side thread, the main thread is never left waiting
-    std::thread tb([&] {
+    c->side.run([&] {
         rc_b = [&]() -> int {
             MH_HIP(hipSetDevice(c->device));
             // the epsilon of the no-flats fill only needs the DEM: computed while the plain fill runs
@@ -1774,7 +1825,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     if (rc_a == MHIP_OK && rc_l == MHIP_OK && (mask & MHIP_STAGE_POURPOINTS)) {
         rc_a = hipStreamWaitEvent(s, c->ev_label, 0) == hipSuccess ? stage_pourpoints(c, s) : MHIP_EHIP;
     }
-    tb.join();
+    c->side.wait();
     if (rc_a != MHIP_OK) return rc_a;
     if (rc_b != MHIP_OK) {
         set_error("%s", err_b);

@@ -242,3 +242,48 @@ def test_complete_with_accum_puts_pour_points_at_the_flow_maximum(tmp_path, fx):
     assert [(p["properties"]["cell_row"], p["properties"]["cell_col"]) for p in pps] == list(zip(opp["row"].tolist(), opp["col"].tolist()))
     with pytest.raises(ValueError):
         process_all(src, str(outdir), [20])                                                 # outdir not empty (scripts/complete.py:45-47)
+
+
+@pytest.mark.gpu
+def test_complete_on_row_bands_equals_one_context_on_a_larger_terrain(tmp_path):
+    """2048 x 1536 fBm, ~40 000 bluespots, a filter that drops most of them, accumulated flow on: `complete` on 4 row bands against
+    `complete` on one context -- every raster equal, the same pour points, nodes, streams and event values (walkers cross the seams
+    thousands of times here, bluespots and watersheds straddle them)."""
+    import threading
+    from _cases import fbm
+    from malstroem_amd.complete import process_all
+    from malstroem_amd.distributed import ThreadComm
+    from malstroem_amd.io import RasterReader, RasterWriter, VectorReader
+    dem = fbm(2048, 1536, beta=2.0, seed=77) * np.float32(0.5)
+    src = str(tmp_path / "dem.tif")
+    RasterWriter(src, (500000.0, 1.6, 0.0, 6200000.0, 0.0, -1.6), None).write(dem)
+    flt = "area > 30 and maxdepth > 0.02 or volume > 4"
+    one = tmp_path / "one"
+    one.mkdir()
+    r1 = process_all(src, str(one), [20, 60], accum=True, filter=flt)
+    bands = tmp_path / "bands"
+    bands.mkdir()
+    res, err = [None] * 4, []
+
+    def work(comm):
+        try:
+            res[comm.rank] = process_all(src, str(bands), [20, 60], accum=True, filter=flt, comm=comm)
+        except Exception as e:      # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            err.append(e)
+
+    threads = [threading.Thread(target=work, args=(c,), daemon=True) for c in ThreadComm.world(4)]
+    [t.start() for t in threads]
+    [t.join(900) for t in threads]
+    assert not err and not any(t.is_alive() for t in threads), err
+    r4 = res[0]
+    assert r4["nlabels"] == r1["nlabels"] > 100
+    for name in ("filled", "bs_depths", "flowdir", "accum", "bluespots", "watersheds"):
+        with RasterReader(str(one / (name + ".tif"))) as a, RasterReader(str(bands / (name + ".tif"))) as b:
+            assert np.array_equal(a.read(), b.read()), name
+    for layer in ("pourpoints", "nodes", "streams", "events"):
+        fa = VectorReader(r1["vector"], layer).read_geojson_features()
+        fb = VectorReader(r4["vector"], layer).read_geojson_features()
+        assert len(fa) == len(fb) > 0, layer
+        assert fa == fb, layer

@@ -235,6 +235,13 @@ def test_rccl_inside_the_library_single_rank():
         assert band.allreduce_max(3.5) == 3.5 and band.allreduce_max(-2.0) == -2.0
         band.upload("dem", fbm(64, 48, seed=3))
         assert band.exchange_halo("dem") == (False, False)      # no neighbours: nothing moves
+        assert band.exchange_edge_rows("dem") == (None, None)
+        assert HipBand.comm_available()
+        band.add_side_comm(HipBand.new_unique_id())             # the second communicator (ncclCommInitRank again on the same device)
+        assert band.has_side_comm
+        band.side_begin()
+        assert band.exchange_edge_rows("dem") == (None, None)   # ... which the thread inside the side bracket uses
+        band.side_end()
     finally:
         band.close()
 
@@ -245,7 +252,8 @@ def test_rccl_inside_the_library_single_rank():
     p = BandPipeline(OneRankRccl(), dem.shape, device=0, rccl=False)
     p.band.close()
     p.band = HipBand(200, 150, 0, 200, device=0, rank=0, size=1, unique_id=HipBand.new_unique_id())
-    p.rccl = True
+    p.band.add_side_comm(HipBand.new_unique_id())
+    p.rccl, p.rccl_side = True, True
     try:
         p.upload_dem(dem)
         out = p.run_chain()

@@ -143,6 +143,34 @@ int mhip_band_ws_resolve(int64_t n, int64_t *vals);
 /* classes of an undirected graph (n nodes, m edges a[k] -- b[k]): cls[i] = smallest node of i's class (the label merge across
  * band seams works on the seam pairs the bands publish) */
 int mhip_band_union_find(int64_t n, int64_t m, const int64_t *a, const int64_t *b, int64_t *cls);
+/* The host sections of the band protocol between its exchanges, one or two passes each over the seam rows (2 * W cells per band)
+ * and the gathered pairs (malstroem_amd/distributed.py: BandPipeline.accum / label / watershed describe the protocol; node of
+ * (band, side, column) = (2 * band + side) * W + column, label keys = (band << 32) | local label).
+ * band_accum_pairs: one pair {int32 child, int32 parent, double own_child, double own_parent} (24 bytes) per cell of a neighbour's
+ *   edge row whose flux crosses this band and leaves it again.
+ * band_accum_solve: the forest of the gathered pairs solved as in band_forest_solve; the neighbours' edge rows top / bot updated.
+ * band_label_pairs: one (mine, theirs) pair per run along a halo row, and the row's phantoms (components without an owned cell).
+ * band_label_merge: classes of the gathered pairs -> offsets[R + 1] of every band's numbering, band `me`'s dropped labels and
+ *   their global labels, and the global labels that live in more than one band.
+ * band_ws_publish:  the edge cells of this band on watershed paths that are still open after looking at the neighbours' rows.
+ * band_ws_lut:      gathered chains followed to their ends; lut[2 * W] = label behind each halo cell of this band. */
+int mhip_band_accum_pairs(int64_t W, const int32_t *exit_half, const double *nbr, const double *own_edge, int64_t child_base,
+                          int64_t parent_base, void *pairs, int64_t *n);
+int mhip_band_accum_solve(int64_t nspace, int64_t m, const void *pairs, int64_t W, int64_t base_top, double *top, int64_t base_bot,
+                          double *bot);
+int mhip_band_label_pairs(int64_t W, const int32_t *halo, const int32_t *edge, const int32_t *nbr, int64_t key_mine, int64_t key_nbr,
+                          int64_t *ea, int64_t *eb, int64_t *npairs, int64_t *ph, int64_t *nph);
+int mhip_band_label_merge(int32_t R, int32_t me, const int64_t *nloc, int64_t m, const int64_t *EA, const int64_t *EB, int64_t nph,
+                          const int64_t *PH, int64_t *offsets, int32_t *dropped, int32_t *target, int64_t *ndrop, int64_t *shared,
+                          int64_t *nshared);
+int mhip_band_ws_publish(int64_t W, int32_t me, const int32_t *mine, const int32_t *up, const int32_t *dn, int64_t *N, int64_t *V,
+                         int64_t *n);
+int mhip_band_ws_lut(int64_t W, int32_t me, int64_t n, const int64_t *N, const int64_t *V, const int32_t *up, const int32_t *dn,
+                     int32_t *lut);
+/* per-label records of labels that live in several bands: parts[r] = band r's n partial records, merged in band order into out.
+ * kind 0: {min, max, sum, count} (label_stats, _label.pyx:22-24); kind 2 / 3: {value, row, col} of label_max_index / label_min_index
+ * (_label.pyx:26-28; row < 0: the band holds no cell of the label; the earlier band wins ties = first raster position) */
+int mhip_band_merge_records(int32_t kind, int32_t R, int64_t n, const void *const *parts, void *out);
 
 /* ---- device-resident pipeline (DemTool / BluespotTool sequences, reference dem.py:53-93,
  *      bluespots.py:138-216): one upload, all stages in HBM, downloads only for the writers. ------- */

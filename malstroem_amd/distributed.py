@@ -765,6 +765,10 @@ class _Lap:
             print("[band profile] %s: %s" % (self.what, ", ".join("%s %.1f" % kv for kv in self.acc)), file=sys.stderr, flush=True)
 
 
+# one pass-through pair of the band accumulation (csrc/bandsolve.hip: BandAccumPair)
+ACCUM_PAIR_DTYPE = np.dtype([("child", "<i4"), ("parent", "<i4"), ("own_child", "<f8"), ("own_parent", "<f8")])
+
+
 class BandPipeline(object):
     """One rank's share of a row-banded DEM.  Every rank calls the same methods in the same order (SPMD)."""
 
@@ -1049,40 +1053,31 @@ class BandPipeline(object):
         nbr_up, nbr_dn = self._neighbour_rows("accum")
         self.exchanges["accum"] += 1
         with self._host("accum"):
-            own_edge = np.concatenate([own_first, own_last]).astype(np.float64)
-            ch, pa, oc, op = [], [], [], []
+            own_edge = np.ascontiguousarray(np.concatenate([own_first, own_last]), dtype=np.float64)
+            exit_map = np.ascontiguousarray(exit_map, dtype=np.int32)
             # node (band, side, column) = (2 * band + side) * W + column; side 0 = first owned row, 1 = last owned row
-            for halo, nbr, base in ((exit_map[:W], nbr_up, (2 * (me - 1) + 1) * W), (exit_map[W:], nbr_dn, (2 * (me + 1)) * W)):
+            pairs = np.empty(2 * W, ACCUM_PAIR_DTYPE)
+            top = None if nbr_up is None else np.array(nbr_up, dtype=np.float64)
+            bot = None if nbr_dn is None else np.array(nbr_dn, dtype=np.float64)
+            k = 0
+            for half, nbr, base in ((exit_map[:W], top, (2 * (me - 1) + 1) * W), (exit_map[W:], bot, (2 * (me + 1)) * W)):
                 if nbr is None:
                     continue
-                k = np.flatnonzero(halo >= 0)
-                e = halo[k].astype(np.int64)
-                ch.append(base + k)
-                pa.append(2 * me * W + e)
-                oc.append(np.asarray(nbr, dtype=np.float64)[k])
-                op.append(own_edge[e])
-            cat = lambda parts, dt: np.concatenate(parts).astype(dt) if parts else np.zeros(0, dt)
-            mine = (cat(ch, np.int64), cat(pa, np.int64), cat(oc, np.float64), cat(op, np.float64))
+                n = ctypes.c_int64(0)
+                _lib.call("mhip_band_accum_pairs", _lib.i64(W), _lib.ptr(half), _lib.ptr(nbr), _lib.ptr(own_edge), _lib.i64(base),
+                          _lib.i64(2 * me * W), _lib.ptr(pairs[k:]), ctypes.byref(n))
+                k += n.value
+            mine = pairs[:k]
         parts = self._cur_comm().allgather(mine)
         with self._host("accum"):
-            C = np.concatenate([p[0] for p in parts])
-            P = np.concatenate([p[1] for p in parts])
-            m = C.size
-            top = None if nbr_up is None else np.asarray(nbr_up, dtype=np.float64).copy()
-            bot = None if nbr_dn is None else np.asarray(nbr_dn, dtype=np.float64).copy()
-            if m:
-                nodes, inv = np.unique(np.concatenate([C, P]), return_inverse=True)
-                val = np.zeros(nodes.size, np.float64)
-                val[inv[:m]] = np.concatenate([p[2] for p in parts])
-                val[inv[m:]] = np.concatenate([p[3] for p in parts])
-                parent = np.full(nodes.size, -1, np.int64)
-                parent[inv[:m]] = inv[m:]
-                val = np.ascontiguousarray(val)
-                _lib.call("mhip_band_forest_solve", _lib.i64(nodes.size), _lib.ptr(parent), _lib.ptr(val))
-                for row, base in ((top, (2 * (me - 1) + 1) * W), (bot, (2 * (me + 1)) * W)):
-                    if row is not None:
-                        lo, hi = np.searchsorted(nodes, [base, base + W])
-                        row[nodes[lo:hi] - base] = val[lo:hi]
+            # (as bytes: NumPy concatenates structured arrays field by field, ten times slower)
+            pairs = np.concatenate([np.ascontiguousarray(p, dtype=ACCUM_PAIR_DTYPE).view(np.uint8) for p in parts]).view(ACCUM_PAIR_DTYPE)
+            if _PROF and me == 0:
+                print("[band profile] accum: %d pass-through pairs of %d seam cells" % (pairs.size, 2 * W * (self.comm.size - 1)), file=sys.stderr,
+                      flush=True)
+            _lib.call("mhip_band_accum_solve", _lib.i64(2 * self.comm.size * W), _lib.i64(pairs.size), _lib.ptr(pairs), _lib.i64(W),
+                      _lib.i64((2 * (me - 1) + 1) * W), _lib.ptr(top) if top is not None else None,
+                      _lib.i64((2 * (me + 1)) * W), _lib.ptr(bot) if bot is not None else None)
 
         def second_pass():
             if self.has_up:
@@ -1113,81 +1108,40 @@ class BandPipeline(object):
         lap.lap("ccl_local + edge rows")
         nbr_up, nbr_dn = self._neighbour_rows("labels")      # the neighbour's LAST row above / FIRST row below, in ITS labels
         lap.lap("neighbour rows")
-        key = lambda r, lab: (np.int64(r) << 32) | lab.astype(np.int64)
-
-        def run_values(row):
-            """the distinct positive labels of a row, from its run starts (a row holds far fewer runs than cells)"""
-            keep = row > 0
-            if row.size > 1:
-                keep[1:] &= row[1:] != row[:-1]
-            return np.unique(row[keep])
-
         with self._host("label"):
-            ea, eb, ph = [], [], []
+            ea, eb, ph = np.empty(2 * W, np.int64), np.empty(2 * W, np.int64), np.empty(2 * W, np.int64)
+            k = q = 0
             for halo, edge, nbr, r_nbr in ((rows["top"], rows["first"], nbr_up, me - 1), (rows["bot"], rows["last"], nbr_dn, me + 1)):
                 if halo is None:
                     continue
-                nbr = np.asarray(nbr)
-                m = (halo > 0) & (nbr > 0)          # one pair per RUN of equal (mine, theirs) along the row
-                if W > 1:
-                    m[1:] &= (halo[1:] != halo[:-1]) | (nbr[1:] != nbr[:-1])
-                ea.append(key(me, halo[m]))
-                eb.append(key(r_nbr, nbr[m]))
-                # phantom = a local component without an owned cell: in the halo row but not in the adjacent owned row
-                ph.append(np.setdiff1d(run_values(halo), run_values(edge), assume_unique=True))
-            cat = lambda parts: np.concatenate(parts).astype(np.int64) if parts else np.zeros(0, np.int64)
-            mine = dict(nloc=int(nloc), ea=cat(ea), eb=cat(eb), ph=np.unique(cat(ph)))
+                nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+                n, nq = ctypes.c_int64(0), ctypes.c_int64(0)
+                # one pair per RUN of equal (mine, theirs) along the row; phantom = a local component without an owned cell
+                _lib.call("mhip_band_label_pairs", _lib.i64(W), _lib.ptr(halo), _lib.ptr(edge), _lib.ptr(nbr), _lib.i64(me << 32), _lib.i64(r_nbr << 32),
+                          _lib.ptr(ea[k:]), _lib.ptr(eb[k:]), ctypes.byref(n), _lib.ptr(ph[q:]), ctypes.byref(nq))
+                k += n.value
+                q += nq.value
+            mine = dict(nloc=int(nloc), ea=ea[:k], eb=eb[:k], ph=ph[:q] | (np.int64(me) << 32))
         allp = comm.allgather(mine)
         lap.lap("allgather")
         with self._host("label"):
-            EA = np.concatenate([p["ea"] for p in allp])
-            EB = np.concatenate([p["eb"] for p in allp])
-            phk = np.concatenate([key(r, p["ph"]) for r, p in enumerate(allp)])      # phantoms may touch no foreground above / below:
-            nodes, inv = np.unique(np.concatenate([EA, EB, phk]), return_inverse=True)   # they are nodes all the same (dropped labels)
-            nn = nodes.size
-            root = np.zeros(nn, np.int64)
-            if nn:
-                ia, ib = np.ascontiguousarray(inv[:EA.size]), np.ascontiguousarray(inv[EA.size:2 * EA.size])
-                _lib.call("mhip_band_union_find", _lib.i64(nn), _lib.i64(EA.size), _lib.ptr(ia), _lib.ptr(ib), _lib.ptr(root))
-            _, cls = np.unique(root, return_inverse=True)
-            ncls = int(cls.max()) + 1 if nn else 0
-            node_rank = (nodes >> 32).astype(np.int64)
-            node_lab = (nodes & 0xffffffff).astype(np.int64)
-            phantom = np.isin(nodes, phk, assume_unique=False)
-            # class owner = smallest rank with a real member; representative = smallest local label of the owner's members
-            big = np.int64(1) << 62
-            score = np.where(phantom, big, nodes)
-            rep_score = np.full(ncls, big, np.int64)
-            np.minimum.at(rep_score, cls, score)
-            is_rep = score == rep_score[cls]
-            # ---- the numbering of every band: all local labels except the DROPPED ones (phantoms and non-representative class
-            # members) keep their order; kept local label l becomes offset + l - #(dropped labels < l).  `nodes` is sorted by
-            # (rank, label), so the dropped labels of a rank are a sorted slice.
-            bounds = np.searchsorted(node_rank, np.arange(R + 1))
-            drop_of = [node_lab[bounds[r]:bounds[r + 1]][~is_rep[bounds[r]:bounds[r + 1]]] for r in range(R)]
-            n_own = [allp[r]["nloc"] - drop_of[r].size for r in range(R)]
-            offsets = np.concatenate([[0], np.cumsum(n_own)]).astype(np.int64)
-            # global label of a class = the new label of its representative, computed from the representative's band's numbering
-            reps = np.flatnonzero(is_rep)
-            rr, rl = node_rank[reps], node_lab[reps]
-            class_label = np.zeros(ncls, np.int64)
-            newl = np.zeros(reps.size, np.int64)
-            for r in range(R):
-                sel = rr == r
-                if sel.any():
-                    newl[sel] = offsets[r] + rl[sel] - np.searchsorted(drop_of[r], rl[sel])
-            class_label[cls[reps]] = newl
-            dropped = drop_of[me].astype(np.int64)
+            EA = np.ascontiguousarray(np.concatenate([p["ea"] for p in allp]))
+            EB = np.ascontiguousarray(np.concatenate([p["eb"] for p in allp]))
+            PH = np.ascontiguousarray(np.concatenate([p["ph"] for p in allp]))
+            if _PROF and me == 0:
+                print("[band profile] label: %d seam pairs, %d phantoms" % (EA.size, PH.size), file=sys.stderr, flush=True)
+            nlocs = np.array([p["nloc"] for p in allp], np.int64)
+            cap = max(2 * EA.size + PH.size, 1)
+            offsets = np.zeros(R + 1, np.int64)
+            dropped, target, shared = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int64)
+            nd, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+            # the classes (phantoms may touch no foreground above / below: they are dropped labels all the same), the numbering of
+            # every band, my dropped labels with their global labels, and the global labels with cells in more than one band
+            _lib.call("mhip_band_label_merge", R, me, _lib.ptr(nlocs), _lib.i64(EA.size), _lib.ptr(EA), _lib.ptr(EB), _lib.i64(PH.size), _lib.ptr(PH),
+                      _lib.ptr(offsets), _lib.ptr(dropped), _lib.ptr(target), ctypes.byref(nd), _lib.ptr(shared), ctypes.byref(ns))
+            dropped, target = dropped[:nd.value], target[:nd.value]
             off = int(offsets[me])
-            mine_sl = slice(int(bounds[me]), int(bounds[me + 1]))
-            members = ~is_rep[mine_sl]               # (phantoms included: my halo cells then carry the neighbour's global label)
-            target = np.zeros(dropped.size, np.int64)
-            target[np.searchsorted(dropped, node_lab[mine_sl][members])] = class_label[cls[mine_sl][members]]
-            # global labels with cells in more than one band (same array on every rank): their records need a merge
-            real = ~phantom
-            pairs = np.unique(cls[real].astype(np.int64) * R + node_rank[real]) if real.any() else np.zeros(0, np.int64)   # (class, rank)
-            ranks_per_class = np.bincount(pairs // R, minlength=ncls) if ncls else np.zeros(0, np.int64)
-            self.shared_labels = np.unique(class_label[np.flatnonzero(ranks_per_class > 1)]).astype(np.int64)
+            self.shared_labels = shared[:ns.value].copy()
             self.nlabels = int(offsets[-1])
             self.label_range = (int(offsets[me]) + 1, int(offsets[me + 1]))
             self.label_offsets = offsets
@@ -1215,56 +1169,24 @@ class BandPipeline(object):
         nbr_up, nbr_dn = self._neighbour_rows("watersheds")      # the neighbour's LAST row above / FIRST row below
         lap.lap("neighbour rows")
         with self._host("watershed"):
-            up64 = None if nbr_up is None else np.asarray(nbr_up).astype(np.int64)
-            dn64 = None if nbr_dn is None else np.asarray(nbr_dn).astype(np.int64)
-            mine = np.concatenate([first, last]).astype(np.int64)        # index e = side * W + column; node (me, side, column) = 2 me W + e
-            neg = np.flatnonzero(mine < 0)
-            idx = -mine[neg] - 1
-            to_up = idx < W
-            tgt_node = np.where(to_up, (2 * (me - 1) + 1) * W + idx, (2 * (me + 1)) * W + (idx - W))
-            tgt_val = np.zeros(neg.size, np.int64)
-            if up64 is not None:
-                tgt_val[to_up] = up64[idx[to_up]]
-            if dn64 is not None:
-                tgt_val[~to_up] = dn64[idx[~to_up] - W]
-            entry = np.where(tgt_val >= 0, tgt_val, -(tgt_node + 1))
-            pointed = np.zeros(2 * W, bool)
-            if up64 is not None:        # their pseudo labels >= W point at their bottom halo = my first row
-                j = -up64[up64 < 0] - 1
-                pointed[j[j >= W] - W] = True
-            if dn64 is not None:        # their pseudo labels < W point at their top halo = my last row
-                j = -dn64[dn64 < 0] - 1
-                pointed[W + j[j < W]] = True
-            pub = pointed[neg] | (tgt_val < 0)
-            mine_pub = ((2 * me * W + neg[pub]).astype(np.int64), entry[pub].astype(np.int64))
+            up = None if nbr_up is None else np.ascontiguousarray(nbr_up, dtype=np.int32)
+            dn = None if nbr_dn is None else np.ascontiguousarray(nbr_dn, dtype=np.int32)
+            mine = np.ascontiguousarray(np.concatenate([first, last]), dtype=np.int32)   # index e = side * W + column; node 2 me W + e
+            N, V, n = np.empty(2 * W, np.int64), np.empty(2 * W, np.int64), ctypes.c_int64(0)
+            pu = _lib.ptr(up) if up is not None else None
+            pd = _lib.ptr(dn) if dn is not None else None
+            _lib.call("mhip_band_ws_publish", _lib.i64(W), me, _lib.ptr(mine), pu, pd, _lib.ptr(N), _lib.ptr(V), ctypes.byref(n))
+            mine_pub = (N[:n.value], V[:n.value])
         parts = comm.allgather(mine_pub)
         with self._host("watershed"):
-            N = np.concatenate([p[0] for p in parts])
-            V = np.concatenate([p[1] for p in parts])
-            order = np.argsort(N)
-            N, V = N[order], V[order]
-            ptr = V < 0
-            if ptr.any():
-                t = -V[ptr] - 1
-                pos = np.searchsorted(N, t)
-                ok = (pos < N.size) & (N[np.minimum(pos, max(N.size - 1, 0))] == t) if N.size else np.zeros(t.size, bool)
-                V[ptr] = np.where(ok, -(pos + 1), 0)          # (a target nobody published: nobody needs it either)
-                V = np.ascontiguousarray(V)
-                _lib.call("mhip_band_ws_resolve", _lib.i64(V.size), _lib.ptr(V))
-            lut = np.zeros(2 * W, np.int64)
-            for row, base, sl in ((up64, (2 * (me - 1) + 1) * W, slice(0, W)), (dn64, (2 * (me + 1)) * W, slice(W, 2 * W))):
-                if row is None:
-                    continue
-                r = row.copy()
-                k = np.flatnonzero(r < 0)
-                if k.size:
-                    pos = np.searchsorted(N, base + k)
-                    pos_c = np.minimum(pos, max(N.size - 1, 0))
-                    found = (pos < N.size) & (N[pos_c] == base + k) if N.size else np.zeros(k.size, bool)
-                    r[k] = np.where(found, V[pos_c] if N.size else 0, 0)
-                lut[sl] = r
+            N = np.ascontiguousarray(np.concatenate([p[0] for p in parts]))
+            V = np.ascontiguousarray(np.concatenate([p[1] for p in parts]))
+            if _PROF and me == 0:
+                print("[band profile] watershed: %d published chain cells" % N.size, file=sys.stderr, flush=True)
+            lut = np.empty(2 * W, np.int32)
+            _lib.call("mhip_band_ws_lut", _lib.i64(W), me, _lib.i64(N.size), _lib.ptr(N), _lib.ptr(V), pu, pd, _lib.ptr(lut))
         lap.lap("seam system (host + allgather)")
-        self._local(b.apply_neg_lut, "watersheds", lut.astype(np.int32))
+        self._local(b.apply_neg_lut, "watersheds", lut)
         lap.lap("apply_neg_lut")
         lap.report()
 
@@ -1275,10 +1197,12 @@ class BandPipeline(object):
         """the communicator of the calling thread: the clone inside run_chain's labelling branch, else the main one"""
         return getattr(self._tls, "comm", None) or self.comm
 
-    def _merged(self, which, merge, fetch_own=True):
-        """own-range slice of record set `which`, with the labels that live in several bands (and the background) merged
-        by `merge(list of per-rank record arrays) -> array`.  fetch_own=False: compute and merge only (the slice of this
-        band's own labels stays on the device, like the records of the single-GPU pipeline until somebody asks for them)"""
+    def _merged(self, which, fetch_own=True):
+        """own-range slice of record set `which`, with the labels that live in several bands (and the background) merged in band
+        order (``mhip_band_merge_records``: min / max / sums for the statistics; for the pour points the larger -- no accumulated
+        flow: smaller -- value wins and the earlier band, i.e. the first raster position, on ties).  fetch_own=False: compute and
+        merge only (the slice of this band's own labels stays on the device, like the records of the single-GPU pipeline until
+        somebody asks for them)"""
         b, (lo, hi) = self.band, self.label_range
         lap = _Lap("records %d" % which, self.comm.rank)
         ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
@@ -1287,7 +1211,10 @@ class BandPipeline(object):
         parts = self._cur_comm().allgather(g)
         lap.lap("allgather")
         with self._host("records"):
-            m = merge(parts)
+            parts = [np.ascontiguousarray(p, dtype=g.dtype) for p in parts]
+            m = np.empty_like(g)
+            pp = (ctypes.c_void_p * len(parts))(*[p.ctypes.data for p in parts])
+            _lib.call("mhip_band_merge_records", int(which), len(parts), _lib.i64(g.size), pp, _lib.ptr(m))
         lap.lap("merge")
         lap.report()
         if not fetch_own:
@@ -1299,15 +1226,7 @@ class BandPipeline(object):
 
     def stats(self, fetch_own=True):
         """label.label_stats(depths, labels): min / max / sum / count per bluespot."""
-        def merge(parts):
-            m = parts[0].copy()
-            for p in parts[1:]:
-                m["min"] = np.minimum(m["min"], p["min"])
-                m["max"] = np.maximum(m["max"], p["max"])
-                m["sum"] = m["sum"] + p["sum"]
-                m["count"] = m["count"] + p["count"]
-            return m
-        return self._merged(0, merge, fetch_own)
+        return self._merged(0, fetch_own)
 
     def watershed_counts(self, fetch_own=True):
         """label.label_count(watersheds): cells per watershed.  A watershed may reach into any band, so every rank publishes
@@ -1323,27 +1242,20 @@ class BandPipeline(object):
         lap.lap("compute + fetch + foreign %d" % fid.size)
         lap.report()
         total0 = 0
-        for r, (ids, vals, c0) in enumerate(self._cur_comm().allgather((fid, fval, bg))):
-            total0 += c0
-            if r != self.comm.rank and own is not None:
-                mine = (ids >= lo) & (ids <= hi)
-                np.add.at(own, ids[mine] - lo, vals[mine])
+        gathered = self._cur_comm().allgather((fid, fval, bg))
+        with self._host("records"):
+            for r, (ids, vals, c0) in enumerate(gathered):
+                total0 += c0
+                if r != self.comm.rank and own is not None:
+                    mine = (ids >= lo) & (ids <= hi)
+                    np.add.at(own, ids[mine] - lo, vals[mine])
         return {"first_label": lo, "records": own, "background": np.int64(total0)}
 
     def pourpoints(self, fetch_own=True, use_accum=True):
         """label.label_max_index(accum, labels) -- or label.label_min_index(no-flats surface, labels) when no accumulated flow
         was asked for (reference bluespots.py:195-206): value, row, col of the first raster cell with the extreme value per
         bluespot (rows are global)."""
-        def merge(parts):
-            m = parts[0].copy()
-            for p in parts[1:]:
-                # strict comparison with the first raster position on ties: bands are in raster order, an earlier band wins ties
-                better = (p["value"] > m["value"]) if use_accum else (p["value"] < m["value"])
-                better |= (m["row"] < 0) & (p["row"] >= 0)
-                better &= p["row"] >= 0
-                m[better] = p[better]
-            return m
-        return self._merged(2 if use_accum else 3, merge, fetch_own)
+        return self._merged(2 if use_accum else 3, fetch_own)
 
     # ---- the bluespot filter on bands (reference bluespots.py:23-46, 165-172)
     def filter(self, keep_of_records):

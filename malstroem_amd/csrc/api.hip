@@ -512,6 +512,7 @@ struct mhip_ctx {
     DevBuf tmp_i32;         // CCL parent scratch
     DevBuf raw_stats, stats, ws_counts, pour;
     int64_t nlabels_raw = -1, nlabels = -1;
+    bool labels_components = false;   // LABELS came from the library's own labelling (not uploaded): 8-connected components
     bool labels_filtered = false;
     double sh = 0, dg = 0;
     int32_t fill_rounds = 0, noflat_rounds = 0;
@@ -684,7 +685,7 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
     if (which == MHIP_R_DEM)  // a new DEM invalidates everything derived from the previous one
         for (int k = 0; k < MHIP_R_COUNT_; ++k)
             if (k != MHIP_R_DEM) c->have[k] = false;
-    if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; }
+    if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; c->labels_components = false; }
     if (which == MHIP_R_FLOWDIR) c->nodir_valid = false;
     return MHIP_OK;
 }
@@ -708,7 +709,7 @@ int mhip_ctx_upload_rows(mhip_ctx *c, int which, int64_t row0, int64_t nrows, co
     MH_HIP(hipStreamSynchronize(cs(c)));      // the caller reuses its window buffer
     if (row0 + nrows == c->H_owned) {
         c->have[which] = true;
-        if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; }
+        if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; c->labels_components = false; }
     }
     return MHIP_OK;
 }
@@ -916,6 +917,7 @@ int mhip_ctx_band_ccl_local(mhip_ctx *c, int64_t *nlocal)
                         nlocal, cs(c)));
     c->nlabels_raw = *nlocal;
     c->have[MHIP_R_LABELS] = true;
+    c->labels_components = true;     // (the relabelling calls of the band protocol join components across bands and drop components)
     c->labels_filtered = false;
     return MHIP_OK;
 }
@@ -1099,7 +1101,7 @@ int mhip_ctx_band_records(mhip_ctx *c, int which)
     if (which == 0) {
         MH_ARG(c->have[MHIP_R_DEPTHS], "label_stats needs the depths");
         MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, n, c->nlabels,
-                               buf.as<mhip_stat_record>(), cs(c), c->W));
+                               buf.as<mhip_stat_record>(), cs(c), c->W, c->labels_components));
     } else if (which == 1) {
         MH_ARG(c->have[MHIP_R_WATERSHEDS], "watershed counts need the watersheds");
         MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>() + off, n, c->nlabels, buf.as<int64_t>(), cs(c), c->W));
@@ -1108,7 +1110,7 @@ int mhip_ctx_band_records(mhip_ctx *c, int which)
         const int src = which == 2 ? MHIP_R_ACCUM : MHIP_R_NOFLAT;
         MH_ARG(c->have[src], which == 2 ? "pour points need the accumulated flow" : "pour points need the no-flats surface");
         MH_TRY(label_arg_dev(c->r[src].as<double>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned, c->W, c->nlabels,
-                             which == 2, buf.as<mhip_index_record>(), cs(c)));
+                             which == 2, buf.as<mhip_index_record>(), cs(c), c->labels_components));
         hipLaunchKernelGGL(global_rows_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, cs(c), buf.as<mhip_index_record>(), nrec,
                            c->row0);
         MH_HIP(hipGetLastError());
@@ -1615,10 +1617,11 @@ static int stage_label(mhip_ctx *c, hipStream_t s)
                         &c->nlabels_raw, s));
     MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
     MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
-                           c->raw_stats.as<mhip_stat_record>(), s, W));
+                           c->raw_stats.as<mhip_stat_record>(), s, W, true));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_LABEL] = true;
     c->have[MHIP_R_LABELS] = true;
+    c->labels_components = true;
     c->labels_filtered = false;
     c->nlabels = c->nlabels_raw;
     return MHIP_OK;
@@ -1657,7 +1660,7 @@ static int stage_pourpoints(mhip_ctx *c, hipStream_t s)
     // bluespots.py:195-206: max accumulated flow if available, else min of the no-flats surface
     if (c->have[MHIP_R_ACCUM])
         MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, true,
-                             c->pour.as<mhip_index_record>(), s));
+                             c->pour.as<mhip_index_record>(), s, c->labels_components));
     else
         MH_TRY(label_arg_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, false,
                              c->pour.as<mhip_index_record>(), s));
@@ -1942,7 +1945,7 @@ static int ctx_apply_keep_on(mhip_ctx *c, const uint8_t *keep, hipStream_t s)
         MH_TRY(relabel_lut_dev(c->r[MHIP_R_LABELS].as<int32_t>(), d_lut.as<int32_t>(), c->nlabels_raw, n, s));
         MH_TRY(c->stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1)));
         MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels,
-                               c->stats.as<mhip_stat_record>(), s, c->W));
+                               c->stats.as<mhip_stat_record>(), s, c->W, c->labels_components));   // (kept components stay components)
     } else {
         // keep everything (background excluded by construction): labels and stats are the raw ones
         c->nlabels = c->nlabels_raw;

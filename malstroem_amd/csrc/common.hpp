@@ -262,11 +262,12 @@ int relabel_sparse_dev(int32_t *d_labels, int64_t n, int64_t nlocal, int32_t off
 int keep_mask_dev(const int32_t *d_labels, const uint8_t *d_keep, int64_t nlab, int64_t n, uint8_t *d_mask,
                   hipStream_t s);
 // W: raster width if the caller knows it (2-D tiles combine a label's rows before the global atomics), 0 = flat array
+// components: the labels are the 8-connected components of a raster of which these n cells (rows of W) are a row range
 int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
-                    hipStream_t s, int64_t W = 0);
+                    hipStream_t s, int64_t W = 0, bool components = false);
 int label_stats64_dev(const double *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s);
 int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
-                  mhip_index_record *d_rec, hipStream_t s);
+                  mhip_index_record *d_rec, hipStream_t s, bool components = false);
 int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d_counts, hipStream_t s, int64_t W = 0);
 int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
 // watershed.hip

@@ -111,11 +111,17 @@ template <int TS> __device__ __forceinline__ int table_slot(int *keys, int key)
     return -1;
 }
 
-// Background (label 0) is accumulated in registers over all tiles of a block and leaves as one atomic set per
-// wavefront; other labels are combined per equal-label run (wavefront shuffles), then per tile (LDS table), and leave
-// as one atomic set per (label, tile); the min/max atomics are skipped when a (possibly stale, hence conservative)
-// read shows they cannot improve the record.
+// A thread follows its column down the tile (32 rows x 256 columns per workgroup, four rows of loads in flight) and keeps the
+// VERTICAL run of equal labels it is in -- label, min, max, sum, count -- in registers; when the label changes the run goes to the
+// label's slot of the tile's LDS table, and the table leaves as one record per (label, tile).  Background cells go to registers
+// that leave once per wavefront.  (Until round 3 the equal-label runs ALONG the rows were combined by segmented shuffles first:
+// 35 ds_bpermute per row of 64 cells, 0.8 of the kernel's 1.6 ms; half the cells of the benchmark DEM carry a label, in runs
+// of 7.6 cells, and a vertical run costs nothing until it ends.)
+// COMPONENTS: the caller vouches that the labels are the 8-connected components of a raster this one is a row range of.  A label
+// none of whose cells in the tile lies on the tile's outline (or on the raster's last row) then lives in this tile alone and
+// its record is WRITTEN instead of merged by a load and up to four atomics.
 constexpr int STATS_TS = 1024;
+template <bool COMPONENTS>
 __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
                                                    TileGeom g, int64_t nlab, StatAcc a, unsigned int *bad)
 {
@@ -127,12 +133,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
     double bsum = 0.0;
     unsigned long long bcnt = 0;
     auto to_global = [&](int32_t l, uint32_t kmin, uint32_t kmax, double sum, unsigned long long cnt) {
-        if (kmin < a.minkey[l]) atomicMin(&a.minkey[l], kmin);
+        if (kmin < a.minkey[l]) atomicMin(&a.minkey[l], kmin);     // (a stale read is conservative)
         if (kmax > a.maxkey[l]) atomicMax(&a.maxkey[l], kmax);
         atomicAdd(&a.sum[l], sum);
         atomicAdd(&a.count[l], cnt);
     };
     const int64_t ntiles = g.ntr * g.ntc;
+    const int64_t last_row = cdiv(g.n, g.W) - 1;
+    const bool edge_col = threadIdx.x == 0 || threadIdx.x == 255;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         for (int k = threadIdx.x; k < STATS_TS; k += 256) {
             keys[k] = -1;
@@ -144,68 +152,85 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
         __syncthreads();
         const int64_t tr = tile / g.ntc, tc = tile - tr * g.ntc;
         const int64_t col = tc * 256 + threadIdx.x;
-        for (int r4 = 0; r4 < TR; r4 += 4) {
-        int32_t lq[4];           // four rows' loads in flight
-        float dq[4];
-        bool vq[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = (tr * TR + r4 + u) * g.W + col;
-            vq[u] = col < g.W && i < g.n;
-            lq[u] = vq[u] ? lab[i] : -1;
-            dq[u] = vq[u] ? data[i] : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int32_t l = lq[u];
-            const float v = dq[u];
-            const bool valid = vq[u];
-            if (valid && (l < 0 || l > nlab)) {
-                atomicOr(bad, 1u);
-                l = -1;
+        // the run this thread is in: label (<= 0: none), first tile row, min, max, sum, count
+        int32_t cl = -1;
+        int cstart = 0;
+        float cmin = 0.0f, cmax = 0.0f;
+        double csum = 0.0;
+        unsigned int ccnt = 0;
+        auto end_run = [&](int end_row) {     // the run cl ended in tile row end_row
+            const uint32_t kmin = f32_key(cmin), kmax = f32_key(cmax);
+            const int h = table_slot<STATS_TS>(keys, cl);
+            if (h >= 0) {
+                atomicMin(&tmin[h], kmin);
+                atomicMax(&tmax[h], kmax);
+                atomicAdd(&tsum[h], csum);
+                atomicAdd(&tcnt[h], ccnt);
+                // bit 31 of the count (a tile holds 8192 cells): the label reaches the tile's outline
+                if (COMPONENTS && (edge_col || cstart == 0 || end_row == TR - 1 || tr * TR + end_row >= last_row)) atomicOr(&tcnt[h], 0x80000000u);
+            } else {
+                to_global(cl, kmin, kmax, csum, (unsigned long long)ccnt);
             }
-            const bool isnan = v != v;
-            // NaN never wins `val < min` / `val > max` in the reference; it does poison the sum.
-            float vmin = isnan ? __builtin_inff() : v, vmax = isnan ? -__builtin_inff() : v;
-            if (__all(l <= 0)) {  // wave-uniform fast path: only background (or padding) in this wave
+        };
+        static_assert(TR % 4 == 0, "rows in batches of four");
+        for (int r4 = 0; r4 < TR; r4 += 4) {
+            int32_t lq[4];           // four rows' loads in flight
+            float dq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (tr * TR + r4 + u) * g.W + col;
+                const bool valid = col < g.W && i < g.n;
+                lq[u] = valid ? lab[i] : -1;
+                dq[u] = valid ? data[i] : 0.0f;
+                if (valid && (lq[u] < 0 || lq[u] > nlab)) {
+                    atomicOr(bad, 1u);
+                    lq[u] = -1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t l = lq[u];
+                const float v = dq[u];
+                const bool isnan = v != v;
+                // NaN never wins `val < min` / `val > max` in the reference; it does poison the sum.
+                const float vmin = isnan ? __builtin_inff() : v, vmax = isnan ? -__builtin_inff() : v;
+                if (l != cl) {
+                    if (cl > 0) end_run(r4 + u - 1);
+                    cl = l;
+                    cstart = r4 + u;
+                    cmin = __builtin_inff();
+                    cmax = -__builtin_inff();
+                    csum = 0.0;
+                    ccnt = 0;
+                }
                 if (l == 0) {
                     bmin = fminf(bmin, vmin);
                     bmax = fmaxf(bmax, vmax);
                     bsum += (double)v;
                     ++bcnt;
-                }
-                continue;
-            }
-            const bool ok = l >= 0;
-            const int len = run_length_from(l, lane, ok);
-            const bool head = is_run_head(l, lane, ok);
-            vmin = seg_reduce(vmin, len, [](float x, float y) { return fminf(x, y); });
-            vmax = seg_reduce(vmax, len, [](float x, float y) { return fmaxf(x, y); });
-            const double sm = seg_reduce((double)v, len, [](double x, double y) { return x + y; });
-            if (head && ok) {
-                if (l == 0) {
-                    bmin = fminf(bmin, vmin);
-                    bmax = fmaxf(bmax, vmax);
-                    bsum += sm;
-                    bcnt += (unsigned long long)len;
-                } else {
-                    const uint32_t kmin = f32_key(vmin), kmax = f32_key(vmax);
-                    const int h = table_slot<STATS_TS>(keys, l);
-                    if (h >= 0) {
-                        atomicMin(&tmin[h], kmin);
-                        atomicMax(&tmax[h], kmax);
-                        atomicAdd(&tsum[h], sm);
-                        atomicAdd(&tcnt[h], (unsigned int)len);
-                    } else {
-                        to_global(l, kmin, kmax, sm, (unsigned long long)len);
-                    }
+                } else if (l > 0) {
+                    cmin = fminf(cmin, vmin);
+                    cmax = fmaxf(cmax, vmax);
+                    csum += (double)v;
+                    ++ccnt;
                 }
             }
         }
-        }   // four rows
+        if (cl > 0) end_run(TR - 1);
         __syncthreads();
-        for (int k = threadIdx.x; k < STATS_TS; k += 256)
-            if (keys[k] >= 0) to_global(keys[k], tmin[k], tmax[k], tsum[k], (unsigned long long)tcnt[k]);
+        for (int k = threadIdx.x; k < STATS_TS; k += 256) {
+            const int l = keys[k];
+            if (l < 0) continue;
+            const unsigned int cnt = tcnt[k];
+            if (!COMPONENTS || (cnt >> 31)) {
+                to_global(l, tmin[k], tmax[k], tsum[k], (unsigned long long)(cnt & 0x7fffffffu));
+            } else {
+                a.minkey[l] = tmin[k];
+                a.maxkey[l] = tmax[k];
+                a.sum[l] = tsum[k];
+                a.count[l] = (unsigned long long)cnt;
+            }
+        }
         __syncthreads();
     }
 #pragma unroll
@@ -369,50 +394,92 @@ __global__ __launch_bounds__(256) void arg_pass2_kernel(const double *__restrict
 // value and position share one 64-bit key, (value << 32) | (0xffffffff - index): the largest key is the largest value at
 // its FIRST raster position, so one atomicMax per run replaces the two passes above.  Needs 0 <= value < 2**32 integral
 // and fewer than 2**32 - 1 cells; a cell that does not qualify raises `notint` and the caller falls back to the two passes.
-__global__ __launch_bounds__(256) void arg_packed_kernel(const double *__restrict__ data, const int32_t *__restrict__ lab,
-                                                        int64_t n, int64_t nlab, uint64_t *key, unsigned int *bad,
-                                                        unsigned int *notint)
+// Tiled like stats_kernel: a thread follows its column down the tile and keeps the largest
+// key of the vertical run it is in; runs go to the tile's LDS table when they end, the table leaves as one atomicMax per
+// (label, tile) -- or as a plain store for a component that lies inside the tile (COMPONENTS, see stats_kernel).
+constexpr int ARG_TS = 1024;
+template <bool COMPONENTS>
+__global__ __launch_bounds__(256) void arg_packed_kernel(const double *__restrict__ data, const int32_t *__restrict__ lab, TileGeom g, int64_t nlab,
+                                                        uint64_t *key, unsigned int *bad, unsigned int *notint)
 {
+    __shared__ int keys[ARG_TS];
+    __shared__ unsigned long long tkey[ARG_TS];
+    __shared__ unsigned char tout[ARG_TS];
     const int lane = threadIdx.x & 63;
     uint64_t bkey = 0;  // background (label 0), kept in registers
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t nloop = cdiv(n, 4 * stride) * 4 * stride;
-    for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < nloop; i4 += 4 * stride) {
-    int32_t lq[4];       // four strides' loads in flight
-    double dq[4];
+    const int64_t ntiles = g.ntr * g.ntc;
+    const int64_t last_row = cdiv(g.n, g.W) - 1;
+    const bool edge_col = threadIdx.x == 0 || threadIdx.x == 255;
+    unsigned int any_bad = 0, any_notint = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int k = threadIdx.x; k < ARG_TS; k += 256) {
+            keys[k] = -1;
+            tkey[k] = 0ull;
+            tout[k] = 0;
+        }
+        __syncthreads();
+        const int64_t tr = tile / g.ntc, tc = tile - tr * g.ntc;
+        const int64_t col = tc * 256 + threadIdx.x;
+        int32_t cl = -1;
+        int cstart = 0;
+        uint64_t ckey = 0;
+        auto end_run = [&](int end_row) {
+            const int h = table_slot<ARG_TS>(keys, cl);
+            if (h >= 0) {
+                atomicMax(&tkey[h], (unsigned long long)ckey);
+                if (COMPONENTS && (edge_col || cstart == 0 || end_row == TR - 1 || tr * TR + end_row >= last_row)) tout[h] = 1;
+            } else if (ckey > key[cl]) {
+                atomicMax(reinterpret_cast<unsigned long long *>(&key[cl]), (unsigned long long)ckey);
+            }
+        };
+        for (int r4 = 0; r4 < TR; r4 += 4) {
+            int32_t lq[4];       // four rows' loads in flight
+            double dq[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = i4 + u * stride;
-        lq[u] = i < n ? lab[i] : -1;
-        dq[u] = i < n ? data[i] : 0.0;
-    }
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (tr * TR + r4 + u) * g.W + col;
+                const bool valid = col < g.W && i < g.n;
+                lq[u] = valid ? lab[i] : -1;
+                dq[u] = valid ? data[i] : 0.0;
+                if (valid && (lq[u] < 0 || lq[u] > nlab)) {
+                    any_bad = 1;
+                    lq[u] = -1;
+                }
+            }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int64_t i = i4 + u * stride;
-        const bool valid = i < n;
-        int32_t l = lq[u];
-        if (valid && (l < 0 || l > nlab)) {
-            atomicOr(bad, 1u);
-            l = -1;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = (tr * TR + r4 + u) * g.W + col;
+                const int32_t l = lq[u];
+                const double v = dq[u];
+                const bool isint = v >= 0.0 && v < 4294967296.0 && (double)(uint32_t)v == v;   // false for NaN
+                if (l >= 0 && !isint) any_notint = 1;
+                const uint64_t k = ((uint64_t)(uint32_t)v << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+                if (l != cl) {
+                    if (cl > 0) end_run(r4 + u - 1);
+                    cl = l;
+                    cstart = r4 + u;
+                    ckey = 0;
+                }
+                if (l == 0) bkey = k > bkey ? k : bkey;
+                else if (l > 0) ckey = k > ckey ? k : ckey;
+            }
         }
-        const double v = dq[u];
-        const bool isint = v >= 0.0 && v < 4294967296.0 && (double)(uint32_t)v == v;   // false for NaN
-        if (valid && !isint) atomicOr(notint, 1u);
-        uint64_t k = ((uint64_t)(uint32_t)v << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
-        if (__all(l <= 0)) {
-            if (l == 0) bkey = k > bkey ? k : bkey;
-            continue;
+        if (cl > 0) end_run(TR - 1);
+        __syncthreads();
+        for (int k = threadIdx.x; k < ARG_TS; k += 256) {
+            const int l = keys[k];
+            if (l < 0) continue;
+            const unsigned long long kk = tkey[k];
+            if (!COMPONENTS || tout[k]) {
+                if (kk > key[l]) atomicMax(reinterpret_cast<unsigned long long *>(&key[l]), kk);
+            } else {
+                key[l] = kk;
+            }
         }
-        const bool ok = l >= 0;
-        const int len = run_length_from(l, lane, ok);
-        const bool head = is_run_head(l, lane, ok);
-        k = seg_reduce(k, len, [](uint64_t x, uint64_t y) { return x > y ? x : y; });
-        if (head && ok) {
-            if (l == 0) bkey = k > bkey ? k : bkey;
-            else if (k > key[l]) atomicMax(reinterpret_cast<unsigned long long *>(&key[l]), (unsigned long long)k);
-        }
+        __syncthreads();
     }
-    }   // four strides
+    if (any_bad) atomicOr(bad, 1u);
+    if (any_notint) atomicOr(notint, 1u);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint64_t ob = __shfl_xor(bkey, o);
@@ -631,7 +698,7 @@ static unsigned tile_grid(const TileGeom &g)
 }
 
 int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec,
-                    hipStream_t s, int64_t W)
+                    hipStream_t s, int64_t W, bool components)
 {
     const int64_t nrec = nlab + 1;
     DevBuf mn, mx, sm, ct, bad;
@@ -644,7 +711,12 @@ int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int
     StatAcc a{mn.as<uint32_t>(), mx.as<uint32_t>(), sm.as<double>(), ct.as<unsigned long long>()};
     hipLaunchKernelGGL(stats_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
     const TileGeom g = tile_geom(n, W);
-    hipLaunchKernelGGL(stats_kernel, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
+    // (the shortcut for components needs the raster's real geometry: tile_geom treats a flat array as 256 columns wide)
+    // (the shortcut for components needs the raster's real geometry: tile_geom treats a flat array as 256 columns wide)
+    if (components && W > 0 && n % W == 0)
+        hipLaunchKernelGGL(stats_kernel<true>, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
+    else
+        hipLaunchKernelGGL(stats_kernel<false>, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
     hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "label_stats");
@@ -669,7 +741,7 @@ int label_stats64_dev(const double *d_data, const int32_t *d_labels, int64_t n, 
 }
 
 int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, bool is_max,
-                  mhip_index_record *d_rec, hipStream_t s)
+                  mhip_index_record *d_rec, hipStream_t s, bool components)
 {
     const int64_t nrec = nlab + 1, n = H * W;
     DevBuf key, idx, bad;
@@ -684,8 +756,13 @@ int label_arg_dev(const double *d_data, const int32_t *d_labels, int64_t H, int6
         MH_TRY(ni.alloc(4));
         MH_HIP(hipMemsetAsync(ni.p, 0, 4, s));
         MH_HIP(hipMemsetAsync(key.p, 0, 8 * (size_t)nrec, s));
-        hipLaunchKernelGGL(arg_packed_kernel, dim3(stride_grid(n)), dim3(256), 0, s, d_data, d_labels, n, nlab, key.as<uint64_t>(),
-                           bad.as<unsigned int>(), ni.as<unsigned int>());
+        const TileGeom g = tile_geom(n, W);
+        if (components)
+            hipLaunchKernelGGL(arg_packed_kernel<true>, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, key.as<uint64_t>(),
+                               bad.as<unsigned int>(), ni.as<unsigned int>());
+        else
+            hipLaunchKernelGGL(arg_packed_kernel<false>, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, key.as<uint64_t>(),
+                               bad.as<unsigned int>(), ni.as<unsigned int>());
         hipLaunchKernelGGL(arg_packed_finish_kernel, dim3(gr), dim3(256), 0, s, d_data, key.as<uint64_t>(), nrec, W, d_rec);
         MH_HIP(hipGetLastError());
         unsigned int h_ni = 0;

@@ -587,6 +587,7 @@ int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t ro
     // branch of mhip_ctx_run fills the gaps on streams of the lowest
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (const char *e = dev_env("MHIP_MAIN_PRIO")) prio_greatest = atoi(e) ? prio_greatest : prio_least;   // development knob
     if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest) != hipSuccess) {
         comm_destroy(c->comm);
         delete c;
@@ -1724,6 +1725,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         }
         int least = 0, greatest = 0;
         MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (const char *e = dev_env("MHIP_SIDE_PRIO")) least = atoi(e) ? greatest : least;   // development knob
         MH_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, least));
         return MHIP_OK;
     };
@@ -1768,7 +1770,8 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
             MH_HIP(hipSetDevice(c->device));
             // the epsilon of the no-flats fill only needs the DEM: computed while the plain fill runs
             int rc_e = MHIP_OK;
-            if (mask & MHIP_STAGE_NOFLAT) rc_e = short_diag_dev(c->r[MHIP_R_DEM].as<float>(), c->H * c->W, &c->sh, &c->dg, sb);
+            // (with the plain fill in the same request its first kernel delivers the DEM's extremes: see below)
+            if ((mask & MHIP_STAGE_NOFLAT) && !do_fill) rc_e = short_diag_dev(c->r[MHIP_R_DEM].as<float>(), c->H * c->W, &c->sh, &c->dg, sb);
             if (rc_e != MHIP_OK) snprintf(err_b, sizeof(err_b), "%s", get_error());
             shdg_done.set_value(rc_e);
             shdg_set = true;
@@ -1811,6 +1814,12 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     const int rc_e = shdg_fut.get();
     if (rc_a == MHIP_OK) rc_a = [&]() -> int {
         MH_TRY(rc_e);
+        if (do_fill && (mask & MHIP_STAGE_NOFLAT)) {
+            // minimum_safe_short_and_diag: from the extremes the priority-flood's tile kernel found on its way through the DEM; the
+            // iterative schedule (fall-back) has none: one pass over the DEM
+            if (c->fill_st.have_minmax) short_diag_from_minmax(c->fill_st.dem_min, c->fill_st.dem_max, c->fill_st.dem_nan, &c->sh, &c->dg);
+            else MH_TRY(short_diag_dev(c->r[MHIP_R_DEM].as<float>(), c->H * c->W, &c->sh, &c->dg, s));
+        }
         static const int label_start = [] { const char *e = dev_env("MHIP_LABEL_START"); return e ? atoi(e) : 2; }();   // 0: with the no-flats fill, 1: at its tail, 2: after it
         if (label_start == 0) tail_hook.fire(s);
         if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, /*shdg_done=*/true, label_start == 1 ? &tail_hook : nullptr));

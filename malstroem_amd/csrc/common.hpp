@@ -115,6 +115,9 @@ struct FillStats {
     int32_t hot_launches = 0;   // the ng_round_kernel launches (the span of the round loop: compaction launches and gaps included)
     int32_t algorithm = 0;  // 0: iterative tile schedule (fill.hip), 1: tiled priority-flood (pflood.hip; rounds = kernel launches),
                             // 2: integer geodesic transform (noflat_geo.hip)
+    // the priority-flood reads every DEM cell anyway: smallest / largest elevation of the local raster and "holds a NaN" ride along
+    bool have_minmax = false, dem_nan = false;
+    float dem_min = 0.0f, dem_max = 0.0f;
 };
 
 // fill.hip
@@ -225,6 +228,7 @@ int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t 
 // d8.hip
 int d8_dev(const double *d_z, uint8_t *d_out, int64_t H, int64_t W, int edges_outward, hipStream_t s, int64_t row_off = 0,
            int64_t Hg = 0, unsigned int *d_interior_nodir = nullptr);   // d_interior_nodir (edges_outward only): left != 0 when an interior cell got NODIR (pre-zeroed by the caller)
+void short_diag_from_minmax(float mn, float mx, bool has_nan, double *sh, double *dg);   // fill.py:235-250
 int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, hipStream_t s);
 int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed, hipStream_t s);
 int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s);

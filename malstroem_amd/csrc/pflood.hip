@@ -68,6 +68,7 @@ struct PfArgs {
     int fixed_top, fixed_bot;   // row band: local row 0 / H - 1 is a halo row of the neighbouring band (a ring row, not a raster border)
     uint32_t *Lv;           // [ntiles * NSMAX] minimax level of every seed (keys)
     unsigned int *flags;    // [0]: overflow
+    uint32_t *mm;           // [ntiles * 8 * 2] per wavefront of pf_tile_kernel: smallest | largest elevation key of its strip (all ones: a NaN)
     unsigned long long *prof;   // -DPF_PROFILE builds: clock ticks per phase of pf_tile_kernel, summed over the tiles
     int stop;                   // -DPF_PHASES builds: pf_tile_kernel returns after phase `stop` - 1 (timing launches only)
 };
@@ -174,6 +175,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     auto cls = [&](int k) -> uint8_t { return (uint8_t)((clsw >> (4 * k)) & 7u); };
     {
         int so = 0;
+        // the DEM's smallest and largest elevation ride along (minimum_safe_short_and_diag, fill.py:235-250, wants them before the
+        // no-flats fill: a separate pass over the DEM next to this kernel cost it 0.4 ms): keys of the cells inside the raster,
+        // all ones for a NaN (np.amax / np.amin propagate it)
+        uint32_t klo = 0xffffffffu, khi = 0u;
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int wr = wr0 + k;
@@ -181,7 +186,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             clsw |= (uint32_t)c << (4 * k);
             const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdem, lane_b * 4, so * 4, 0));
             zk[wr * WN + wc] = c ? dem_key(v) : KINV;
+            const uint32_t kv = v != v ? 0xffffffffu : f32_key(v);
+            klo = c && kv < klo ? kv : klo;
+            khi = c && kv > khi ? kv : khi;
             so = k + 1 < nrow_in ? so + Wi : so;
+        }
+        if (a.mm) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t lo2 = (uint32_t)__shfl_xor((int)klo, o), hi2 = (uint32_t)__shfl_xor((int)khi, o);
+                klo = lo2 < klo ? lo2 : klo;
+                khi = hi2 > khi ? hi2 : khi;
+            }
+            if (wc == 0) {
+                a.mm[((size_t)tile * (NT / 64) + q) * 2] = klo;
+                a.mm[((size_t)tile * (NT / 64) + q) * 2 + 1] = khi;
+            }
         }
     }
     if (t == 0) { s_cnt = 0; s_ne = 0; }
@@ -1193,6 +1213,31 @@ __global__ void pf_fill_f32_kernel(float *p, int64_t n, float v)
 
 }  // namespace
 
+// the per-wavefront elevation keys of pf_tile_kernel -> out[0] = smallest, out[1] = largest (all ones: the DEM holds a NaN)
+__global__ __launch_bounds__(256) void pf_minmax_kernel(const uint32_t *__restrict__ mm, int64_t npairs, uint32_t *out)
+{
+    __shared__ uint32_t lo_l[4], hi_l[4];
+    uint32_t klo = 0xffffffffu, khi = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * 256) {
+        const uint2 v = reinterpret_cast<const uint2 *>(mm)[i];
+        klo = v.x < klo ? v.x : klo;
+        khi = v.y > khi ? v.y : khi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo2 = (uint32_t)__shfl_xor((int)klo, o), hi2 = (uint32_t)__shfl_xor((int)khi, o);
+        klo = lo2 < klo ? lo2 : klo;
+        khi = hi2 > khi ? hi2 : khi;
+    }
+    if ((threadIdx.x & 63) == 0) { lo_l[threadIdx.x >> 6] = klo; hi_l[threadIdx.x >> 6] = khi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { klo = lo_l[k] < klo ? lo_l[k] : klo; khi = hi_l[k] > khi ? hi_l[k] : khi; }
+        atomicMin(&out[0], klo);
+        atomicMax(&out[1], khi);
+    }
+}
+
 // ---- the resumable run -------------------------------------------------------------------------------------------------------
 struct PfRun::Impl {
     DevBuf ws;
@@ -1206,6 +1251,9 @@ struct PfRun::Impl {
     size_t nslots = 0;
     int nbr = 0, nbc = 0, round = 0, launches = 0;
     bool halo_dirty = false;
+    uint32_t *mmout = nullptr;          // [2] smallest | largest elevation key of the raster (pf_minmax_kernel)
+    uint32_t h_mm[2] = {0xffffffffu, 0u};
+    bool mm_valid = false;
     hipEvent_t k1_e0 = nullptr, k1_e1 = nullptr;    // around pf_tile_kernel (the stage's largest launch)
     ~Impl()
     {
@@ -1268,7 +1316,9 @@ int PfRun::solve(hipStream_t s)
         MH_HIP(hipGetLastError());
         MH_HIP(hipMemcpyAsync(h_cnt.data(), m.any + m.round + 1, sizeof(unsigned int) * PF_BATCH, hipMemcpyDeviceToHost, s));
         MH_HIP(hipMemcpyAsync(&h_flag, m.a.flags, 4, hipMemcpyDeviceToHost, s));
+        if (!m.mm_valid) MH_HIP(hipMemcpyAsync(m.h_mm, m.mmout, 8, hipMemcpyDeviceToHost, s));
         MH_HIP(hipStreamSynchronize(s));
+        m.mm_valid = true;
         if (h_flag) return MHIP_ELIMIT;
         if (dev_env("MHIP_PF_DEBUG")) {
             fprintf(stderr, "[pf_solve] rounds %d..%d appended work:", m.round, m.round + PF_BATCH - 1);
@@ -1327,6 +1377,7 @@ int PfRun::begin(hipStream_t s)
     const size_t o_list = off; off = al(off + m.nslots * 2 * 4);
     const size_t o_cnt = off; off = al(off + (size_t)(PF_MAXR + 2) * 4 + 64 + 32 * 8);
     const size_t o_eblk = off; off = al(off + m.nslots * EMAX * 8);
+    const size_t o_mm = off; off = al(off + (size_t)ntiles * (NT / 64) * 2 * 4 + 64);
     MH_TRY(m.ws.alloc(off));
     char *b = m.ws.as<char>();
     MH_HIP(hipMemsetAsync(b + o_act, 0, o_eblk - o_act, s));              // active bytes, per-round words, flags, visits
@@ -1351,6 +1402,13 @@ int PfRun::begin(hipStream_t s)
     m.mark = reinterpret_cast<unsigned int *>(b + o_act);
     m.list = reinterpret_cast<int *>(b + o_list);
     m.eblk = reinterpret_cast<unsigned long long *>(b + o_eblk);
+    a.mm = reinterpret_cast<uint32_t *>(b + o_mm);
+    m.mmout = a.mm + (size_t)ntiles * (NT / 64) * 2;
+    m.mm_valid = false;
+    {
+        const uint32_t init[2] = {0xffffffffu, 0u};
+        MH_HIP(hipMemcpyAsync(m.mmout, init, sizeof(init), hipMemcpyHostToDevice, s));
+    }
     m.round = 0;
     m.halo_dirty = false;
 
@@ -1400,6 +1458,7 @@ int PfRun::begin(hipStream_t s)
     MH_HIP(hipEventRecord(m.k1_e0, s));
     hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, a);
     MH_HIP(hipEventRecord(m.k1_e1, s));
+    hipLaunchKernelGGL(pf_minmax_kernel, dim3(64), dim3(256), 0, s, a.mm, ntiles * (NT / 64), m.mmout);
     hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
     MH_TRY(pack(s, 0, m.nbr));
     MH_HIP(hipGetLastError());
@@ -1499,6 +1558,12 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
         st->algorithm = 1;
         if (m.k1_e0 && hipEventElapsedTime(&st->hot_ms, m.k1_e0, m.k1_e1) == hipSuccess) st->hot_launches = 1;
         else (void)hipGetLastError();
+        if (m.mm_valid) {
+            st->have_minmax = true;
+            st->dem_nan = m.h_mm[1] == 0xffffffffu;
+            st->dem_min = key_f32(m.h_mm[0]);
+            st->dem_max = st->dem_nan ? 0.0f : key_f32(m.h_mm[1]);
+        }
     } else {
         MH_HIP(hipStreamSynchronize(s));   // the workspace goes back to the pool now
     }

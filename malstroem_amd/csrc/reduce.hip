@@ -219,14 +219,19 @@ int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStr
     unsigned int h[4];
     MH_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
     MH_HIP(hipStreamSynchronize(s));
-    double amax = (double)key_f32(h[0]), amin = (double)key_f32(h[1]);
-    if (h[2]) amax = amin = __builtin_nan("");  // np.amax/np.amin propagate NaN
+    short_diag_from_minmax(key_f32(h[1]), key_f32(h[0]), h[2] != 0, sh, dg);
+    return MHIP_OK;
+}
+
+void short_diag_from_minmax(float mn, float mx, bool has_nan, double *sh, double *dg)
+{
+    double amax = (double)mx, amin = (double)mn;
+    if (has_nan) amax = amin = __builtin_nan("");  // np.amax/np.amin propagate NaN
     double a = __builtin_fabs(amax), b = __builtin_fabs(amin);
     double maxval = a > b ? a : b;  // python max(): first wins on ties/NaN ordering is irrelevant here
     double nextval = __builtin_nextafter(maxval, __builtin_inf());
     *sh = (nextval - maxval) * 1024.0;
     *dg = *sh * __builtin_pow(2.0, 0.5);
-    return MHIP_OK;
 }
 
 int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s)

@@ -494,7 +494,7 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     else
         hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
-    MH_HIP(hipStreamSynchronize(s));  // the node buffer goes back to the pool
+    MH_HIP(stream_sync(s));  // the node buffer goes back to the pool
 #ifdef MH_PROFILE_ACCUM
     {
         unsigned long long pr[2][8];

@@ -7,6 +7,7 @@
 //     with HIP-event timing per stage.
 // There is no CPU fallback anywhere in this file: without a HIP device every compute call returns MHIP_ENODEV.
 #include <cstdarg>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -34,6 +35,20 @@ const char *dev_env(const char *name)
 {
     static const bool on = [] { const char *e = getenv("MHIP_DEVELOPER"); return e && e[0] == '1'; }();
     return on ? getenv(name) : nullptr;
+}
+
+hipError_t stream_sync(hipStream_t s)
+{
+    static const long spin_us = [] { const char *e = getenv("MALSTROEM_HIP_SPIN_US"); return e ? atol(e) : 3000L; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
+    return hipStreamSynchronize(s);
 }
 
 // ---- caching device allocator -------------------------------------------------------------------
@@ -115,7 +130,7 @@ static int upload(DevBuf &b, const void *host, size_t bytes, hipStream_t s)
 static int download(void *host, const DevBuf &b, size_t bytes, hipStream_t s)
 {
     MH_HIP(hipMemcpyAsync(host, b.p, bytes, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 
@@ -422,7 +437,7 @@ static int trace_on_device(const uint8_t *d_fd, const int32_t *d_lab, int64_t H,
     if (out_found) MH_HIP(hipMemcpyAsync(out_found, d_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     if (out_len) MH_HIP(hipMemcpyAsync(out_len, d_n.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     if (total) MH_HIP(hipMemcpyAsync(out_cells, d_p.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 
@@ -607,7 +622,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
 {
     if (!c) return MHIP_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)stream_sync(c->stream);
     for (auto &kv : c->ev) {
         (void)hipEventDestroy(kv.second.first);
         (void)hipEventDestroy(kv.second.second);
@@ -615,7 +630,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
     (void)hipStreamDestroy(c->stream);
     for (hipStream_t st : {c->stream_b, c->stream_c}) {
         if (st) {
-            (void)hipStreamSynchronize(st);
+            (void)stream_sync(st);
             (void)hipStreamDestroy(st);
         }
     }
@@ -669,7 +684,7 @@ int mhip_ctx_side_end(mhip_ctx *c)
 {
     MH_ARG(c && t_side_ctx == c, "ctx_side_end without ctx_side_begin on this thread");
     MH_HIP(hipSetDevice(c->device));
-    MH_HIP(hipStreamSynchronize(c->stream_b));
+    MH_HIP(stream_sync(c->stream_b));
     t_side_ctx = nullptr;
     return MHIP_OK;
 }
@@ -681,7 +696,7 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
     MH_TRY(ctx_raster(c, which));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * c->ht, host, rowb * (size_t)c->H_owned, hipMemcpyHostToDevice, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     c->have[which] = true;
     if (which == MHIP_R_DEM)  // a new DEM invalidates everything derived from the previous one
         for (int k = 0; k < MHIP_R_COUNT_; ++k)
@@ -707,7 +722,7 @@ int mhip_ctx_upload_rows(mhip_ctx *c, int which, int64_t row0, int64_t nrows, co
         for (int k = 0; k < MHIP_R_COUNT_; ++k) c->have[k] = false;
     if (which == MHIP_R_FLOWDIR) c->nodir_valid = false;
     MH_HIP(hipMemcpyAsync(c->r[which].as<char>() + rowb * (size_t)(c->ht + row0), host, rowb * (size_t)nrows, hipMemcpyHostToDevice, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));      // the caller reuses its window buffer
+    MH_HIP(stream_sync(cs(c)));      // the caller reuses its window buffer
     if (row0 + nrows == c->H_owned) {
         c->have[which] = true;
         if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; c->labels_components = false; }
@@ -723,7 +738,7 @@ int mhip_ctx_download_rows(mhip_ctx *c, int which, int64_t row0, int64_t nrows, 
     MH_HIP(hipSetDevice(c->device));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * (size_t)(c->ht + row0), rowb * (size_t)nrows, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -734,7 +749,7 @@ int mhip_ctx_download(mhip_ctx *c, int which, void *host)
     MH_HIP(hipSetDevice(c->device));
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * c->ht, rowb * (size_t)c->H_owned, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -759,7 +774,7 @@ int mhip_ctx_get_edge_row(mhip_ctx *c, int which, int side, void *host)
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     const int64_t row = side == 0 ? c->ht : side == 1 ? c->ht + c->H_owned - 1 : side == 2 ? 0 : c->H - 1;
     MH_HIP(hipMemcpyAsync(host, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -790,7 +805,7 @@ int mhip_ctx_get_edge_row_dev(mhip_ctx *c, int which, int side, void *dev_dst)
     const size_t rowb = raster_elem(which) * (size_t)c->W;
     const int64_t row = side == 0 ? c->ht : side == 1 ? c->ht + c->H_owned - 1 : side == 2 ? 0 : c->H - 1;
     MH_HIP(hipMemcpyAsync(dev_dst, c->r[which].as<char>() + rowb * row, rowb, hipMemcpyDeviceToDevice, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));   // the transport reads the buffer on its own stream
+    MH_HIP(stream_sync(cs(c)));   // the transport reads the buffer on its own stream
     return MHIP_OK;
 }
 
@@ -830,7 +845,7 @@ int mhip_ctx_exchange_halo(mhip_ctx *c, int which, int32_t *changed)
     if (c->hb) MH_TRY(row_update_async(base + rowb * (c->H - 1), c->comm_stage.as<char>() + rowb, (int64_t)rowb, c->comm_flags.as<int>() + 1, s));
     int h[2] = {0, 0};
     MH_HIP(hipMemcpyAsync(h, c->comm_flags.p, 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     changed[0] = h[0];
     changed[1] = h[1];
     return MHIP_OK;
@@ -857,7 +872,7 @@ int mhip_ctx_exchange_edge_rows(mhip_ctx *c, int which, void *host_from_up, void
     MH_TRY(comm_exchange_rows(comm, c->rank, c->nranks, base + rowb * c->ht, base + rowb * (c->ht + c->H_owned - 1), stage.p, rowb, s));
     if (c->ht) MH_HIP(hipMemcpyAsync(host_from_up, stage.p, rowb, hipMemcpyDeviceToHost, s));
     if (c->hb) MH_HIP(hipMemcpyAsync(host_from_down, stage.as<char>() + rowb, rowb, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 
@@ -876,7 +891,7 @@ int mhip_ctx_allreduce_max(mhip_ctx *c, double value, double *out)
     MH_HIP(hipMemcpyAsync(c->comm_word.p, &value, 8, hipMemcpyHostToDevice, s));
     MH_TRY(comm_allreduce_max(c->comm, c->comm_word.as<double>(), s));
     MH_HIP(hipMemcpyAsync(out, c->comm_word.p, 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 
@@ -903,7 +918,7 @@ int mhip_ctx_band_accum_boundary(mhip_ctx *c, int32_t *exit_map)
     MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, cs(c), c->ht, c->hb, 1,
                      d_map.as<int32_t>()));
     MH_HIP(hipMemcpyAsync(exit_map, d_map.p, 8 * (size_t)c->W, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -981,7 +996,7 @@ int mhip_ctx_band_relabel_range(mhip_ctx *c, int64_t lo, int64_t hi, const int32
     }
     MH_TRY(relabel_range_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, (int32_t)lo, (int32_t)hi, d_lut.as<int32_t>(), d_fid.as<int32_t>(),
                              d_fnew.as<int32_t>(), (int32_t)nf, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     c->nlabels = c->nlabels_raw = nlabels_new;
     c->labels_filtered = true;
     return MHIP_OK;
@@ -1025,7 +1040,7 @@ int mhip_ctx_band_trace(mhip_ctx *c, const int64_t *cells_rc, const int32_t *src
     if (out_exit_rc) MH_HIP(hipMemcpyAsync(out_exit_rc, d_e.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));
     if (out_len) MH_HIP(hipMemcpyAsync(out_len, d_n.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     if (total) MH_HIP(hipMemcpyAsync(out_cells, d_p.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 
@@ -1052,7 +1067,7 @@ int mhip_ctx_band_apply_neg_lut(mhip_ctx *c, int which, const int32_t *lut, int6
     MH_TRY(d_lut.alloc(4 * (size_t)n));
     MH_HIP(hipMemcpyAsync(d_lut.p, lut, 4 * (size_t)n, hipMemcpyHostToDevice, cs(c)));
     MH_TRY(negative_lut_dev(c->r[which].as<int32_t>(), c->H * c->W, d_lut.as<int32_t>(), n, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -1128,7 +1143,7 @@ int mhip_ctx_band_fetch(mhip_ctx *c, int which, int64_t first, int64_t count, vo
     MH_HIP(hipSetDevice(c->device));
     const size_t e = band_record_size(which);
     MH_HIP(hipMemcpyAsync(out, band_record_buf(c, which).as<char>() + e * (size_t)first, e * (size_t)count, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -1148,7 +1163,7 @@ int mhip_ctx_band_gather(mhip_ctx *c, int which, const int64_t *ids, int64_t nid
                        d_ids.as<int64_t>(), nids, e, d_out.as<char>());
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(out, d_out.p, (size_t)e * (size_t)nids, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
 }
 
@@ -1169,13 +1184,13 @@ int mhip_ctx_band_foreign_counts(mhip_ctx *c, int64_t lo, int64_t hi, int64_t ca
     MH_HIP(hipGetLastError());
     unsigned long long k = 0;
     MH_HIP(hipMemcpyAsync(&k, d_n.p, 8, hipMemcpyDeviceToHost, cs(c)));
-    MH_HIP(hipStreamSynchronize(cs(c)));
+    MH_HIP(stream_sync(cs(c)));
     *nfound = (int64_t)k;
     const int64_t take = (int64_t)k < cap ? (int64_t)k : cap;
     if (take > 0) {
         MH_HIP(hipMemcpyAsync(ids, d_ids.p, 8 * (size_t)take, hipMemcpyDeviceToHost, cs(c)));
         MH_HIP(hipMemcpyAsync(counts, d_vals.p, 8 * (size_t)take, hipMemcpyDeviceToHost, cs(c)));
-        MH_HIP(hipStreamSynchronize(cs(c)));
+        MH_HIP(stream_sync(cs(c)));
     }
     return MHIP_OK;
 }
@@ -1486,7 +1501,7 @@ int mhip_ctx_trace_downstream(mhip_ctx *c, const int64_t *cells_rc, int64_t n, i
 int mhip_ctx_sync(mhip_ctx *c)
 {
     MH_ARG(c, "ctx");
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(stream_sync(c->stream));
     return MHIP_OK;
 }
 
@@ -1930,7 +1945,7 @@ int mhip_ctx_raw_stats(mhip_ctx *c, mhip_stat_record *records)
     MH_ARG(c && records && c->raw_stats.p && c->nlabels_raw >= 0, "ctx_raw_stats needs a LABEL run");
     MH_HIP(hipMemcpyAsync(records, c->raw_stats.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1), hipMemcpyDeviceToHost,
                           c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(stream_sync(c->stream));
     return MHIP_OK;
 }
 
@@ -1970,7 +1985,7 @@ int mhip_ctx_stats(mhip_ctx *c, mhip_stat_record *records)
 {
     MH_ARG(c && records && c->stats.p && c->labels_filtered, "ctx_stats needs LABEL + apply_keep");
     MH_HIP(hipMemcpyAsync(records, c->stats.p, sizeof(mhip_stat_record) * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(stream_sync(c->stream));
     return MHIP_OK;
 }
 
@@ -1978,7 +1993,7 @@ int mhip_ctx_watershed_counts(mhip_ctx *c, int64_t *counts)
 {
     MH_ARG(c && counts && c->ws_counts.p, "ctx_watershed_counts needs a WATERSHED run");
     MH_HIP(hipMemcpyAsync(counts, c->ws_counts.p, 8 * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(stream_sync(c->stream));
     return MHIP_OK;
 }
 
@@ -1986,7 +2001,7 @@ int mhip_ctx_pourpoints(mhip_ctx *c, mhip_index_record *records)
 {
     MH_ARG(c && records && c->pour.p, "ctx_pourpoints needs a POURPOINTS run");
     MH_HIP(hipMemcpyAsync(records, c->pour.p, sizeof(mhip_index_record) * (size_t)(c->nlabels + 1), hipMemcpyDeviceToHost, c->stream));
-    MH_HIP(hipStreamSynchronize(c->stream));
+    MH_HIP(stream_sync(c->stream));
     return MHIP_OK;
 }
 

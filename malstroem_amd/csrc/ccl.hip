@@ -458,14 +458,14 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
         MH_HIP(hipGetLastError());
         unsigned long long h_total = 0;
         MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));     // (the scratch buffers of this branch go back to the pool after the sync)
+        MH_HIP(stream_sync(s));     // (the scratch buffers of this branch go back to the pool after the sync)
         *nlabels = (int64_t)h_total;
         return MHIP_OK;
     }
     MH_HIP(hipGetLastError());
     unsigned long long h_total = 0;
     MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     *nlabels = (int64_t)h_total;
     return MHIP_OK;
 }

@@ -16,6 +16,9 @@ const char *get_error();
 // Development knobs and test hooks (engine selection for A/B runs, debug prints, fault injection for the liveness tests of the
 // run-time checks) are read ONLY when MHIP_DEVELOPER=1 is set: a stray variable in a user's environment never steers the product.
 const char *dev_env(const char *name);
+// hipStreamSynchronize with a short busy wait first: the round loops of the fills read a few words back every 16-32 launches and
+// the device idles while a sleeping host thread is woken (30-50 us per read-back; MALSTROEM_HIP_SPIN_US=0 turns the busy wait off)
+hipError_t stream_sync(hipStream_t s);
 
 #define MH_HIP(expr)                                                                             \
     do {                                                                                         \

@@ -861,7 +861,7 @@ int FillRun::begin(hipStream_t s, bool *active)
     m.rounds_used = 1;
     unsigned int h_cnt[NSHARD];
     MH_HIP(hipMemcpyAsync(h_cnt, m.count + NSHARD, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     unsigned int t = 0;
     for (int k = 0; k < NSHARD; ++k) t += h_cnt[k];
     *active = t != 0;
@@ -881,7 +881,7 @@ int FillRun::batch(hipStream_t s, bool *active)
     unsigned int h_cnt[MAX_BATCH * NSHARD];
     for (int b = 0; b < BATCH; ++b) MH_TRY(fill_launch_any(*this, m.round + b, INIT_NONE, s));
     MH_HIP(hipMemcpyAsync(h_cnt, m.count + (size_t)(m.round + 1) * NSHARD, sizeof(unsigned int) * BATCH * NSHARD, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     int used = BATCH;
     bool still = true;
     for (int b = 0; b < BATCH; ++b) {
@@ -969,7 +969,7 @@ int FillRun::certify(hipStream_t s, bool *changed)
     MH_HIP(hipGetLastError());
     unsigned int h_cnt[NSHARD];
     MH_HIP(hipMemcpyAsync(h_cnt, cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     unsigned int queued = 0;
     for (int k = 0; k < NSHARD; ++k) queued += h_cnt[k];
     if (!queued) return MHIP_OK;
@@ -987,7 +987,7 @@ int FillRun::finish(hipStream_t s, FillStats *st)
         if (!m.trivial) {
             unsigned long long h_stats[128];
             MH_HIP(hipMemcpyAsync(h_stats, m.d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s));
-            MH_HIP(hipStreamSynchronize(s));
+            MH_HIP(stream_sync(s));
             st->rounds = m.rounds_used;
 #ifdef MH_PROFILE_VISIT
             {

@@ -680,7 +680,7 @@ int check_bad(DevBuf &bad, hipStream_t s, const char *what)
 {
     unsigned int h = 0;
     MH_HIP(hipMemcpyAsync(&h, bad.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     if (h) {
         set_error("%s: label outside [0, nlabels]", what);
         return MHIP_EINVAL;
@@ -804,7 +804,7 @@ int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStrea
     hipLaunchKernelGGL(max_kernel, dim3(grid), dim3(256), 0, s, d_labels, n, m.as<int>());
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(out_max, m.p, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 

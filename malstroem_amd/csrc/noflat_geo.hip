@@ -914,7 +914,7 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
     MH_TRY(launch_rounds(s, 1));
     unsigned long long h_c[4] = {0, 0, 0, 0};
     MH_HIP(hipMemcpyAsync(h_c, m.d_cnt, sizeof(h_c), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));   // (the table upload is complete as well: `tab` may go)
+    MH_HIP(stream_sync(s));   // (the table upload is complete as well: `tab` may go)
     m.used = 1;
     m.irregular = h_c[C_IRREGULAR];
     if (h_c[C_FATAL] || (m.irregular && !allow_partial)) {
@@ -943,7 +943,7 @@ int GeoRun::batch(hipStream_t s, bool *active)
         if (tail_hook) tail_hook->fire(s);      // the throughput-bound rounds are behind this point of the stream
         uint32_t h_any[BATCH];
         MH_HIP(hipMemcpyAsync(h_any, m.d_any + (m.round - nb), sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
+        MH_HIP(stream_sync(s));
         for (int k = 0; k < nb; ++k) {
             if (!h_any[k]) {   // that round found no marked tile: so did the later launches of the batch
                 *active = false;
@@ -983,7 +983,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     MH_HIP(hipGetLastError());
     unsigned long long h_all[C_STATS + 128 + 16];
     MH_HIP(hipMemcpyAsync(h_all, m.d_cnt, sizeof(h_all), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     if (allow_partial && h_all[C_UNREACHED]) partial = true;      // (the verification above then reported those cells: ignored)
     if (st) {
         *st = FillStats();
@@ -1038,7 +1038,7 @@ int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_
     MH_HIP(hipGetLastError());
     unsigned long long bad = 0;
     MH_HIP(hipMemcpyAsync(&bad, cnt.as<unsigned long long>() + C_MISMATCH, 8, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     *ok = bad == 0;
     return MHIP_OK;
 }

@@ -1317,7 +1317,7 @@ int PfRun::solve(hipStream_t s)
         MH_HIP(hipMemcpyAsync(h_cnt.data(), m.any + m.round + 1, sizeof(unsigned int) * PF_BATCH, hipMemcpyDeviceToHost, s));
         MH_HIP(hipMemcpyAsync(&h_flag, m.a.flags, 4, hipMemcpyDeviceToHost, s));
         if (!m.mm_valid) MH_HIP(hipMemcpyAsync(m.h_mm, m.mmout, 8, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
+        MH_HIP(stream_sync(s));
         m.mm_valid = true;
         if (h_flag) return MHIP_ELIMIT;
         if (dev_env("MHIP_PF_DEBUG")) {
@@ -1526,7 +1526,7 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
     {
         unsigned long long h_prof[24];
         MH_HIP(hipMemcpyAsync(h_prof, m.a.prof, sizeof(h_prof), hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
+        MH_HIP(stream_sync(s));
         const char *names[9] = {"load", "descent+plateaus", "doubling", "slots", "pairs", "compact", "label-correcting", "outputs", "spill"};
         double tot = 0;
         for (int i = 0; i < 9; ++i) tot += (double)h_prof[i];
@@ -1549,7 +1549,7 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
     if (st) {
         unsigned long long h_vis = 0;
         MH_HIP(hipMemcpyAsync(&h_vis, m.visits, 8, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
+        MH_HIP(stream_sync(s));
         *st = FillStats();
         st->rounds = m.launches;
         st->visits = (int64_t)h_vis;
@@ -1565,7 +1565,7 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
             st->dem_max = st->dem_nan ? 0.0f : key_f32(m.h_mm[1]);
         }
     } else {
-        MH_HIP(hipStreamSynchronize(s));   // the workspace goes back to the pool now
+        MH_HIP(stream_sync(s));   // the workspace goes back to the pool now
     }
     if (violated) *violated = h_viol != 0;
     m.ws.release();

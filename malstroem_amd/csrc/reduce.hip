@@ -81,7 +81,7 @@ int minmax_dev(const float *d_x, int64_t n, float *mn, float *mx, int *has_nan, 
     MH_HIP(hipGetLastError());
     unsigned int h[4];
     MH_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     *mx = key_f32(h[0]);
     *mn = key_f32(h[1]);
     *has_nan = h[2] != 0;
@@ -111,7 +111,7 @@ int row_update_dev(void *d_dst, const void *d_src, int64_t nbytes, int *changed,
                        nbytes, flag.as<int>());
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(changed, flag.p, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 
@@ -174,7 +174,7 @@ int read_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s)
     MH_HIP(hipEventRecord(e0, s));
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(read16_kernel, dim3(256 * 32), dim3(256), 0, s, a.as<v4f>(), b.as<float>(), n);
     MH_HIP(hipEventRecord(e1, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     float ms = 0;
     MH_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
@@ -197,7 +197,7 @@ int copy_bandwidth_dev(size_t bytes, int reps, double *gbs, hipStream_t s)
     MH_HIP(hipEventRecord(e0, s));
     for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(copy16_kernel, dim3(256 * 32), dim3(256), 0, s, a.as<v4f>(), b.as<v4f>(), n);
     MH_HIP(hipEventRecord(e1, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     float ms = 0;
     MH_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
@@ -218,7 +218,7 @@ int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStr
     MH_HIP(hipGetLastError());
     unsigned int h[4];
     MH_HIP(hipMemcpyAsync(h, acc.p, sizeof(h), hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     short_diag_from_minmax(key_f32(h[1]), key_f32(h[0]), h[2] != 0, sh, dg);
     return MHIP_OK;
 }

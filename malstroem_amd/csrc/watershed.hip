@@ -342,7 +342,7 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     // flow directions of unknown origin: count; the D8 kernel leaves the number next to its result
     if (!d_known_interior_nodir) hipLaunchKernelGGL(ws_count_interior_nodir, dim3(grid), dim3(256), 0, s, d_fd, H, W, d_cnt);
     MH_HIP(hipMemcpyAsync(&interior_nodir, d_known_interior_nodir ? d_known_interior_nodir : d_cnt, 4, hipMemcpyDeviceToHost, s));
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     uint32_t *q = nullptr;
     if (interior_nodir && band_mode) {
         set_error("watersheds on a row band need every flow path to leave the raster (interior NODIR cell found)");
@@ -363,13 +363,13 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
                 hipLaunchKernelGGL(ws_jump_perimeter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, P.as<int32_t>(), H, W, (int)ntc, ntiles, d_changed + j);
             unsigned int h[2] = {0, 0};
             MH_HIP(hipMemcpyAsync(h, d_changed, 8, hipMemcpyDeviceToHost, s));
-            MH_HIP(hipStreamSynchronize(s));
+            MH_HIP(stream_sync(s));
             round += k;
             if (!h[k - 1]) break;
         }
         hipLaunchKernelGGL(ws_assign_hop_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, P.as<int32_t>(), src, d_labels, n);
         MH_HIP(hipGetLastError());
-        MH_HIP(hipStreamSynchronize(s));
+        MH_HIP(stream_sync(s));
         return MHIP_OK;
     }
     if (src != d_labels) MH_HIP(hipMemcpyAsync(d_labels, src, 4 * (size_t)n, hipMemcpyDeviceToDevice, s));
@@ -383,13 +383,13 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
             hipLaunchKernelGGL(ws_jump_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, n, d_changed + j);
         unsigned int h[2] = {0, 0};
         MH_HIP(hipMemcpyAsync(h, d_changed, 8, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
+        MH_HIP(stream_sync(s));
         round += k;
         if (!h[k - 1]) break;
     }
     hipLaunchKernelGGL(ws_assign_kernel, dim3(grid), dim3(256), 0, s, P.as<int32_t>(), q, d_labels, n, unassigned);
     MH_HIP(hipGetLastError());
-    MH_HIP(hipStreamSynchronize(s));
+    MH_HIP(stream_sync(s));
     return MHIP_OK;
 }
 

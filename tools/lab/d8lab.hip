@@ -11,6 +11,7 @@ void set_error(const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(s
 const char *get_error() { return ""; }
 int pool_alloc(void **p, size_t n) { return hipMalloc(p, n) == hipSuccess ? 0 : -1; }
 void pool_free(void *p, size_t) { (void)hipFree(p); }
+hipError_t stream_sync(hipStream_t s) { return hipStreamSynchronize(s); }
 }  // namespace mh
 
 using namespace mh;

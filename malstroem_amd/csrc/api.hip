@@ -1629,11 +1629,15 @@ static int stage_label(mhip_ctx *c, hipStream_t s)
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_LABEL, s, &e1));
     if (!c->have[MHIP_R_DEPTHS]) MH_TRY(stage_depths(c, s));   // stage DAG: the fill left them to this branch
+    // (label_stats of the raw labels rides on the labelling's last pass; MHIP_LABEL_FUSE=0, development: two passes)
+    static const bool fuse = [] { const char *e = dev_env("MHIP_LABEL_FUSE"); return !(e && e[0] == '0'); }();
     MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), H, W,
-                        &c->nlabels_raw, s));
-    MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
-    MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
-                           c->raw_stats.as<mhip_stat_record>(), s, W, true));
+                        &c->nlabels_raw, s, fuse ? &c->raw_stats : nullptr));
+    if (!fuse) {
+        MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
+        MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
+                               c->raw_stats.as<mhip_stat_record>(), s, W, true));
+    }
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_LABEL] = true;
     c->have[MHIP_R_LABELS] = true;

@@ -18,6 +18,7 @@
 //   5. emit   : labels[i] = rank of root(i), 0 for background
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void ccl_emit_kernel(const int32_t *__restrict
 }
 
 template <typename T>
-int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s)
+int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s, DevBuf *stats_out = nullptr)
 {
     const int64_t n = H * W;
     if (n >= (int64_t)INT32_MAX - 1) {
@@ -454,9 +455,21 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
         hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bcounts.as<uint32_t>(), nwb, total.as<unsigned long long>());
         hipLaunchKernelGGL(ccl_bits_prefix_kernel, dim3((unsigned)nwb), dim3(WB), 0, s, bits.as<unsigned long long>(), nwords, bcounts.as<uint32_t>(),
                            wprefix.as<uint32_t>());
+        unsigned long long h_total = 0;
+        if constexpr (std::is_same<T, float>::value) {
+            if (stats_out) {
+                // the statistics ride on the emit pass (label_ops.hip: EmitArgs); their buffers want the number of labels first
+                MH_HIP(hipGetLastError());
+                MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
+                MH_HIP(stream_sync(s));
+                *nlabels = (int64_t)h_total;
+                MH_TRY(stats_out->alloc(sizeof(mhip_stat_record) * (size_t)(h_total + 1)));
+                return label_emit_stats_dev(parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_data, d_labels, H, W, (int64_t)h_total,
+                                            stats_out->as<mhip_stat_record>(), s);     // (synchronises: the scratch buffers may go)
+            }
+        }
         hipLaunchKernelGGL(ccl_emit_ranked_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, n);
         MH_HIP(hipGetLastError());
-        unsigned long long h_total = 0;
         MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
         MH_HIP(stream_sync(s));     // (the scratch buffers of this branch go back to the pool after the sync)
         *nlabels = (int64_t)h_total;
@@ -467,15 +480,21 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
     MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
     MH_HIP(stream_sync(s));
     *nlabels = (int64_t)h_total;
+    if constexpr (std::is_same<T, float>::value) {
+        if (stats_out) {
+            MH_TRY(stats_out->alloc(sizeof(mhip_stat_record) * (size_t)(h_total + 1)));
+            MH_TRY(label_stats_dev(d_data, d_labels, n, (int64_t)h_total, stats_out->as<mhip_stat_record>(), s, W, true));
+        }
+    }
     return MHIP_OK;
 }
 
 }  // namespace
 
 int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
-                 hipStream_t s)
+                 hipStream_t s, DevBuf *stats_out)
 {
-    return ccl8_dev<float>(d_data, d_labels, d_tmp, H, W, nlabels, s);
+    return ccl8_dev<float>(d_data, d_labels, d_tmp, H, W, nlabels, s, stats_out);
 }
 int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
                 hipStream_t s)

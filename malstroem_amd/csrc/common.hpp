@@ -253,8 +253,11 @@ int comm_allreduce_max(void *comm, double *d_value, hipStream_t s);
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0, int halo_zero = 0,
               int32_t *d_exit_map = nullptr);
 // ccl.hip   (d_tmp: H*W int32 scratch)
+// stats_out: the labelling's last pass also reduces label_stats(d_data, labels) into *stats_out (allocated here: nlabels + 1 records)
 int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
-                 hipStream_t s);
+                 hipStream_t s, DevBuf *stats_out = nullptr);
+int label_emit_stats_dev(const int32_t *d_parent, const unsigned long long *d_rootbits, const uint32_t *d_wordprefix, const float *d_data,
+                         int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s);
 int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
                 hipStream_t s);
 // label_ops.hip

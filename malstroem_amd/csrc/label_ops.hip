@@ -121,9 +121,18 @@ template <int TS> __device__ __forceinline__ int table_slot(int *keys, int key)
 // none of whose cells in the tile lies on the tile's outline (or on the raster's last row) then lives in this tile alone and
 // its record is WRITTEN instead of merged by a load and up to four atomics.
 constexpr int STATS_TS = 1024;
-template <bool COMPONENTS>
+// EMIT: the labels do not exist yet -- the kernel is the last pass of the connected-component labelling (ccl.hip) as well: it
+// turns parent[] (cell -> root of its tile piece -> root of its component) into ranks, WRITES the label raster and reduces on
+// the way, which saves the labelling's own emit pass the statistics would read back (4 + 4 B per cell and a launch).
+struct EmitArgs {
+    const int32_t *parent;                  // [n] tile-local root of every cell (-1: background); parent[root] = component root
+    const unsigned long long *rootbits;     // one bit per cell: component roots
+    const uint32_t *wordprefix;             // root bits before each 64-bit word
+    int32_t *labels;                        // out
+};
+template <bool COMPONENTS, bool EMIT>
 __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
-                                                   TileGeom g, int64_t nlab, StatAcc a, unsigned int *bad)
+                                                   TileGeom g, int64_t nlab, StatAcc a, unsigned int *bad, EmitArgs em)
 {
     __shared__ int keys[STATS_TS];
     __shared__ unsigned int tcnt[STATS_TS], tmin[STATS_TS], tmax[STATS_TS];
@@ -180,11 +189,26 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
             for (int u = 0; u < 4; ++u) {
                 const int64_t i = (tr * TR + r4 + u) * g.W + col;
                 const bool valid = col < g.W && i < g.n;
-                lq[u] = valid ? lab[i] : -1;
+                lq[u] = valid ? (EMIT ? em.parent[i] : lab[i]) : -1;
                 dq[u] = valid ? data[i] : 0.0f;
-                if (valid && (lq[u] < 0 || lq[u] > nlab)) {
+                if (!EMIT && valid && (lq[u] < 0 || lq[u] > nlab)) {
                     atomicOr(bad, 1u);
                     lq[u] = -1;
+                }
+            }
+            if (EMIT) {
+                // rank of the component root = the label (the four rows' look-ups are independent: in flight together)
+                int32_t gq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gq[u] = lq[u] >= 0 ? em.parent[lq[u]] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t i = (tr * TR + r4 + u) * g.W + col;
+                    const bool valid = col < g.W && i < g.n;
+                    const int32_t gg = gq[u];
+                    const int32_t l = gg >= 0 ? (int32_t)(em.wordprefix[gg >> 6] + (uint32_t)__popcll(em.rootbits[gg >> 6] & ((1ull << (gg & 63)) - 1ull))) + 1 : 0;
+                    if (valid) em.labels[i] = l;
+                    lq[u] = valid ? l : -1;
                 }
             }
 #pragma unroll
@@ -714,12 +738,34 @@ int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int
     // (the shortcut for components needs the raster's real geometry: tile_geom treats a flat array as 256 columns wide)
     // (the shortcut for components needs the raster's real geometry: tile_geom treats a flat array as 256 columns wide)
     if (components && W > 0 && n % W == 0)
-        hipLaunchKernelGGL(stats_kernel<true>, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
+        hipLaunchKernelGGL((stats_kernel<true, false>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>(), EmitArgs{});
     else
-        hipLaunchKernelGGL(stats_kernel<false>, dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>());
+        hipLaunchKernelGGL((stats_kernel<false, false>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>(), EmitArgs{});
     hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "label_stats");
+}
+
+// the last pass of ccl8_dev fused with label_stats (see EmitArgs): labels written, records of the labels in d_rec
+int label_emit_stats_dev(const int32_t *d_parent, const unsigned long long *d_rootbits, const uint32_t *d_wordprefix, const float *d_data,
+                         int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s)
+{
+    const int64_t nrec = nlab + 1, n = H * W;
+    DevBuf mn, mx, sm, ct;
+    MH_TRY(mn.alloc(4 * (size_t)nrec));
+    MH_TRY(mx.alloc(4 * (size_t)nrec));
+    MH_TRY(sm.alloc(8 * (size_t)nrec));
+    MH_TRY(ct.alloc(8 * (size_t)nrec));
+    StatAcc a{mn.as<uint32_t>(), mx.as<uint32_t>(), sm.as<double>(), ct.as<unsigned long long>()};
+    hipLaunchKernelGGL(stats_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
+    TileGeom g;
+    g.n = n; g.W = W; g.ntr = cdiv(H, TR); g.ntc = cdiv(W, 256);
+    hipLaunchKernelGGL((stats_kernel<true, true>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, (const int32_t *)nullptr, g, nlab, a, (unsigned int *)nullptr,
+                       EmitArgs{d_parent, d_rootbits, d_wordprefix, d_labels});
+    hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
+    MH_HIP(hipGetLastError());
+    MH_HIP(stream_sync(s));      // the accumulators go back to the pool
+    return MHIP_OK;
 }
 
 int label_stats64_dev(const double *d_data, const int32_t *d_labels, int64_t n, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s)

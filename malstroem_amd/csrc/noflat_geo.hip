@@ -821,6 +821,13 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
     const unsigned grid = (unsigned)std::min<int64_t>((m.nt + 3) / 4, 512);
     for (int k = 0; k < nb; ++k, ++m.round) {
         a.maxcyc = m.maxcyc;
+        {   // development knob: MHIP_NG_HEAD="rounds,cycles": the first `rounds` rounds run up to `cycles` local cycles per visit
+            static const char *eh = dev_env("MHIP_NG_HEAD");
+            if (eh) {
+                int hr = 0, hc = 1;
+                if (sscanf(eh, "%d,%d", &hr, &hc) == 2 && m.round <= hr) a.maxcyc = hc;
+            }
+        }
         a.count = m.d_any + m.round;     // tiles of this round (round 0: every tile)
         if (!m.round) {
             hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), m.lds, s, a);

@@ -274,7 +274,10 @@ int mhip_ctx_zero_raster(mhip_ctx *ctx, int which);
  * cells k with exit_map[k] = e  -- a forest over all bands' edge cells that the launcher solves on the host; it writes the
  * solved values into the ACCUM halo rows and runs mhip_ctx_run(ACCUM) once (reference: the same sums as _flow.pyx:212-247). */
 int mhip_ctx_band_accum_boundary(mhip_ctx *ctx, int32_t *exit_map /* 2 * W, host */);
-/* labelling on a band: local components -> host merges the boundary equivalences of all bands -> global LUT */
+/* labelling on a band: local components -> host merges the boundary equivalences of all bands -> global LUT.
+ * The relabel calls below may only JOIN components that are connected across bands (or drop components): the record passes take a
+ * label without a cell on a tile outline for a component that lies inside that tile and write its record without atomics.  (Labels
+ * that were uploaded with mhip_ctx_upload / _upload_rows carry no such promise and take the general path.) */
 int mhip_ctx_band_ccl_local(mhip_ctx *ctx, int64_t *nlocal);
 int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int64_t nlabels_global);
 /* the same without a dense table: local label l -> offset + l - #(dropped labels < l); dropped[k] (sorted: the local labels

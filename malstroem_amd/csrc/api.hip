@@ -1565,7 +1565,10 @@ static int stage_fill(mhip_ctx *c, hipStream_t s, bool with_depths = true)
 }
 
 // shdg_done: minimum_safe_short_and_diag of the current DEM is already in c->sh / c->dg (computed next to the fill)
-static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false, StageHook *tail_hook = nullptr)
+// with_flowdir: FLOWDIR is part of the same request -- the geodesic transform's finishing pass writes the directions as well when
+// it can (one context, regular surface); *flowdir_done then tells the caller that stage_flowdir has nothing left to do
+static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false, StageHook *tail_hook = nullptr, bool with_flowdir = false,
+                        bool *flowdir_done = nullptr)
 {
     const int64_t H = c->H, W = c->W, n = H * W;
     MH_ARG(c->have[MHIP_R_DEM], "NOFLAT needs the DEM");
@@ -1580,8 +1583,18 @@ static int stage_noflat(mhip_ctx *c, hipStream_t s, bool shdg_done = false, Stag
         MH_TRY(fill_plain_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_FILLED].as<float>(), H, W, s, &st0));
         c->have[MHIP_R_FILLED] = true;
     }
+    D8Sink d8;
+    static const bool fuse_d8 = [] { const char *e = dev_env("MHIP_D8_FUSE"); return !(e && e[0] == '0'); }();   // (development: 0 = D8 as a pass of its own)
+    if (with_flowdir && fuse_d8 && !c->ht && !c->hb) {
+        MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
+        MH_TRY(c->nodir_cnt.alloc(4));
+        MH_HIP(hipMemsetAsync(c->nodir_cnt.p, 0, 4, s));
+        d8.flowdir = c->r[MHIP_R_FLOWDIR].as<uint8_t>();
+        d8.nodir = c->nodir_cnt.as<unsigned int>();
+    }
     MH_TRY(fill_noflat_dev(c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_NOFLAT].as<double>(), H, W, c->sh, c->dg, s, &st,
-                           c->r[MHIP_R_FILLED].as<float>(), tail_hook));
+                           c->r[MHIP_R_FILLED].as<float>(), tail_hook, d8.flowdir ? &d8 : nullptr));
+    if (flowdir_done) *flowdir_done = d8.done;
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_NOFLAT] = true;
     c->noflat_rounds = st.rounds;
@@ -1604,6 +1617,18 @@ static int stage_flowdir(mhip_ctx *c, hipStream_t s)
     c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
     c->have[MHIP_R_FLOWDIR] = true;
     c->nodir_valid = !c->ht && !c->hb;     // (a band's halo rows are computed from clamped data: their codes do not count)
+    return MHIP_OK;
+}
+
+// the no-flats fill's finishing pass wrote the flow directions (stage_noflat: with_flowdir): the stage is an empty interval
+static int stage_flowdir_fused(mhip_ctx *c, hipStream_t s)
+{
+    hipEvent_t *e1;
+    MH_TRY(stage_begin(c, MHIP_STAGE_FLOWDIR, s, &e1));
+    MH_HIP(hipEventRecord(*e1, s));
+    c->ev_valid[MHIP_STAGE_FLOWDIR] = true;
+    c->have[MHIP_R_FLOWDIR] = true;
+    c->nodir_valid = true;
     return MHIP_OK;
 }
 
@@ -1713,8 +1738,9 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
 
     if (!overlap) {
         if (mask & MHIP_STAGE_FILL) MH_TRY(stage_fill(c, s));
-        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s));
-        if (mask & MHIP_STAGE_FLOWDIR) MH_TRY(stage_flowdir(c, s));
+        bool fd_done = false;
+        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, false, nullptr, (mask & MHIP_STAGE_FLOWDIR) != 0, &fd_done));
+        if (mask & MHIP_STAGE_FLOWDIR) MH_TRY(fd_done ? stage_flowdir_fused(c, s) : stage_flowdir(c, s));
         if (mask & MHIP_STAGE_ACCUM) MH_TRY(stage_accum(c, s));
         if (mask & MHIP_STAGE_LABEL) MH_TRY(stage_label(c, s));
         if (mask & MHIP_STAGE_WATERSHED) MH_TRY(stage_watershed(c, s));
@@ -1841,9 +1867,11 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         }
         static const int label_start = [] { const char *e = dev_env("MHIP_LABEL_START"); return e ? atoi(e) : 2; }();   // 0: with the no-flats fill, 1: at its tail, 2: after it
         if (label_start == 0) tail_hook.fire(s);
-        if (mask & MHIP_STAGE_NOFLAT) MH_TRY(stage_noflat(c, s, /*shdg_done=*/true, label_start == 1 ? &tail_hook : nullptr));
+        bool fd_done = false;
+        if (mask & MHIP_STAGE_NOFLAT)
+            MH_TRY(stage_noflat(c, s, /*shdg_done=*/true, label_start == 1 ? &tail_hook : nullptr, (mask & MHIP_STAGE_FLOWDIR) != 0, &fd_done));
         if (mask & MHIP_STAGE_FLOWDIR) {
-            MH_TRY(stage_flowdir(c, s));
+            MH_TRY(fd_done ? stage_flowdir_fused(c, s) : stage_flowdir(c, s));
             MH_HIP(hipEventRecord(c->ev_flowdir, s));
         }
         return MHIP_OK;

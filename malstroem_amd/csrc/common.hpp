@@ -80,6 +80,46 @@ struct DevBuf {
 __host__ __device__ inline int dir_dr(int k) { return (k == 0 || k == 1 || k == 7) ? -1 : (k >= 3 && k <= 5) ? 1 : 0; }
 __host__ __device__ inline int dir_dc(int k) { return (k >= 1 && k <= 3) ? 1 : (k >= 5 && k <= 7) ? -1 : 0; }
 
+// ---- D8 of one cell (d8.hip; noflat_geo.hip: ng_finish_kernel) ------------------------------------------------------------
+__device__ __forceinline__ unsigned d8_code(double z, double u, double ur, double r, double dr, double d, double dl,
+                                            double l, double ul)
+{
+    const double INV_SQRT2 = 0.7071067811865475;  // 1 / 2**0.5, _flow.pyx:93-94
+    // `if dz > dzmax: dzmax = dz; i = k` in the reference's order.  The running maximum is a v_max_f64 (same value as the
+    // conditional move: it only changes when dz > dzmax; NaN drops are ignored by both), the index a 32-bit select.
+    unsigned i = 8;
+    double dzmax = 0.0, dz;
+#define MH_D8_STEP(expr, k)          \
+    dz = (expr);                     \
+    i = dz > dzmax ? (k) : i;        \
+    dzmax = fmax(dzmax, dz);
+    MH_D8_STEP(__dsub_rn(z, u), 0u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, ur), INV_SQRT2), 1u)
+    MH_D8_STEP(__dsub_rn(z, r), 2u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, dr), INV_SQRT2), 3u)
+    MH_D8_STEP(__dsub_rn(z, d), 4u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, dl), INV_SQRT2), 5u)
+    MH_D8_STEP(__dsub_rn(z, l), 6u)
+    MH_D8_STEP(__dmul_rn(__dsub_rn(z, ul), INV_SQRT2), 7u)
+#undef MH_D8_STEP
+    return i;
+}
+
+// flow.py:130-139: rows first, then columns overwrite, corners last (same order => same result on 1-wide rasters)
+__device__ __forceinline__ unsigned edge_code(int64_t r, int64_t c, int64_t maxr, int64_t maxc)
+{
+    unsigned code = 8;
+    if (r == 0) code = 0;
+    if (r == maxr) code = 4;
+    if (c == 0) code = 6;
+    if (c == maxc) code = 2;
+    if (r == 0 && c == 0) code = 7;
+    if (r == 0 && c == maxc) code = 1;
+    if (r == maxr && c == 0) code = 5;
+    if (r == maxr && c == maxc) code = 3;
+    return code;
+}
+
 // monotone float/double <-> unsigned keys (for atomicMin/Max); NaN must be filtered by the caller
 __host__ __device__ inline uint32_t f32_key(float f)
 {
@@ -207,6 +247,9 @@ struct GeoRun {
     double seed_add = 0;                              // ... with the upper bound F + seed_add in `out`
     bool partial = false;                             // set by end(): `out` still needs the float64 relaxation on those flats
     StageHook *tail_hook = nullptr;                   // fired when the first batch of rounds has been launched
+    uint8_t *d8_out = nullptr;                        // optional: end() also writes the flow directions of the surface (one context, no halo rows)
+    unsigned int *d8_nodir = nullptr;                 // ... and sets this word when an interior cell has none
+    bool d8_done = false;                             // set by end(): d8_out holds the directions of the verified surface
     struct Impl;
     Impl *impl;
     GeoRun();
@@ -220,12 +263,19 @@ struct GeoRun {
     int launch_rounds(hipStream_t s, int nb);
 };
 // noflat_geo.hip: MHIP_ELIMIT = not applicable, run the float64 relaxation
+// D8Sink: the caller wants the flow directions of the surface too; when the geodesic transform's finishing pass could write them
+// (`done`) the D8 pass over the surface is not needed
+struct D8Sink {
+    uint8_t *flowdir = nullptr;
+    unsigned int *nodir = nullptr;     // zeroed by the caller; set when an interior cell has no downslope neighbour
+    bool done = false;
+};
 int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
-                             hipStream_t s, FillStats *st, bool *partial, StageHook *tail_hook = nullptr);
+                             hipStream_t s, FillStats *st, bool *partial, StageHook *tail_hook = nullptr, D8Sink *d8 = nullptr);
 int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s, bool *ok, int fixed_top = 0,
                       int fixed_bot = 0);
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                    FillStats *st = nullptr, const float *d_filled = nullptr, StageHook *tail_hook = nullptr);
+                    FillStats *st = nullptr, const float *d_filled = nullptr, StageHook *tail_hook = nullptr, D8Sink *d8 = nullptr);
 int short_diag_dev(const float *d_dem, int64_t n, double *sh, double *dg, hipStream_t s);
 int depths_dev(const float *d_filled, const float *d_dem, float *d_out, int64_t n, hipStream_t s);
 // d8.hip

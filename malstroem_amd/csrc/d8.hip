@@ -71,44 +71,7 @@ __device__ __forceinline__ void load_row(const double *__restrict__ z, int64_t r
     }
 }
 
-__device__ __forceinline__ unsigned d8_code(double z, double u, double ur, double r, double dr, double d, double dl,
-                                            double l, double ul)
-{
-    const double INV_SQRT2 = 0.7071067811865475;  // 1 / 2**0.5, _flow.pyx:93-94
-    // `if dz > dzmax: dzmax = dz; i = k` in the reference's order.  The running maximum is a v_max_f64 (same value as the
-    // conditional move: it only changes when dz > dzmax; NaN drops are ignored by both), the index a 32-bit select.
-    unsigned i = 8;
-    double dzmax = 0.0, dz;
-#define MH_D8_STEP(expr, k)          \
-    dz = (expr);                     \
-    i = dz > dzmax ? (k) : i;        \
-    dzmax = fmax(dzmax, dz);
-    MH_D8_STEP(__dsub_rn(z, u), 0u)
-    MH_D8_STEP(__dmul_rn(__dsub_rn(z, ur), INV_SQRT2), 1u)
-    MH_D8_STEP(__dsub_rn(z, r), 2u)
-    MH_D8_STEP(__dmul_rn(__dsub_rn(z, dr), INV_SQRT2), 3u)
-    MH_D8_STEP(__dsub_rn(z, d), 4u)
-    MH_D8_STEP(__dmul_rn(__dsub_rn(z, dl), INV_SQRT2), 5u)
-    MH_D8_STEP(__dsub_rn(z, l), 6u)
-    MH_D8_STEP(__dmul_rn(__dsub_rn(z, ul), INV_SQRT2), 7u)
-#undef MH_D8_STEP
-    return i;
-}
-
-// flow.py:130-139: rows first, then columns overwrite, corners last (same order => same result on 1-wide rasters)
-__device__ __forceinline__ unsigned edge_code(int64_t r, int64_t c, int64_t maxr, int64_t maxc)
-{
-    unsigned code = 8;
-    if (r == 0) code = 0;
-    if (r == maxr) code = 4;
-    if (c == 0) code = 6;
-    if (c == maxc) code = 2;
-    if (r == 0 && c == 0) code = 7;
-    if (r == 0 && c == maxc) code = 1;
-    if (r == maxr && c == 0) code = 5;
-    if (r == maxr && c == maxc) code = 3;
-    return code;
-}
+// (d8_code / edge_code: common.hpp -- the no-flats fill's finishing pass computes the codes from the same registers)
 
 // row_off / Hg: row band of a larger raster (local row r is global row r + row_off of Hg rows); only global border
 // rows get the border codes, the band's halo rows are computed from clamped data and overwritten by the host.

@@ -1091,8 +1091,9 @@ void noflat_seed(FillRun &f, const float *d_filled, double sh, double dg, int64_
 }
 
 int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, double sh, double dg, hipStream_t s,
-                    FillStats *st, const float *d_filled, StageHook *tail_hook)
+                    FillStats *st, const float *d_filled, StageHook *tail_hook, D8Sink *d8)
 {
+    if (d8) d8->done = false;
     struct FireAtExit {     // whatever path is taken, the hook fires (at the latest when the stage is done)
         StageHook *h;
         hipStream_t s;
@@ -1101,7 +1102,7 @@ int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, dou
     // the integer geodesic transform of noflat_geo.hip first; it hands back MHIP_ELIMIT for what it does not cover
     bool partial = false;
     const double seed_add = 1.01 * (double)(H * W) * dg;      // see noflat_seed()
-    const int rc = fill_noflat_geodesic_dev(d_dem, d_filled, d_out, H, W, sh, dg, seed_add, s, st, &partial, tail_hook);
+    const int rc = fill_noflat_geodesic_dev(d_dem, d_filled, d_out, H, W, sh, dg, seed_add, s, st, &partial, tail_hook, d8);
     if (tail_hook) tail_hook->fire(s);      // (not applicable: the relaxation below is throughput bound all the way)
     if (rc != MHIP_ELIMIT && !(rc == MHIP_OK && partial)) return rc;
     if (rc == MHIP_OK) {

@@ -694,9 +694,12 @@ __device__ __forceinline__ double dright(double v)
     const uint32_t lo = from_right((uint32_t)b), hi = from_right((uint32_t)(b >> 32));
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
+// D8: the cell's flow direction as well (flow.terrain_flowdirection with the edges flowing outward, d8.hip) -- the 3 x 3
+// neighbourhood of G is in registers here already; as a pass of its own D8 reads all of G back (8 of its 9 bytes per cell).
+template <bool D8>
 __global__ __launch_bounds__(256) void ng_finish_kernel(const float *__restrict__ F, const uint32_t *__restrict__ d, const float *__restrict__ dem,
                                                         double *__restrict__ G, int64_t H, int64_t W, double sh, double dg, double seed_add, int fixed_top,
-                                                        int fixed_bot, unsigned long long *counters)
+                                                        int fixed_bot, unsigned long long *counters, uint8_t *__restrict__ flowdir, unsigned int *nodir)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t c = ((int64_t)blockIdx.x * 4 + wave) * TI + lane - 1;
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(256) void ng_finish_kernel(const float *__restrict_
     const bool mine = lane >= 1 && lane <= TI && col_in;                // this lane writes (and checks) its column
     const bool inner_col = c > 0 && c + 1 < W;
     const double PINF = __builtin_inf();
-    unsigned unreached = 0, bad = 0;
+    unsigned unreached = 0, bad = 0, anynodir = 0;
     auto value = [&](int64_t r) -> double {
         if (!(r >= 0 && r < H && col_in)) return PINF;
         const float f = F[r * W + cc];
@@ -735,12 +738,22 @@ __global__ __launch_bounds__(256) void ng_finish_kernel(const float *__restrict_
             const bool halo = (r == 0 && fixed_top) || (r == H - 1 && fixed_bot);   // the neighbouring band checks its own rows
             bad += (b == want || halo) ? 0u : 1u;                                    // NaN anywhere fails too
             G[r * W + c] = b;
+            if (D8) {
+                unsigned code;
+                if (r == 0 || r == H - 1 || c == 0 || c == W - 1) code = edge_code(r, c, H - 1, W - 1);
+                else {
+                    code = d8_code(b, a, ar, br, nr, n, nl, bl, al);
+                    anynodir |= code == 8u ? 1u : 0u;      // an interior cell without a downslope neighbour (d8.hip: the watersheds' fast-path test)
+                }
+                flowdir[r * W + c] = (uint8_t)code;
+            }
         }
         a = b;
         b = n;
     }
     if (unreached) atomicAdd(&counters[C_UNREACHED], (unsigned long long)unreached);
     if (bad) atomicAdd(&counters[C_MISMATCH], (unsigned long long)bad);
+    if (D8 && __any(anynodir != 0u) && lane == 0) *nodir = 1u;      // ("none" / "some": a plain store of the same value)
 }
 
 // rn(eps / 2**(E - 52)) for the binade class e (E = e - 127) with eps = M * 2**q exactly; 0: no integer weight in (0, 2**28)
@@ -982,9 +995,14 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     partial = m.irregular != 0 && allow_partial;
     if (dev_env("MHIP_NG_CORRUPT") && W > 8)   // test hook (tests/test_gpu_noflat_geodesic.py): wrong distances in the middle row -- the check
         MH_HIP(hipMemsetAsync(dist + (H / 2) * W + 1, 0x01, 4 * (size_t)(W - 2), s));   // below has to catch them and send the raster to the relaxation
-    if (!partial)
-        hipLaunchKernelGGL(ng_finish_kernel, dim3((unsigned)((W + 4 * TI - 1) / (4 * TI)), (unsigned)((H + FRB - 1) / FRB)), dim3(256), 0, s, filled, dist, dem,
-                           out, H, W, sh, dg, seed_add, fixed_top, fixed_bot, m.d_cnt);
+    d8_done = false;
+    const bool with_d8 = !partial && d8_out && d8_nodir && !fixed_top && !fixed_bot;
+    if (with_d8)
+        hipLaunchKernelGGL(ng_finish_kernel<true>, dim3((unsigned)((W + 4 * TI - 1) / (4 * TI)), (unsigned)((H + FRB - 1) / FRB)), dim3(256), 0, s, filled, dist, dem,
+                           out, H, W, sh, dg, seed_add, fixed_top, fixed_bot, m.d_cnt, d8_out, d8_nodir);
+    else if (!partial)
+        hipLaunchKernelGGL(ng_finish_kernel<false>, dim3((unsigned)((W + 4 * TI - 1) / (4 * TI)), (unsigned)((H + FRB - 1) / FRB)), dim3(256), 0, s, filled, dist, dem,
+                           out, H, W, sh, dg, seed_add, fixed_top, fixed_bot, m.d_cnt, (uint8_t *)nullptr, (unsigned int *)nullptr);
     else              // (a partial surface is checked by the caller once the relaxation has settled the irregular flats)
         hipLaunchKernelGGL(ng_assemble_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, filled, dist, out, n, seed_add, m.d_cnt);
     MH_HIP(hipGetLastError());
@@ -1029,6 +1047,7 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
                 h_all[C_MISMATCH]);
     }
     *ok = partial ? true : !(h_all[C_UNREACHED] || h_all[C_MISMATCH]);
+    d8_done = with_d8 && !partial && *ok;        // (a surface that still goes through the relaxation gets its directions from d8.hip)
     m.ws.release();
     return MHIP_OK;
 }
@@ -1054,10 +1073,11 @@ int noflat_verify_dev(const float *d_dem, const double *d_out, int64_t H, int64_
 // which hold an upper bound (F + seed_add): the caller relaxes those in float64 and verifies.  MHIP_ELIMIT: not applicable to
 // this raster (NaN cells, epsilons without weights, a cell the verification rejects): the caller runs the float64 relaxation.
 int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *d_out, int64_t H, int64_t W, double sh, double dg, double seed_add,
-                             hipStream_t s, FillStats *st, bool *partial, StageHook *tail_hook)
+                             hipStream_t s, FillStats *st, bool *partial, StageHook *tail_hook, D8Sink *d8)
 {
     GeoRun g;
     g.tail_hook = tail_hook;
+    if (d8) { g.d8_out = d8->flowdir; g.d8_nodir = d8->nodir; d8->done = false; }
     g.dem = d_dem; g.filled = d_filled; g.out = d_out; g.H = H; g.W = W; g.sh = sh; g.dg = dg;
     g.allow_partial = partial != nullptr && seed_add == seed_add && seed_add < 1e300;
     g.seed_add = seed_add;
@@ -1067,6 +1087,7 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
     while (active) MH_TRY(g.batch(s, &active));
     MH_TRY(g.end(s, &ok, st));
     if (partial) *partial = g.partial;
+    if (d8) d8->done = g.d8_done;
     return ok ? MHIP_OK : MHIP_ELIMIT;
 }
 

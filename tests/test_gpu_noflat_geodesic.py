@@ -143,3 +143,37 @@ def test_size_independent_properties_at_8192():
     lowest = np.minimum(np.minimum(np.minimum(G[:-2, :-2], G[:-2, 2:]), np.minimum(G[2:, :-2], G[2:, 2:])),
                         np.minimum(np.minimum(G[:-2, 1:-1], G[2:, 1:-1]), np.minimum(G[1:-1, :-2], G[1:-1, 2:])))
     assert np.all(lowest < c)
+
+
+def _flowdir_of_request(dem):
+    from malstroem_amd.pipeline import HydroPipeline
+    with HydroPipeline(dem.shape) as pipe:
+        pipe.upload("dem", dem)
+        pipe.run("fill", "noflat", "flowdir")           # one request: the no-flats fill's finishing pass may write the directions
+        pipe.sync()
+        fused = pipe.download("flowdir")
+        alg = pipe.get_int("noflat_algorithm")
+        pipe.run("flowdir")                              # a request of its own: d8.hip on the resident surface
+        pipe.sync()
+        return fused, pipe.download("flowdir"), alg
+
+
+def test_flow_directions_whichever_pass_writes_them(monkeypatch):
+    """In one request with the no-flats fill the flow directions come out of the geodesic transform's finishing pass
+    (ng_finish_kernel: d8_code on the 3 x 3 neighbourhood it holds anyway); a partial surface (a sea at 0), a surface the final
+    check rejects, and a FLOWDIR request of its own go through d8.hip.  Same bits as the oracle every time."""
+    regular = np.ascontiguousarray(fbm(700, 450, beta=2.5, seed=21) + np.float32(3.0))
+    regular[300:340, 100:300] = regular[300, 100]                                   # a flat over several tiles
+    sea = np.ascontiguousarray(fbm(600, 520, beta=2.0, seed=22) - np.float32(30.0))
+    sea[sea < 0] = 0.0
+    for dem, want_alg in ((regular, 2), (sea, 3)):
+        s, d = oracle.minimum_safe_short_and_diag(dem)
+        want = oracle.terrain_flowdirection(oracle.fill_terrain_no_flats(dem, s, d))
+        fused, alone, alg = _flowdir_of_request(dem)
+        assert alg == want_alg
+        assert np.array_equal(fused, want) and np.array_equal(alone, want)
+    monkeypatch.setenv("MHIP_NG_CORRUPT", "1")           # the finishing pass sees wrong distances: its directions must not be used
+    s, d = oracle.minimum_safe_short_and_diag(regular)
+    want = oracle.terrain_flowdirection(oracle.fill_terrain_no_flats(regular, s, d))
+    fused, alone, alg = _flowdir_of_request(regular)
+    assert alg == 0 and np.array_equal(fused, want) and np.array_equal(alone, want)

@@ -230,6 +230,83 @@ __device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], con
     }
 }
 
+// ---- a window of ONE class (nearly every tile): the passes need no class bytes, and the two layouts' inverted adjacency bytes
+// of TWO register rows share a word:  pk[k] = A(2k) | B(2k) << 8 | A(2k + 1) << 16 | B(2k + 1) << 24  (A: the row layout's byte
+// of register row r, B: the transposed layout's).  Half the block (8 instead of 16 KB per visit), 32 instead of 64 registers, 32
+// instead of 64 loads, and no rotation of the words after a transpose: a pass picks its bits by a compile-time offset.
+template <bool DOWN, int PH>
+__device__ __forceinline__ void pass_pk(uint32_t (&d)[WN], uint32_t (&pk)[WN / 2], const uint32_t S, const uint32_t G, uint32_t &acc_all, uint32_t &acc_first,
+                                        uint32_t &acc_last)
+{
+    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
+    constexpr int bC = DOWN ? 0 : 4, bL = DOWN ? 7 : 5, bR = DOWN ? 1 : 3;
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]));
+#pragma unroll
+    for (int r = 0; r < WN / 2; ++r) asm volatile("" : "+v"(pk[r]));
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int r = first + dir * i;
+        const int base = 16 * (r & 1) + 8 * PH;
+        const uint32_t behind = d[r - dir];
+        const uint32_t bl = from_left(behind), br = from_right(behind);
+        const uint32_t w = pk[r >> 1];
+        const uint32_t c0 = (behind + S) | (uint32_t)__builtin_amdgcn_sbfe((int)w, base + bC, 1);
+        const uint32_t c1 = (bl + G) | (uint32_t)__builtin_amdgcn_sbfe((int)w, base + bL, 1);
+        const uint32_t c2 = (br + G) | (uint32_t)__builtin_amdgcn_sbfe((int)w, base + bR, 1);
+        const uint32_t cu = d[r];
+        const uint32_t nv = min(min(c0, c1), min(c2, cu));
+        const uint32_t x = nv ^ cu;
+        acc_all |= x;
+        asm volatile("" : "+v"(acc_all));
+        if (r == 1) acc_first |= (w & (0x83u << base)) != (0x83u << base) ? x : 0u;
+        if (r == TI) acc_last |= (w & (0x38u << base)) != (0x38u << base) ? x : 0u;
+        d[r] = nv;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void relax_pk(uint32_t (&d)[WN], uint32_t (&pk)[WN / 2], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc,
+                                         unsigned &wake, bool &changed, bool &capped, unsigned &cycles)
+{
+    const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
+    capped = true;
+#pragma nounroll
+    for (int cyc = 0; cyc < maxcyc; ++cyc) {
+        uint64_t chg = 0;
+        ++cycles;
+        {   // lane = column, first / last = row 1 / 62
+            uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
+            pass_pk<true, 0>(d, pk, S, G, acc_all, acc_first, acc_last);
+            pass_pk<false, 0>(d, pk, S, G, acc_all, acc_first, acc_last);
+            const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
+            chg |= all;
+            const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
+            const unsigned l1 = (all & B1) ? 1u : 0u, l62 = (all & B62) ? 1u : 0u;
+            const unsigned f1 = (fst & B1) ? 1u : 0u, f62 = (fst & B62) ? 1u : 0u, g1 = (lst & B1) ? 1u : 0u, g62 = (lst & B62) ? 1u : 0u;
+            wake |= (e_first << 1) | (e_last << 7) | (l1 << 3) | (l62 << 5) | (f1 << 0) | (f62 << 2) | (g1 << 6) | (g62 << 8);
+            transpose32(d, scr_b, lane);
+        }
+        {   // lane = row, first / last = column 1 / 62
+            uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
+            pass_pk<true, 1>(d, pk, S, G, acc_all, acc_first, acc_last);
+            pass_pk<false, 1>(d, pk, S, G, acc_all, acc_first, acc_last);
+            const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
+            chg |= all;
+            const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
+            const unsigned l1 = (all & B1) ? 1u : 0u, l62 = (all & B62) ? 1u : 0u;
+            const unsigned f1 = (fst & B1) ? 1u : 0u, f62 = (fst & B62) ? 1u : 0u, g1 = (lst & B1) ? 1u : 0u, g62 = (lst & B62) ? 1u : 0u;
+            wake |= (e_first << 3) | (e_last << 5) | (l1 << 1) | (l62 << 7) | (f1 << 0) | (f62 << 6) | (g1 << 2) | (g62 << 8);
+            transpose32(d, scr_b, lane);
+        }
+        changed |= chg != 0;
+        if (!chg) {
+            capped = false;
+            break;
+        }
+    }
+}
+
 // ---- a tile that is ONE flat (every cell of the 62 x 62 interior is adjacent to all of its 8 neighbours, one class): no masks --
 // the interior of the lakes the tail rounds spend their time in.  Per row: min(left, right of the row behind) + Dg, the cell
 // behind + S, min3 with the cell itself; the two ring lanes are put back (they belong to the neighbouring tiles).
@@ -317,7 +394,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.blk + (int64_t)t * (WN * WN)), 0, WN * WN * 4, 0x00020000);
     const int Wi = (int)W;
     const int last_row = (int)(H - 1 - r0 < WN - 1 ? H - 1 - r0 : WN - 1);   // last window row inside the raster
-    uint32_t ni[WN], d[WN];
+    uint32_t ni[WN], d[WN], pk[WN / 2];
     uint32_t hdr;
     if constexpr (FIRST) {
         // ---- classification of the window from the plain fill F (adjacency bits = AGNPS direction codes of common.hpp:
@@ -427,9 +504,6 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < WN; ++r) __builtin_amdgcn_raw_buffer_store_b32(ni[r], rb, lane * 4, r * WN * 4, 0);
-        __builtin_amdgcn_sched_barrier(0);
         // one class in the whole window?  (from the words that stay live anyway: the adjacency byte is inverted by now)
         uint32_t esel = 255u;
 #pragma unroll
@@ -466,6 +540,16 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         }
         const bool uniform = !__any(mism != 0u);
         hdr = HDR_ACTIVE | seams | (uniform ? HDR_UNIFORM : 0u) | ((uniform && open_tile) ? HDR_OPEN : 0u) | (eref << 16);
+        __builtin_amdgcn_sched_barrier(0);
+        // the block: packed for a window of one class (relax_pk), the full words otherwise; none for a tile that is one flat
+        if (uniform && !open_tile) {
+#pragma unroll
+            for (int k = 0; k < WN / 2; ++k)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(ni[2 * k + 1], ni[2 * k], 0x06040200u), rb, lane * 4, k * WN * 4, 0);
+        } else if (!uniform) {
+#pragma unroll
+            for (int r = 0; r < WN; ++r) __builtin_amdgcn_raw_buffer_store_b32(ni[r], rb, lane * 4, r * WN * 4, 0);
+        }
         if (lane == 0) {
             a.hdr[t] = hdr;
             a.mark[t] = 1;       // the first relaxation of the tile is a visit of the next launch like any other
@@ -476,7 +560,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     } else {
         hdr = __builtin_amdgcn_readfirstlane(a.hdr[t]);
         if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
-        if (!(hdr & HDR_OPEN)) {           // (a tile that is one flat needs no words)
+        if (hdr & HDR_OPEN) {              // (a tile that is one flat needs no words)
+        } else if (hdr & HDR_UNIFORM) {    // packed: two register rows per word
+#pragma unroll
+            for (int k = 0; k < WN / 2; ++k) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
+        } else {
 #pragma unroll
             for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
         }
@@ -498,7 +586,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     unsigned wake = 0;
     bool changed = false, capped = false;
     if (hdr & HDR_OPEN) relax_open(d, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
-    else if (hdr & HDR_UNIFORM) relax(d, ni, UniformW{tab_l[eref], tab_l[256 + eref]}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    else if (hdr & HDR_UNIFORM) relax_pk(d, pk, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     wake &= hdr & 0x1ffu;
 #ifdef NG_PROFILE

@@ -59,7 +59,7 @@ constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simp
 constexpr int G_SHIFT = 44;
 constexpr uint64_t G_ONE = 1ull << G_SHIFT, G_SUM = G_ONE - 1, G_PEND = 0x7ffffull;
 
-enum : uint8_t { F_EXIT = 1, F_RESOLVED = 2, F_ENTRY = 4 };
+enum : uint8_t { F_EXIT = 1, F_RESOLVED = 2, F_ENTRY = 4, F_DEXT_SHIFT = 3 };   // bits 3..5: external in-degree of the cell (at most 5)
 
 __device__ __forceinline__ bool flows_into(unsigned code, int k_from_me) { return code <= 7u && code == (unsigned)((k_from_me + 4) & 7); }
 
@@ -102,7 +102,9 @@ __device__ unsigned long long g_accum_prof[2][8];
 // ---- the tile kernel (phase 1 when FINAL == false, phase 3 when FINAL == true) ------------------------------
 // WIDE: 64-bit sums (a row band's final pass, where the halo cells are sources of the neighbouring band's flux -- sums of the
 // whole raster -- and any raster of 2**31 cells or more; everything else stays below 2**31 in every sum)
-template <bool FINAL, bool WIDE>
+// STOREL (phase 1 of a raster that is no row band and has fewer than 2**31 cells): the tile-local sums are kept -- 16-bit
+// words (sum <= 4096 | taint << 15) at the start of each tile row's own segment of `out` -- for accum_final_walk_kernel.
+template <bool FINAL, bool WIDE, bool STOREL = false>
 // Row-band mode: local row 0 / H-1 may be a HALO row owned by the neighbouring band.  Its cells carry the neighbour's
 // final value in `out` (> 0: known, acts as a source of that much flux; <= 0: not known yet, blocks everything below it);
 // they never receive and are never written here.
@@ -275,6 +277,15 @@ __global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restri
         return;
     }
 
+    if (STOREL) {   // (a wave writes one tile row per step: 256 contiguous bytes)
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int i = tid + ATN * j;
+            const int r = i / AT, c = i - r * AT;
+            if ((r0 + r) < H && (c0 + c) < W)     // (at most the 4096 cells of the tile: 13 bits + the taint)
+                reinterpret_cast<uint16_t *>(out + (r0 + r) * W + c0)[c] = (uint16_t)((S[i] & 0x7fffu) | ((S[i] & TAINT_S) ? 0x8000u : 0u));
+        }
+    }
     // boundary pass: where does the path of every halo cell of this tile go?  -1: it ends inside the band (or never enters it),
     // <= -2: it leaves the band again from the cell  -2 - value = side * W + column,  >= 0: it leaves the tile through that node
     auto band_side = [&](int64_t gr) { return (fixed_top && gr == 0) ? (int64_t)0 : W; };
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restri
             }
         }
         if (nd.bexit) nd.bexit[node] = bex;
-        nd.flags[node] = fl;
+        nd.flags[node] = (uint8_t)(fl | (dext_l[tid] << F_DEXT_SHIFT));
         nd.dst[node] = dst;
         nd.exit_of[node] = ex;
         nd.gstate[node] = ((resolved ? 0ull : 1ull) << G_SHIFT) | (unsigned long long)(s & ~TAINT_S);  // unresolved: blocks itself forever
@@ -364,6 +375,117 @@ __global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restri
         nd.next[node] = -1;
     }
     MH_ASTAMP(3);
+}
+
+// ---- phase 3 without a second doubling (one context, fewer than 2**31 cells) ------------------------------------------------
+// final[c] = local[c] + the external inflow of every ENTRY cell whose tile-local path runs through c.  Entries are few (60 of a
+// tile's 252 perimeter cells on the benchmark terrain) and their paths short (38 cells on average, the longest of a tile 70), and
+// they cover a sixth of the cells: every entry WALKS its path and adds its inflow -- one non-returning LDS add and one pointer
+// read per step, ~2300 steps per tile on one or two wavefronts -- where the doubling pushed 5 x 4096 sums.  The local sums come
+// from phase 1 (STOREL), the pointers from the tile's own flow directions (no ring needed: the external in-degree of an entry is
+// in its node flags).  A cell that phase 1 left tainted ends every walk that reaches it (all of its downstream cells are
+// tainted as well); an entry whose inflow never arrived taints its path.
+__global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H, int64_t W, int ntc, Nodes nd)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t S[AT * AT];
+    __shared__ __attribute__((aligned(16))) uint16_t P[AT * AT];
+    __shared__ uint32_t wl_cell[NODE_STRIDE], wl_add[NODE_STRIDE];
+    __shared__ uint32_t wl_n;
+    const int tile = blockIdx.x;
+    const int ti = tile / ntc, tj = tile - ti * ntc;
+    const int64_t r0 = (int64_t)ti * AT, c0 = (int64_t)tj * AT;
+    const int tid = threadIdx.x;
+    if (tid == 0) wl_n = 0;
+    // node data of my perimeter cell first (the longest dependent chain of the kernel starts here)
+    uint8_t fl = 0;
+    uint64_t inflow = 0;
+    uint32_t arrived = 0;
+    if (tid < PERIM) {
+        const int64_t node = (int64_t)tile * NODE_STRIDE + tid;
+        fl = nd.flags[node];
+        inflow = nd.inflow[node];
+        arrived = nd.arrived[node];
+    }
+    const bool wide = (W % 16) == 0 && c0 + AT <= W;
+    // local sums and pointers: a lane takes four cells of a row (16 lanes per row: 256 B of sums, 64 B of directions), 16 rows
+    // per step of the workgroup; LDS in 16- / 8-byte writes
+    for (int q = tid; q < AT * 16; q += ATN) {
+        const int r = q >> 4, c4 = (q & 15) * 4;
+        const int64_t rr = r0 + r;
+        uint32_t l[4];
+        uint8_t b[4];
+        if (rr < H && wide) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(out + rr * W + c0) + c4);
+            l[0] = v.x & 0xffffu; l[1] = v.x >> 16; l[2] = v.y & 0xffffu; l[3] = v.y >> 16;
+            const uint32_t f = *reinterpret_cast<const uint32_t *>(fd + rr * W + c0 + c4);
+            memcpy(b, &f, 4);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t cc = c0 + c4 + t;
+                const bool in = rr < H && cc < W;
+                l[t] = in ? reinterpret_cast<const uint16_t *>(out + rr * W + c0)[c4 + t] : 0x8000u;
+                b[t] = in ? fd[rr * W + cc] : (uint8_t)8;
+            }
+        }
+        uint16_t nx[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            l[t] = (l[t] & 0x7fffu) | ((l[t] & 0x8000u) ? TAINT32 : 0u);
+            const int c = c4 + t;
+            const unsigned code = b[t];
+            nx[t] = (uint16_t)SENT13;
+            if (code <= 7u && !(l[t] & TAINT32)) {
+                const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
+                if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W) nx[t] = (uint16_t)(nr * AT + nc);
+            }
+        }
+        *reinterpret_cast<uint4 *>(&S[r * AT + c4]) = make_uint4(l[0], l[1], l[2], l[3]);
+        *reinterpret_cast<uint2 *>(&P[r * AT + c4]) = make_uint2((uint32_t)nx[0] | ((uint32_t)nx[1] << 16), (uint32_t)nx[2] | ((uint32_t)nx[3] << 16));
+    }
+    __syncthreads();
+    // the walkers: every entry with its inflow (bit 31: the inflow never arrived -- the path is tainted)
+    if (tid < PERIM && (fl & F_ENTRY)) {
+        const unsigned dext = (fl >> F_DEXT_SHIFT) & 7u;
+        int r, c;
+        perim_cell(tid, r, c);
+        const uint32_t k = atomicAdd(&wl_n, 1u);
+        wl_cell[k] = (uint32_t)(r * AT + c);
+        wl_add[k] = arrived == dext ? (uint32_t)inflow : TAINT32;
+    }
+    __syncthreads();
+    const uint32_t nw = wl_n;
+    if ((uint32_t)tid < nw) {
+        uint32_t a = wl_cell[tid];
+        const uint32_t v = wl_add[tid];
+        if (v & TAINT32) {
+            do {
+                atomicOr(&S[a], TAINT32);
+                a = P[a];
+            } while (a != SENT13);
+        } else {
+            do {
+                atomicAdd(&S[a], v);
+                a = P[a];
+            } while (a != SENT13);
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < AT * 16; q += ATN) {
+        const int r = q >> 4, c4 = (q & 15) * 4;
+        const int64_t rr = r0 + r;
+        if (rr >= H) continue;
+        typedef double __attribute__((ext_vector_type(2))) v2d;
+        const uint4 sv = *reinterpret_cast<const uint4 *>(&S[r * AT + c4]);
+        const uint32_t sq[4] = {sv.x, sv.y, sv.z, sv.w};
+        if (wide) {
+            *reinterpret_cast<v2d *>(out + rr * W + c0 + c4) = v2d{(sq[0] & TAINT32) ? 0.0 : (double)sq[0], (sq[1] & TAINT32) ? 0.0 : (double)sq[1]};
+            *reinterpret_cast<v2d *>(out + rr * W + c0 + c4 + 2) = v2d{(sq[2] & TAINT32) ? 0.0 : (double)sq[2], (sq[3] & TAINT32) ? 0.0 : (double)sq[3]};
+        } else {
+            for (int t = 0; t < 4; ++t)
+                if (c0 + c4 + t < W) out[rr * W + c0 + c4 + t] = (sq[t] & TAINT32) ? 0.0 : (double)sq[t];
+        }
+    }
 }
 
 // ---- phase 2: the perimeter graph -------------------------------------------------------------------------
@@ -479,7 +601,12 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     if (d_exit_map) MH_HIP(hipMemsetAsync(nd.halo_first, 0xff, 8 * (size_t)W, s));
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
     // the local sums of phase 1 fit 32 bits unless halo cells bring the neighbouring band's flux in (the final pass of a row band)
-    if ((fixed_top || fixed_bot) && !halo_zero)
+    // the final pass as walks from the entry cells (accum_final_walk_kernel) wherever the sums fit 32 bits and no halo row is a source
+    static const bool doubling_final = dev_env("MHIP_ACC_DOUBLING") != nullptr;      // development knob: the second doubling pass (A/B)
+    const bool walk_final = !(fixed_top || fixed_bot) && !d_exit_map && H * W < (int64_t)0x7fffffff && !doubling_final;
+    if (walk_final)
+        hipLaunchKernelGGL((accum_tile_kernel<false, false, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
+    else if ((fixed_top || fixed_bot) && !halo_zero)
         hipLaunchKernelGGL((accum_tile_kernel<false, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else
         hipLaunchKernelGGL((accum_tile_kernel<false, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
@@ -489,7 +616,9 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     // final values are at most H * W without halo sources: 32-bit sums (half the LDS, cheaper atomics) below 2**31 cells
-    if (!(fixed_top || fixed_bot) && H * W < (int64_t)0x7fffffff)
+    if (walk_final)
+        hipLaunchKernelGGL(accum_final_walk_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd);
+    else if (!(fixed_top || fixed_bot) && H * W < (int64_t)0x7fffffff)
         hipLaunchKernelGGL((accum_tile_kernel<true, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else
         hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);

@@ -385,7 +385,10 @@ __global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restri
 // from phase 1 (STOREL), the pointers from the tile's own flow directions (no ring needed: the external in-degree of an entry is
 // in its node flags).  A cell that phase 1 left tainted ends every walk that reaches it (all of its downstream cells are
 // tainted as well); an entry whose inflow never arrived taints its path.
-__global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H, int64_t W, int ntc, Nodes nd)
+// `pc.key` (optional): the pour points on the way (common.hpp: PourCandDev) -- the final sums of the tile's candidate cells go
+// into the keys of their labels.
+__global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H, int64_t W, int ntc, Nodes nd,
+                                                              PourCandDev pc)
 {
     __shared__ __attribute__((aligned(16))) uint32_t S[AT * AT];
     __shared__ __attribute__((aligned(16))) uint16_t P[AT * AT];
@@ -471,6 +474,48 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
         }
     }
     __syncthreads();
+    if (pc.key) {
+        auto key_of = [&](int lr, int lc, bool *bad) -> unsigned long long {
+            const uint32_t sv = S[lr * AT + lc];
+            if (sv & TAINT32) *bad = true;      // (an unresolved cell: the caller runs the general pass)
+            const uint32_t cell = (uint32_t)((r0 + lr) * W + c0 + lc);
+            return ((unsigned long long)((sv & TAINT32) ? 0u : sv) << 32) | (unsigned long long)(0xffffffffu - cell);
+        };
+        bool bad = false;
+        // unlabelled candidates: one key for the tile
+        unsigned long long best = 0;
+        {
+            uint32_t m = pc.mask0[(int64_t)tile * 256 + tid];
+            const int lr = tid >> 2, cb = (tid & 3) * 16;
+            while (m) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1;
+                const unsigned long long kk = key_of(lr, cb + k, &bad);
+                best = kk > best ? kk : best;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ob = __shfl_xor(best, o);
+            best = ob > best ? ob : best;
+        }
+        __shared__ unsigned long long best_w[ATN / 64];
+        if ((tid & 63) == 0) best_w[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 1; w < ATN / 64; ++w) best = best_w[w] > best ? best_w[w] : best;
+            pc.tile_key0[tile] = best;
+        }
+        // labelled candidates: a handful per label
+        const uint32_t off = (uint32_t)tile * POUR_TILE_CAP, cnt = pc.tile_cnt[tile];
+        for (uint32_t i = tid; i < cnt; i += ATN) {
+            const uint2 e = pc.list[off + i];
+            const uint32_t gr = e.x / (uint32_t)W, gc = e.x - gr * (uint32_t)W;
+            atomicMax(&pc.key[e.y], key_of((int)(gr - (uint32_t)r0), (int)(gc - (uint32_t)c0), &bad));
+        }
+        if (bad) pc.flags[1] = 1u;
+    }
     for (int q = tid; q < AT * 16; q += ATN) {
         const int r = q >> 4, c4 = (q & 15) * 4;
         const int64_t rr = r0 + r;
@@ -571,7 +616,7 @@ __global__ __launch_bounds__(256) void accum_band_exit_kernel(Nodes nd, int64_t 
 }  // namespace
 
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot, int halo_zero,
-              int32_t *d_exit_map)
+              int32_t *d_exit_map, PourLink *pour)
 {
     const int ntr = (int)cdiv(H, AT), ntc = (int)cdiv(W, AT);
     const int64_t ntiles = (int64_t)ntr * ntc, nnodes = ntiles * NODE_STRIDE;
@@ -616,8 +661,15 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     hipLaunchKernelGGL(accum_mark_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     hipLaunchKernelGGL(accum_graph_walk_kernel, dim3(gn), dim3(256), 0, s, nd, nnodes);
     // final values are at most H * W without halo sources: 32-bit sums (half the LDS, cheaper atomics) below 2**31 cells
-    if (walk_final)
-        hipLaunchKernelGGL(accum_final_walk_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd);
+    if (walk_final) {
+        PourCandDev pc;      // (no keys: the pour points stay a pass of their own)
+        if (pour && pour->wait && pour->wait(pour->arg) == 1 && pour->dev.key) {
+            MH_HIP(hipStreamWaitEvent(s, pour->ev, 0));
+            pc = pour->dev;
+            pour->consumed = true;
+        }
+        hipLaunchKernelGGL(accum_final_walk_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, pc);
+    }
     else if (!(fixed_top || fixed_bot) && H * W < (int64_t)0x7fffffff)
         hipLaunchKernelGGL((accum_tile_kernel<true, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else

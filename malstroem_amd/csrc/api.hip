@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include <condition_variable>
 #include <functional>
+#include <atomic>
 #include <future>
 #include <thread>
 
@@ -526,6 +527,8 @@ struct mhip_ctx {
     bool have[MHIP_R_COUNT_] = {};
     DevBuf tmp_i32;         // CCL parent scratch
     DevBuf raw_stats, stats, ws_counts, pour;
+    DevBuf pp_mask0, pp_list, pp_tiles, pp_misc, pp_key;    // pour-point candidates on their way from the watersheds to the accumulation (PourLink)
+    hipEvent_t ev_cand = nullptr;
     int64_t nlabels_raw = -1, nlabels = -1;
     bool labels_components = false;   // LABELS came from the library's own labelling (not uploaded): 8-connected components
     bool labels_filtered = false;
@@ -634,7 +637,7 @@ int mhip_ctx_destroy(mhip_ctx *c)
             (void)hipStreamDestroy(st);
         }
     }
-    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label, c->ev_tail})
+    for (hipEvent_t e : {c->ev_fork, c->ev_flowdir, c->ev_join, c->ev_label, c->ev_tail, c->ev_cand})
         if (e) (void)hipEventDestroy(e);
     delete c->geo;
     delete c->pf;
@@ -1632,13 +1635,13 @@ static int stage_flowdir_fused(mhip_ctx *c, hipStream_t s)
     return MHIP_OK;
 }
 
-static int stage_accum(mhip_ctx *c, hipStream_t s)
+static int stage_accum(mhip_ctx *c, hipStream_t s, PourLink *pour = nullptr)
 {
     MH_ARG(c->have[MHIP_R_FLOWDIR], "ACCUM needs flow directions");
     MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_ACCUM, s, &e1));
-    MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, s, c->ht, c->hb));
+    MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, s, c->ht, c->hb, 0, nullptr, pour));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_ACCUM] = true;
     c->have[MHIP_R_ACCUM] = true;
@@ -1672,7 +1675,30 @@ static int stage_label(mhip_ctx *c, hipStream_t s)
     return MHIP_OK;
 }
 
-static int stage_watershed(mhip_ctx *c, hipStream_t s)
+// the buffers of a PourLink for this context's raster and labels; zeroed on `s` (the stream of the watersheds' tile pass)
+static int pour_link_buffers(mhip_ctx *c, PourLink *pl, hipStream_t s)
+{
+    const int64_t H = c->H, W = c->W;
+    const int64_t ntiles = cdiv(H, 64) * cdiv(W, 64);
+    MH_TRY(c->pp_mask0.alloc(2 * 256 * (size_t)ntiles));
+    MH_TRY(c->pp_list.alloc(8 * (size_t)POUR_TILE_CAP * (size_t)ntiles));
+    MH_TRY(c->pp_tiles.alloc(12 * (size_t)ntiles));
+    MH_TRY(c->pp_misc.alloc(16));
+    MH_TRY(c->pp_key.alloc(8 * (size_t)(c->nlabels + 1)));
+    MH_HIP(hipMemsetAsync(c->pp_misc.p, 0, 16, s));
+    MH_HIP(hipMemsetAsync(c->pp_key.p, 0, 8 * (size_t)(c->nlabels + 1), s));
+    pl->dev.mask0 = c->pp_mask0.as<uint16_t>();
+    pl->dev.list = c->pp_list.as<uint2>();
+    pl->dev.tile_key0 = c->pp_tiles.as<unsigned long long>();
+    pl->dev.tile_cnt = reinterpret_cast<uint32_t *>(c->pp_tiles.as<unsigned long long>() + ntiles);
+    pl->dev.flags = c->pp_misc.as<uint32_t>() + 1;
+    pl->dev.components = c->labels_components ? 1 : 0;
+    pl->dev.key = c->pp_key.as<unsigned long long>();
+    pl->ev = c->ev_cand;
+    return MHIP_OK;
+}
+
+static int stage_watershed(mhip_ctx *c, hipStream_t s, PourLink *pour = nullptr)
 {
     const int64_t H = c->H, W = c->W, n = H * W;
     MH_ARG(c->have[MHIP_R_LABELS] && c->have[MHIP_R_FLOWDIR], "WATERSHED needs labels and flow directions");
@@ -1681,9 +1707,10 @@ static int stage_watershed(mhip_ctx *c, hipStream_t s)
     MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_WATERSHED, s, &e1));
+    if (pour) MH_TRY(pour_link_buffers(c, pour, s));
     // (out of place: the watersheds start from the label raster without a copy of it)
     MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), H, W, 0, s, false,
-                          c->nodir_valid ? c->nodir_cnt.as<unsigned int>() : nullptr, c->r[MHIP_R_LABELS].as<int32_t>()));
+                          c->nodir_valid ? c->nodir_cnt.as<unsigned int>() : nullptr, c->r[MHIP_R_LABELS].as<int32_t>(), pour));
     MH_TRY(c->ws_counts.alloc(8 * (size_t)(c->nlabels + 1)));
     MH_TRY(label_count_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), n, c->nlabels, c->ws_counts.as<int64_t>(), s, W));
     MH_HIP(hipEventRecord(*e1, s));
@@ -1692,7 +1719,7 @@ static int stage_watershed(mhip_ctx *c, hipStream_t s)
     return MHIP_OK;
 }
 
-static int stage_pourpoints(mhip_ctx *c, hipStream_t s)
+static int stage_pourpoints(mhip_ctx *c, hipStream_t s, PourLink *pour = nullptr)
 {
     const int64_t H = c->H, W = c->W;
     MH_ARG(c->have[MHIP_R_LABELS] && (c->have[MHIP_R_ACCUM] || c->have[MHIP_R_NOFLAT]),
@@ -1703,7 +1730,21 @@ static int stage_pourpoints(mhip_ctx *c, hipStream_t s)
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_POURPOINTS, s, &e1));
     // bluespots.py:195-206: max accumulated flow if available, else min of the no-flats surface
-    if (c->have[MHIP_R_ACCUM])
+    bool from_keys = false;
+    if (pour && pour->consumed && c->have[MHIP_R_ACCUM]) {
+        // the accumulation's final pass has left one key per label (common.hpp: PourLink) -- unless the candidate list overflowed
+        // or a cell stayed unresolved (a flow cycle): then the general pass below
+        uint32_t h[3] = {0, 1, 1};
+        MH_HIP(hipMemcpyAsync(h, c->pp_misc.p, 12, hipMemcpyDeviceToHost, s));
+        MH_HIP(stream_sync(s));
+        if (!h[1] && !h[2]) {
+            MH_TRY(pour_finish_dev(c->pp_key.as<unsigned long long>(), c->pp_tiles.as<unsigned long long>(), cdiv(H, 64) * cdiv(W, 64), c->nlabels, W,
+                                   c->pour.as<mhip_index_record>(), s));
+            from_keys = true;
+        }
+    }
+    if (from_keys) {
+    } else if (c->have[MHIP_R_ACCUM])
         MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, true,
                              c->pour.as<mhip_index_record>(), s, c->labels_components));
     else
@@ -1784,6 +1825,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         MH_HIP(hipEventCreateWithFlags(&c->ev_label, hipEventDisableTiming));
         MH_HIP(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
     }
+    if (!c->ev_cand) MH_HIP(hipEventCreateWithFlags(&c->ev_cand, hipEventDisableTiming));
     hipStream_t sb = c->stream_b;
     const bool do_fill = (mask & MHIP_STAGE_FILL) != 0;
     MH_ARG(c->have[MHIP_R_DEM] || !(mask & (MHIP_STAGE_FILL | MHIP_STAGE_NOFLAT)), "FILL / NOFLAT need the DEM");
@@ -1806,6 +1848,24 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         t->p->set_value(hipEventRecord(t->c->ev_tail, st) == hipSuccess ? MHIP_OK : MHIP_EHIP);
     };
     std::future<int> flowdir_fut = flowdir_ready.get_future(), label_fut = label_ready.get_future();
+    // Pour points out of the accumulation's final pass (common.hpp: PourLink): the watersheds' tile pass on the other thread lists
+    // the candidate cells, the accumulation's final pass on this one waits for them.  MHIP_POUR=pass (development): the pass
+    // over accumulation + labels at the end of the request instead.
+    struct CandHand {
+        std::promise<int> p;
+        std::future<int> f;
+        std::atomic<bool> set{false};
+    } cand_hand;
+    cand_hand.f = cand_hand.p.get_future();
+    PourLink pour_link;
+    pour_link.arg = &cand_hand;
+    pour_link.notify = [](void *a, int v) {
+        CandHand *h = static_cast<CandHand *>(a);
+        if (!h->set.exchange(true)) h->p.set_value(v);
+    };
+    pour_link.wait = [](void *a) { return static_cast<CandHand *>(a)->f.get(); };
+    static const bool pour_pass = [] { const char *e = dev_env("MHIP_POUR"); return e && std::string(e) == "pass"; }();
+    PourLink *const pour = ((mask & MHIP_STAGE_ACCUM) && (mask & MHIP_STAGE_WATERSHED) && (mask & MHIP_STAGE_POURPOINTS) && !pour_pass) ? &pour_link : nullptr;
     const bool ws_needs_new_flowdir = (mask & MHIP_STAGE_WATERSHED) && (mask & MHIP_STAGE_FLOWDIR);
     int rc_b = MHIP_OK;
     char err_b[512] = "";
@@ -1843,7 +1903,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
                     MH_TRY(flowdir_fut.get());
                     MH_HIP(hipStreamWaitEvent(sw, c->ev_flowdir, 0));
                 }
-                MH_TRY(stage_watershed(c, sw));
+                MH_TRY(stage_watershed(c, sw, pour));
             }
             MH_HIP(hipEventRecord(c->ev_join, sw));
             return MHIP_OK;
@@ -1851,6 +1911,7 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
         if (rc_b != MHIP_OK && !err_b[0]) snprintf(err_b, sizeof(err_b), "%s", get_error());
         if (!shdg_set) shdg_done.set_value(rc_b);
         if (!label_set) label_ready.set_value(rc_b);
+        pour_link.notify(pour_link.arg, 0);       // (no candidates if the watersheds never got that far: nobody is left waiting)
     });
     int rc_a = MHIP_OK;
     if (do_fill) rc_a = stage_fill(c, s, /*with_depths=*/false);
@@ -1878,11 +1939,11 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
     }();
     tail_hook.fire(s);                    // (no NOFLAT in the mask, or it failed early: the other thread is never left waiting)
     flowdir_ready.set_value(rc_a);
-    if (rc_a == MHIP_OK && (mask & MHIP_STAGE_ACCUM)) rc_a = stage_accum(c, s);
+    if (rc_a == MHIP_OK && (mask & MHIP_STAGE_ACCUM)) rc_a = stage_accum(c, s, pour);
     // POURPOINTS needs the final labels and the accumulation, not the watersheds: it runs next to them
     const int rc_l = label_fut.get();
     if (rc_a == MHIP_OK && rc_l == MHIP_OK && (mask & MHIP_STAGE_POURPOINTS)) {
-        rc_a = hipStreamWaitEvent(s, c->ev_label, 0) == hipSuccess ? stage_pourpoints(c, s) : MHIP_EHIP;
+        rc_a = hipStreamWaitEvent(s, c->ev_label, 0) == hipSuccess ? stage_pourpoints(c, s, pour) : MHIP_EHIP;
     }
     c->side.wait();
     if (rc_a != MHIP_OK) return rc_a;

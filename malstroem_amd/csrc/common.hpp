@@ -299,9 +299,35 @@ void comm_destroy(void *comm);
 int comm_exchange_rows(void *comm, int rank, int nranks, const void *first_row, const void *last_row, void *stage, size_t rowbytes,
                        hipStream_t s);
 int comm_allreduce_max(void *comm, double *d_value, hipStream_t s);
+// Pour points out of the accumulation's final pass (bluespots.py:195-206: the cell of the largest accumulated flow of every label,
+// the first in raster order among equals).  Accumulated flow grows strictly along a flow path, so the largest value of a label
+// sits on a cell whose downstream cell is NOT of that label -- a CANDIDATE: 3 % of the labelled cells, a fifth of the unlabelled
+// ones.  The watersheds' tile pass (labels + flow directions of a 64 x 64 tile in one place) lists the candidates; the
+// accumulation's final pass (the final sums of the same tile in LDS) turns them into one packed key per label,
+// (value << 32) | (0xffffffff - cell), by atomicMax -- and the pass over accumulation + labels that the pour points were
+// (12.6 B/cell at the end of a step) goes.  Exact unless a cell stays unresolved (a flow cycle: the value 0 does not grow along
+// the path) or the list overflows: both raise a flag and the caller runs the general pass.
+struct PourCandDev {             // device side, tile = 64 x 64 cells as in accum.hip / watershed.hip, thread t <-> row t >> 2, columns (t & 3) * 16 ..
+    uint16_t *mask0 = nullptr;   // [ntiles * 256] unlabelled candidates: bit k of word t = column (t & 3) * 16 + k of row t >> 2
+    uint2 *list = nullptr;       // [ntiles * POUR_TILE_CAP] labelled candidates: (cell, label); a tile's entries start at tile * POUR_TILE_CAP
+    uint32_t *tile_cnt = nullptr;          // [ntiles]   (no global counters: 65 536 atomics on one address cost a millisecond)
+    unsigned long long *tile_key0 = nullptr;   // [ntiles] the best key among the tile's unlabelled candidates (label 0: reduced by pour_finish_dev)
+    uint32_t *flags = nullptr;   // [0] a tile's list overflowed, [1] an unresolved cell
+    int components = 0;          // the labels are 8-connected components: two neighbouring labelled cells share their label
+    unsigned long long *key = nullptr;   // [nlabels + 1], zeroed
+};
+constexpr uint32_t POUR_TILE_CAP = 512;
+struct PourLink {                // host side: hand-over between the thread of the watersheds and the thread of the accumulation
+    PourCandDev dev;
+    hipEvent_t ev = nullptr;                       // recorded behind the tile pass that wrote the candidates
+    void (*notify)(void *, int) = nullptr;         // watersheds_dev: candidates recorded (1) / there will be none (0)
+    int (*wait)(void *) = nullptr;                 // accum_dev, before its final pass: blocks; 1: the candidates exist (wait for `ev`)
+    void *arg = nullptr;
+    bool consumed = false;                         // the final pass has written the keys
+};
 // accum.hip
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0, int halo_zero = 0,
-              int32_t *d_exit_map = nullptr);
+              int32_t *d_exit_map = nullptr, PourLink *pour = nullptr);
 // ccl.hip   (d_tmp: H*W int32 scratch)
 // stats_out: the labelling's last pass also reduces label_stats(d_data, labels) into *stats_out (allocated here: nlabels + 1 records)
 int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
@@ -332,7 +358,9 @@ int label_count_dev(const int32_t *d_labels, int64_t n, int64_t nlab, int64_t *d
 int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStream_t s);
 // watershed.hip
 int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s,
-                   bool band_mode = false, const unsigned int *d_known_interior_nodir = nullptr, const int32_t *d_src = nullptr);
+                   bool band_mode = false, const unsigned int *d_known_interior_nodir = nullptr, const int32_t *d_src = nullptr, PourLink *pour = nullptr);
+int pour_finish_dev(unsigned long long *d_key, const unsigned long long *d_tile_key0, int64_t ntiles, int64_t nlab, int64_t W, mhip_index_record *d_rec,
+                    hipStream_t s);
 int band_pseudo_labels_dev(int32_t *d_ws, int64_t H, int64_t W, int top, int bottom, hipStream_t s);
 int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nlut, hipStream_t s);
 

@@ -114,8 +114,10 @@ __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, i
 // jumped through global memory (6 % of the raster, and one hop now crosses a tile); the final pass takes one more hop for the
 // cells that still point at an entry.
 constexpr int WT = 64;
+// `pc` (optional): the pour-point candidates of the tile on the way (common.hpp: PourCandDev) -- a cell whose downstream cell does
+// not carry its own label (or which has none).  Whether the downstream cell is labelled is in `val` already.
 __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict__ fd, const int32_t *__restrict__ lab, int32_t *__restrict__ P, int64_t H,
-                                                     int64_t W, int ntc, int32_t unassigned)
+                                                     int64_t W, int ntc, int32_t unassigned, PourCandDev pc)
 {
     __shared__ uint16_t ptr[WT * WT];
     __shared__ int32_t val[WT * WT];     // of a terminal: its own index (labelled), NONE, or the entry cell its path continues at
@@ -166,6 +168,61 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
         val[li] = v;
     }
     __syncthreads();
+    if (pc.mask0) {
+        uint32_t m0 = 0, ml = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t c = cbase + k;
+            if (!(r < H && c < W)) continue;
+            const int32_t l = lb[k];
+            bool same = false;         // the downstream cell carries my label (unlabelled: it is unlabelled as well)
+            if (code[k] <= 7u) {
+                const int64_t nr = r + dir_dr((int)code[k]), nc = c + dir_dc((int)code[k]);
+                if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
+                    const int64_t lr2 = nr - r0, lc2 = nc - c0, gd = nr * W + nc;
+                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) {
+                        const bool labelled_d = val[lr2 * WT + lc2] == (int32_t)gd;
+                        if (pc.components) same = labelled_d == (l != unassigned);
+                        else same = (labelled_d ? lab[gd] : unassigned) == l;
+                    } else {
+                        same = lab[gd] == l;
+                    }
+                }
+            }
+            if (!same) {
+                if (l == unassigned) m0 |= 1u << k;
+                else ml |= 1u << k;
+            }
+        }
+        pc.mask0[(int64_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)m0;
+        // the labelled candidates of the tile, contiguous in the list: counts -> offsets over the workgroup, one global atomic
+        __shared__ uint32_t wsum[4], base_s;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t mine = (uint32_t)__builtin_popcount(ml);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            const bool fits = tot <= POUR_TILE_CAP;
+            if (!fits) pc.flags[0] = 1u;      // (the caller then runs the general pass over accumulation + labels)
+            pc.tile_cnt[blockIdx.x] = fits ? tot : 0u;
+            base_s = fits ? blockIdx.x * POUR_TILE_CAP : 0xffffffffu;
+        }
+        __syncthreads();
+        if (base_s != 0xffffffffu) {
+            uint32_t o = base_s + incl - mine;
+            for (int w = 0; w < wave; ++w) o += wsum[w];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if ((ml >> k) & 1u) pc.list[o++] = make_uint2((uint32_t)(r * W + cbase + k), (uint32_t)lb[k]);
+        }
+    }
     for (int round = 0; round < 13; ++round) {
         bool ch = false;
 #pragma unroll
@@ -321,9 +378,68 @@ int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nl
     return MHIP_OK;
 }
 
-int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s, bool band_mode,
-                   const unsigned int *d_known_interior_nodir, const int32_t *d_src)
+namespace {
+// label 0: the largest of the tiles' keys
+__global__ __launch_bounds__(1024) void pour_key0_kernel(const unsigned long long *__restrict__ tile_key0, int64_t ntiles, unsigned long long *key)
 {
+    unsigned long long best = 0;
+    for (int64_t t = threadIdx.x; t < ntiles; t += 1024) best = tile_key0[t] > best ? tile_key0[t] : best;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ob = __shfl_xor(best, o);
+        best = ob > best ? ob : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best) atomicMax(&key[0], best);
+}
+
+__global__ __launch_bounds__(256) void pour_finish_kernel(const unsigned long long *__restrict__ key, int64_t nrec, int64_t W, mhip_index_record *rec)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    mhip_index_record r;
+    const unsigned long long k = key[i];
+    if (k == 0) {  // no cell (a real key never is 0: its low word is 0xffffffff - cell > 0): label_max_index's initial record
+        r.value = -__builtin_inf();
+        r.row = -1;
+        r.col = -1;
+    } else {
+        const uint64_t p = 0xffffffffu - (uint32_t)k;
+        r.value = (double)(uint32_t)(k >> 32);
+        r.row = (int64_t)(p / (uint64_t)W);
+        r.col = (int64_t)(p % (uint64_t)W);
+    }
+    rec[i] = r;
+}
+
+}  // namespace
+
+int pour_finish_dev(unsigned long long *d_key, const unsigned long long *d_tile_key0, int64_t ntiles, int64_t nlab, int64_t W, mhip_index_record *d_rec,
+                    hipStream_t s)
+{
+    hipLaunchKernelGGL(pour_key0_kernel, dim3(1), dim3(1024), 0, s, d_tile_key0, ntiles, d_key);
+    hipLaunchKernelGGL(pour_finish_kernel, dim3((unsigned)cdiv(nlab + 1, 256)), dim3(256), 0, s, d_key, nlab + 1, W, d_rec);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+namespace {
+// watersheds_dev never leaves the thread that waits for its pour-point candidates without an answer
+struct PourNotify {
+    PourLink *pl;
+    bool done = false;
+    void operator()(int v)
+    {
+        if (pl && pl->notify && !done) pl->notify(pl->arg, v);
+        done = true;
+    }
+    ~PourNotify() { (*this)(0); }
+};
+}  // namespace
+
+int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W, int32_t unassigned, hipStream_t s, bool band_mode,
+                   const unsigned int *d_known_interior_nodir, const int32_t *d_src, PourLink *pour)
+{
+    PourNotify notify{pour};
     // d_src (optional): the label raster to start from when d_labels does not hold a copy of it yet -- the fast path then reads
     // the labels there and writes every cell of d_labels; the general path makes the copy first
     const int32_t *src = d_src ? d_src : d_labels;
@@ -354,7 +470,15 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     }
     if (!q) {
         const int64_t ntr = cdiv(H, WT), ntc = cdiv(W, WT), ntiles = ntr * ntc;
-        hipLaunchKernelGGL(ws_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, src, P.as<int32_t>(), H, W, (int)ntc, unassigned);
+        const bool cand = pour && pour->dev.mask0 && unassigned == 0 && n < 0xffffffffll;
+        hipLaunchKernelGGL(ws_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, src, P.as<int32_t>(), H, W, (int)ntc, unassigned,
+                           cand ? pour->dev : PourCandDev());
+        if (cand) {
+            MH_HIP(hipEventRecord(pour->ev, s));
+            notify(1);
+        } else {
+            notify(0);
+        }
         constexpr int MAX_ROUNDS = 40;   // x 5 hops over entry cells; flow cycles end here
         for (int round = 0; round < MAX_ROUNDS;) {
             const int k = round == 0 ? 2 : 1;

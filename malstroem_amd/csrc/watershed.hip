@@ -114,10 +114,28 @@ __global__ __launch_bounds__(256) void ws_jump_kernel(int32_t *P, uint32_t *Q, i
 // jumped through global memory (6 % of the raster, and one hop now crosses a tile); the final pass takes one more hop for the
 // cells that still point at an entry.
 constexpr int WT = 64;
+// The perimeter cells of the tiles -- the only cells a path can ENTER a tile at -- also live in a compact array, 256 slots per tile
+// (1 KB: the jumps over the entry cells gather there instead of in the raster, where a tile's left / right columns cost a
+// sector per cell: 8.7 B per raster cell for 6 % of the cells).  slot: top row, bottom row, left column, right column.
+__device__ __forceinline__ int ws_perim_slot(int lr, int lc)
+{
+    if (lr == 0) return lc;
+    if (lr == WT - 1) return WT + lc;
+    if (lc == 0) return 2 * WT + (lr - 1);
+    if (lc == WT - 1) return 2 * WT + (WT - 2) + (lr - 1);
+    return -1;
+}
+// the node of an entry cell; -1 for a cell inside its tile (a pointer caught in a flow cycle: it never resolves)
+__device__ __forceinline__ int64_t ws_node_of(int32_t cell, uint32_t W, int ntc)
+{
+    const uint32_t r = (uint32_t)cell / W, c = (uint32_t)cell - r * W;
+    const int slot = ws_perim_slot((int)(r & 63u), (int)(c & 63u));
+    return slot < 0 ? -1 : (int64_t)((r >> 6) * (uint32_t)ntc + (c >> 6)) * 256 + slot;
+}
 // `pc` (optional): the pour-point candidates of the tile on the way (common.hpp: PourCandDev) -- a cell whose downstream cell does
 // not carry its own label (or which has none).  Whether the downstream cell is labelled is in `val` already.
 __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict__ fd, const int32_t *__restrict__ lab, int32_t *__restrict__ P, int64_t H,
-                                                     int64_t W, int ntc, int32_t unassigned, PourCandDev pc)
+                                                     int64_t W, int ntc, int32_t unassigned, PourCandDev pc, int32_t *__restrict__ Pn)
 {
     __shared__ uint16_t ptr[WT * WT];
     __shared__ int32_t val[WT * WT];     // of a terminal: its own index (labelled), NONE, or the entry cell its path continues at
@@ -247,6 +265,8 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
             const int32_t v = val[t];
             out[k] = (v == (int32_t)gt && t != li) ? (v | DONE) : v;   // v: own index (a labelled cell keeps P == self), NONE, or an entry cell
         }
+        const int slot = ws_perim_slot(lr, lc0 + k);
+        if (slot >= 0) Pn[(int64_t)blockIdx.x * 256 + slot] = (r < H && cbase + k < W) ? out[k] : NONE;
     }
     if (vec) {
 #pragma unroll
@@ -258,27 +278,24 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
     }
 }
 
-// the jump of ws_jump_kernel for the perimeter cells of the tiles only
-__global__ __launch_bounds__(256) void ws_jump_perimeter_kernel(int32_t *P, int64_t H, int64_t W, int ntc, int64_t ntiles, unsigned int *open)
+// the jump of ws_jump_kernel for the perimeter cells of the tiles only, on their compact array: a node that still points at an
+// entry cell takes over what that entry's node points at.  A labelled node holds its own cell.
+__global__ __launch_bounds__(256) void ws_jump_perimeter_kernel(int32_t *Pn, int64_t W, int ntc, int64_t nnodes, unsigned int *open)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t tile = k >> 8;
-    const int p = (int)(k & 255);
-    if (tile >= ntiles || p >= 4 * WT - 4) return;
-    int lr, lc;
-    if (p < WT) { lr = 0; lc = p; }
-    else if (p < 2 * WT) { lr = WT - 1; lc = p - WT; }
-    else if (p < 3 * WT - 2) { lr = p - 2 * WT + 1; lc = 0; }
-    else { lr = p - (3 * WT - 2) + 1; lc = WT - 1; }
-    const int64_t r = (tile / ntc) * WT + lr, c = (tile % ntc) * WT + lc;
-    if (r >= H || c >= W) return;
-    const int64_t i = r * W + c;
-    int32_t t = P[i];
-    if (t < 0 || t == NONE || t == (int32_t)i) return;
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nnodes || (x & 255) >= 4 * WT - 4) return;
+    int32_t t = Pn[x];
+    if (t < 0 || t == NONE) return;
+    if (ws_node_of(t, (uint32_t)W, ntc) == x) return;      // labelled: a fixed point
     const int32_t t0 = t;
 #pragma unroll
     for (int h = 0; h < HOPS; ++h) {
-        const int32_t pt = P[t];
+        const int64_t nd = ws_node_of(t, (uint32_t)W, ntc);
+        if (nd < 0) {          // a flow cycle inside that tile: final as it is (the cell stays unassigned)
+            if (t != t0) Pn[x] = t;
+            return;
+        }
+        const int32_t pt = Pn[nd];
         if (pt == t) {
             t |= DONE;
             break;
@@ -286,14 +303,15 @@ __global__ __launch_bounds__(256) void ws_jump_perimeter_kernel(int32_t *P, int6
         t = pt;
         if (t < 0 || t == NONE) break;
     }
-    if (t != t0) P[i] = t;
+    if (t != t0) Pn[x] = t;
     if (t >= 0 && t != NONE) *open = 1u;
 }
 
 // final pass of the fast path: a cell that still points at an entry cell takes that cell's (resolved) pointer
 // `src` != `lab`: out of place -- every cell of `lab` is written (its own label unless it takes one from downstream), which saves
 // the caller the copy of the label raster it would otherwise start from
-__global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__restrict__ P, const int32_t *src, int32_t *lab, int64_t n)
+__global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__restrict__ P, const int32_t *__restrict__ Pn, const int32_t *src, int32_t *lab, int64_t n,
+                                                           int64_t W, int ntc)
 {
     // four cells per thread: 16-byte loads of P (and of src out of place), one 16-byte store out of place
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -301,8 +319,10 @@ __global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__res
     const bool copy = src != lab;
     auto target = [&](int64_t i, int32_t p) -> int32_t {     // the cell whose label cell i takes, or -1: it keeps its own
         if (p == NONE || p == (int32_t)i) return -1;         // flows out unlabelled, or labelled
-        if (p >= 0) {                                         // an entry cell
-            const int32_t q = P[p];
+        if (p >= 0) {                                         // an entry cell: what its node has been resolved to
+            const int64_t nd = ws_node_of(p, (uint32_t)W, ntc);
+            if (nd < 0) return -1;                            // (a flow cycle inside the tile)
+            const int32_t q = Pn[nd];
             if (q == p) p = q | DONE;                         // the entry cell is labelled itself
             else if (q < 0) p = q;                            // resolved through the entry cell
             else return -1;                                   // NONE, or a flow cycle: stays unassigned
@@ -471,8 +491,10 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
     if (!q) {
         const int64_t ntr = cdiv(H, WT), ntc = cdiv(W, WT), ntiles = ntr * ntc;
         const bool cand = pour && pour->dev.mask0 && unassigned == 0 && n < 0xffffffffll;
+        DevBuf Pn;
+        MH_TRY(Pn.alloc(4 * 256 * (size_t)ntiles));
         hipLaunchKernelGGL(ws_tile_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, d_fd, src, P.as<int32_t>(), H, W, (int)ntc, unassigned,
-                           cand ? pour->dev : PourCandDev());
+                           cand ? pour->dev : PourCandDev(), Pn.as<int32_t>());
         if (cand) {
             MH_HIP(hipEventRecord(pour->ev, s));
             notify(1);
@@ -484,14 +506,15 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
             const int k = round == 0 ? 2 : 1;
             MH_HIP(hipMemsetAsync(d_changed, 0, 8, s));
             for (int j = 0; j < k; ++j)
-                hipLaunchKernelGGL(ws_jump_perimeter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, P.as<int32_t>(), H, W, (int)ntc, ntiles, d_changed + j);
+                hipLaunchKernelGGL(ws_jump_perimeter_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, Pn.as<int32_t>(), W, (int)ntc, ntiles * 256, d_changed + j);
             unsigned int h[2] = {0, 0};
             MH_HIP(hipMemcpyAsync(h, d_changed, 8, hipMemcpyDeviceToHost, s));
             MH_HIP(stream_sync(s));
             round += k;
             if (!h[k - 1]) break;
         }
-        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, P.as<int32_t>(), src, d_labels, n);
+        hipLaunchKernelGGL(ws_assign_hop_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, P.as<int32_t>(), Pn.as<int32_t>(), src, d_labels, n, W,
+                           (int)ntc);
         MH_HIP(hipGetLastError());
         MH_HIP(stream_sync(s));
         return MHIP_OK;

@@ -516,6 +516,7 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
         }
         if (bad) pc.flags[1] = 1u;
     }
+    uint32_t anyt = 0;     // an unresolved cell anywhere (a label may consist of a flow cycle alone: no candidate, and its record is (0, first cell))
     for (int q = tid; q < AT * 16; q += ATN) {
         const int r = q >> 4, c4 = (q & 15) * 4;
         const int64_t rr = r0 + r;
@@ -524,13 +525,18 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
         const uint4 sv = *reinterpret_cast<const uint4 *>(&S[r * AT + c4]);
         const uint32_t sq[4] = {sv.x, sv.y, sv.z, sv.w};
         if (wide) {
+            anyt |= sq[0] | sq[1] | sq[2] | sq[3];
             *reinterpret_cast<v2d *>(out + rr * W + c0 + c4) = v2d{(sq[0] & TAINT32) ? 0.0 : (double)sq[0], (sq[1] & TAINT32) ? 0.0 : (double)sq[1]};
             *reinterpret_cast<v2d *>(out + rr * W + c0 + c4 + 2) = v2d{(sq[2] & TAINT32) ? 0.0 : (double)sq[2], (sq[3] & TAINT32) ? 0.0 : (double)sq[3]};
         } else {
             for (int t = 0; t < 4; ++t)
-                if (c0 + c4 + t < W) out[rr * W + c0 + c4 + t] = (sq[t] & TAINT32) ? 0.0 : (double)sq[t];
+                if (c0 + c4 + t < W) {
+                    anyt |= sq[t];
+                    out[rr * W + c0 + c4 + t] = (sq[t] & TAINT32) ? 0.0 : (double)sq[t];
+                }
         }
     }
+    if (pc.key && (anyt & TAINT32)) pc.flags[1] = 1u;
 }
 
 // ---- phase 2: the perimeter graph -------------------------------------------------------------------------

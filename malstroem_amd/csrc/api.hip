@@ -529,6 +529,7 @@ struct mhip_ctx {
     DevBuf raw_stats, stats, ws_counts, pour;
     DevBuf pp_mask0, pp_list, pp_tiles, pp_misc, pp_key;    // pour-point candidates on their way from the watersheds to the accumulation (PourLink)
     hipEvent_t ev_cand = nullptr;
+    int pour_algorithm = 0;
     int64_t nlabels_raw = -1, nlabels = -1;
     bool labels_components = false;   // LABELS came from the library's own labelling (not uploaded): 8-connected components
     bool labels_filtered = false;
@@ -1743,6 +1744,7 @@ static int stage_pourpoints(mhip_ctx *c, hipStream_t s, PourLink *pour = nullptr
             from_keys = true;
         }
     }
+    c->pour_algorithm = from_keys ? 1 : 0;
     if (from_keys) {
     } else if (c->have[MHIP_R_ACCUM])
         MH_TRY(label_arg_dev(c->r[MHIP_R_ACCUM].as<double>(), c->r[MHIP_R_LABELS].as<int32_t>(), H, W, c->nlabels, true,
@@ -2006,6 +2008,7 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "fill_launches") *value = c->fill_st.rounds;
     else if (k == "fill_hot_launches") *value = c->fill_st.hot_launches;
     else if (k == "noflat_hot_launches") *value = c->noflat_st.hot_launches;
+    else if (k == "pour_algorithm") *value = c->pour_algorithm;   // 0 a pass over values + labels (label_ops.hip), 1 keys out of the accumulation's final pass (PourLink)
     else if (k == "noflat_algorithm") *value = c->noflat_st.algorithm;   // 0 float64 relaxation (fill.hip), 2 integer geodesic transform (noflat_geo.hip)
     else if (k == "noflat_visits") *value = c->noflat_st.visits;
     else if (k == "noflat_cycles") *value = c->noflat_st.cycles;

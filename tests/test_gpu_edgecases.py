@@ -296,3 +296,57 @@ def test_fused_apply_and_proof_on_widths_that_are_multiples_of_256(alg, shape, b
         assert pipe.get_int("fill_algorithm") in (0, 1)       # (4 = the proof failed and the surface was repaired: never here)
     assert np.array_equal(got, want, equal_nan=True)
     assert np.array_equal(dep, oracle.depths(want, dem), equal_nan=True)
+
+
+def test_pour_points_out_of_the_accumulation_pass_and_the_cases_that_take_the_general_pass():
+    """ACCUM + WATERSHED + POURPOINTS in one request: the watersheds' tile pass lists the candidate cells, the accumulation's final
+    pass turns them into keys (common.hpp: PourLink).  Labels that are no connected components (the candidate test compares
+    labels), a flow cycle (unresolved cells: the general pass), more than 512 labelled candidates in a tile (overflow: the
+    general pass) -- the records are label_max_index(accumulated_flow) of the oracle every time, record 0 included."""
+    from malstroem_amd.pipeline import HydroPipeline
+    from malstroem_amd.algorithms.flow import set_edges_flow_outward
+    from _cases import zigzag_flowdir
+
+    def run(fd, labels):
+        with HydroPipeline(fd.shape) as p:
+            p.upload("flowdir", fd)
+            p.upload("labels", labels)
+            for _ in range(2):
+                p.run("accum", "watershed", "pourpoints")
+            p.sync()
+            return p.download("accum"), p.download("watersheds"), p.pourpoints(), p.get_int("pour_algorithm")
+
+    def check(fd, labels, from_keys):
+        n = int(labels.max())
+        acc, ws, pour, alg = run(fd, labels)
+        assert alg == from_keys
+        oacc = oracle.accumulated_flow(fd)
+        ows = labels.copy()
+        oracle.watersheds_from_labels(fd, ows)
+        assert np.array_equal(acc, oacc) and np.array_equal(ws, ows)
+        opour = oracle.label_max_index(oacc, labels, n)
+        for f in opour.dtype.names:
+            assert np.array_equal(pour[f], opour[f]), f
+
+    rng = np.random.default_rng(5)
+    h, w = 300, 520
+    dem = fbm(h, w, seed=11)
+    s, d = oracle.minimum_safe_short_and_diag(dem)
+    fd = oracle.terrain_flowdirection(oracle.fill_terrain_no_flats(dem, s, d))
+    # (a) rectangles of labels: neighbours with different labels, one label in several places, unlabelled gaps
+    labels = np.zeros((h, w), np.int32)
+    for k in range(400):
+        r, c = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
+        labels[r:r + int(rng.integers(1, 9)), c:c + int(rng.integers(1, 9))] = int(rng.integers(1, 120))
+    check(fd, labels, 1)
+    # (b) every cell flows to the right, two cells in the middle flow into each other: everything upstream of them is unresolved
+    fdz = zigzag_flowdir(h, w, 3)
+    set_edges_flow_outward(fdz)
+    fdz[150, 200], fdz[150, 201] = 2, 6
+    cyc = labels.copy()
+    cyc[150, 200:202] = 121         # a label that is the cycle alone: no candidate cell, its record is (0, first cell)
+    check(fdz, cyc, 0)
+    # (c) a label of its own for every cell of a block: every one of them is a candidate
+    many = np.zeros((h, w), np.int32)
+    many[64:128, 64:128] = 1 + np.arange(64 * 64, dtype=np.int32).reshape(64, 64)
+    check(fd, many, 0)

@@ -2011,6 +2011,10 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "pour_algorithm") *value = c->pour_algorithm;   // 0 a pass over values + labels (label_ops.hip), 1 keys out of the accumulation's final pass (PourLink)
     else if (k == "noflat_algorithm") *value = c->noflat_st.algorithm;   // 0 float64 relaxation (fill.hip), 2 integer geodesic transform (noflat_geo.hip)
     else if (k == "noflat_visits") *value = c->noflat_st.visits;
+    else if (k == "noflat_reject") *value = c->noflat_st.geo_reject;            // diagnostics: FillStats::geo_reject and its counts
+    else if (k == "noflat_reject_irregular") *value = c->noflat_st.geo_irregular;
+    else if (k == "noflat_reject_unreached") *value = c->noflat_st.geo_unreached;
+    else if (k == "noflat_reject_mismatch") *value = c->noflat_st.geo_mismatch;
     else if (k == "noflat_cycles") *value = c->noflat_st.cycles;
     else if (k == "H") *value = c->H;
     else if (k == "W") *value = c->W;

@@ -161,6 +161,10 @@ struct FillStats {
     // the priority-flood reads every DEM cell anyway: smallest / largest elevation of the local raster and "holds a NaN" ride along
     bool have_minmax = false, dem_nan = false;
     float dem_min = 0.0f, dem_max = 0.0f;
+    // why the integer geodesic transform handed a raster back to the float64 relaxation (diagnostics: ctx_get_int "noflat_reject*"):
+    // 0 it did not, 1 not applicable (irregular levels / NaN cells / epsilons without weights), 2 its final check failed
+    int32_t geo_reject = 0;
+    int64_t geo_irregular = 0, geo_unreached = 0, geo_mismatch = 0;
 };
 
 // fill.hip

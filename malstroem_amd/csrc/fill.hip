@@ -1133,10 +1133,16 @@ int fill_noflat_dev(const float *d_dem, double *d_out, int64_t H, int64_t W, dou
             return MHIP_OK;
         }
     }
+    FillStats st_geo = st ? *st : FillStats();      // (why the transform handed the raster back: diagnostics)
     FillRun f;
     f.noflat = true; f.dem = d_dem; f.out = d_out; f.H = H; f.W = W; f.sh = sh; f.dg = dg;
     noflat_seed(f, d_filled, sh, dg, H * W);
-    return fill_run_to_convergence(f, s, st);
+    const int rc_f = fill_run_to_convergence(f, s, st);
+    if (st) {
+        st->geo_reject = st_geo.geo_reject ? st_geo.geo_reject : (rc == MHIP_OK ? 2 : 1);
+        st->geo_irregular = st_geo.geo_irregular; st->geo_unreached = st_geo.geo_unreached; st->geo_mismatch = st_geo.geo_mismatch;
+    }
+    return rc_f;
 }
 
 }  // namespace mh

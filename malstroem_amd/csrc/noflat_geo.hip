@@ -1100,6 +1100,9 @@ int GeoRun::end(hipStream_t s, bool *ok, FillStats *st)
     if (allow_partial && h_all[C_UNREACHED]) partial = true;      // (the verification above then reported those cells: ignored)
     if (st) {
         *st = FillStats();
+        st->geo_irregular = (int64_t)m.irregular;
+        st->geo_unreached = (int64_t)h_all[C_UNREACHED];
+        st->geo_mismatch = (int64_t)h_all[C_MISMATCH];
         st->rounds = m.used;
         st->tiles = m.nt;
         st->algorithm = partial ? 3 : 2;
@@ -1171,11 +1174,15 @@ int fill_noflat_geodesic_dev(const float *d_dem, const float *d_filled, double *
     g.seed_add = seed_add;
     bool applicable = false, active = false, ok = false;
     MH_TRY(g.begin(s, &applicable, &active));
-    if (!applicable) return MHIP_ELIMIT;
+    if (!applicable) {
+        if (st) st->geo_reject = 1;
+        return MHIP_ELIMIT;
+    }
     while (active) MH_TRY(g.batch(s, &active));
     MH_TRY(g.end(s, &ok, st));
     if (partial) *partial = g.partial;
     if (d8) d8->done = g.d8_done;
+    if (!ok && st) st->geo_reject = 2;
     return ok ? MHIP_OK : MHIP_ELIMIT;
 }
 

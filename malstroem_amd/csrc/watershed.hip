@@ -484,7 +484,11 @@ int watersheds_dev(const uint8_t *d_fd, int32_t *d_labels, int64_t H, int64_t W,
         set_error("watersheds on a row band need every flow path to leave the raster (interior NODIR cell found)");
         return MHIP_EINVAL;
     }
-    if (interior_nodir) {
+    // The fast path takes "the first labelled cell downstream" without asking whether that cell's own path meets an edge cell: true
+    // when every path leaves the raster, i.e. no interior NODIR cell AND no flow cycle.  Directions the library computed itself
+    // (d_known_interior_nodir: D8 descends strictly, edges flow outward) have no cycles; a raster of unknown origin may (a labelled
+    // cell on a cycle labels nothing in the reference): it takes the general path.  (Row bands always bring their own D8.)
+    if (interior_nodir || (!d_known_interior_nodir && !band_mode)) {
         MH_TRY(Q.alloc(4 * (size_t)n));
         q = Q.as<uint32_t>();
     }

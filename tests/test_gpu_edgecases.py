@@ -307,18 +307,22 @@ def test_pour_points_out_of_the_accumulation_pass_and_the_cases_that_take_the_ge
     from malstroem_amd.algorithms.flow import set_edges_flow_outward
     from _cases import zigzag_flowdir
 
-    def run(fd, labels):
-        with HydroPipeline(fd.shape) as p:
-            p.upload("flowdir", fd)
+    def run(fd, labels, dem=None):
+        with HydroPipeline(labels.shape) as p:
+            if dem is not None:      # directions the library computed itself: no flow cycle, the watersheds' fast path
+                p.upload("dem", dem)
+                p.run("fill", "noflat", "flowdir")
+            else:                    # of unknown origin: the general path (a labelled cell on a cycle labels nothing)
+                p.upload("flowdir", fd)
             p.upload("labels", labels)
             for _ in range(2):
                 p.run("accum", "watershed", "pourpoints")
             p.sync()
             return p.download("accum"), p.download("watersheds"), p.pourpoints(), p.get_int("pour_algorithm")
 
-    def check(fd, labels, from_keys):
+    def check(fd, labels, from_keys, dem=None):
         n = int(labels.max())
-        acc, ws, pour, alg = run(fd, labels)
+        acc, ws, pour, alg = run(fd, labels, dem)
         assert alg == from_keys
         oacc = oracle.accumulated_flow(fd)
         ows = labels.copy()
@@ -338,7 +342,8 @@ def test_pour_points_out_of_the_accumulation_pass_and_the_cases_that_take_the_ge
     for k in range(400):
         r, c = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
         labels[r:r + int(rng.integers(1, 9)), c:c + int(rng.integers(1, 9))] = int(rng.integers(1, 120))
-    check(fd, labels, 1)
+    check(fd, labels, 1, dem)
+    check(fd, labels, 0)
     # (b) every cell flows to the right, two cells in the middle flow into each other: everything upstream of them is unresolved
     fdz = zigzag_flowdir(h, w, 3)
     set_edges_flow_outward(fdz)
@@ -349,4 +354,4 @@ def test_pour_points_out_of_the_accumulation_pass_and_the_cases_that_take_the_ge
     # (c) a label of its own for every cell of a block: every one of them is a candidate
     many = np.zeros((h, w), np.int32)
     many[64:128, 64:128] = 1 + np.arange(64 * 64, dtype=np.int32).reshape(64, 64)
-    check(fd, many, 0)
+    check(fd, many, 0, dem)

@@ -462,7 +462,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         }
         // the raster border cells inside this window are sources: their distance 0 is read by every later visit (and by
         // ng_assemble), so somebody has to write it
-        if (ti == 0 || tj == 0 || last_row < WN - 1 || c0 + WN - 1 >= W - 1) {
+        if (ti == 0 || tj == 0 || H - 1 - r0 <= WN - 1 || c0 + WN - 1 >= W - 1) {   // (<=: the raster's last row may be the window's last row)
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
                 const bool brow = (ti == 0 && r == 0 && !a.fixed_top) | (r == last_row && last_row == (int)(H - 1 - r0) && !a.fixed_bot);

@@ -114,13 +114,13 @@ class DemSource(object):
         return out
 
 
-KERNEL_OF_STAGE = {"fill": "pf_tile_kernel", "noflat": "ng_round_kernel", "flowdir": "d8s_kernel", "accum": "accum_tile_kernel<false/true> + perimeter graph", "label": "depths + ccl_* + stats_kernel",
-                   "watershed": "ws_* + count_kernel", "pourpoints": "arg_packed_kernel"}
+KERNEL_OF_STAGE = {"fill": "pf_tile_kernel", "noflat": "ng_round_kernel", "flowdir": "d8s_kernel", "accum": "accum_tile_kernel + perimeter graph + accum_final_walk_kernel", "label": "depths + ccl_* + stats_kernel",
+                   "watershed": "ws_* + count_kernel", "pourpoints": "pour_finish_kernel (keys out of accum_final_walk_kernel; arg_packed_kernel for the general pass)"}
 # FETCH_SIZE reports half of the bytes of a coalesced streaming read on gfx950 whatever the load width (calibrated per run on kernels
 # with known reads: tools/pmc_traffic.py); the committed table carries the corrected figure (`fetch_bytes_per_cell`)
 STAGE_KERNELS = {"flowdir": ("d8_kernel", "d8s_kernel"), "fill": ("fill_round_kernel<float", "pf_"), "noflat": ("fill_round_kernel<double", "noflat_", "ng_"),
                  "accum": ("accum_",), "label": ("ccl_", "stats_", "depths_kernel"), "watershed": ("ws_", "count_kernel"),
-                 "pourpoints": ("arg_",)}
+                 "pourpoints": ("arg_", "pour_")}
 
 
 def pmc_traffic(stage, n):

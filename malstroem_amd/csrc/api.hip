@@ -1735,14 +1735,13 @@ static int stage_pourpoints(mhip_ctx *c, hipStream_t s, PourLink *pour = nullptr
     if (pour && pour->consumed && c->have[MHIP_R_ACCUM]) {
         // the accumulation's final pass has left one key per label (common.hpp: PourLink) -- unless the candidate list overflowed
         // or a cell stayed unresolved (a flow cycle): then the general pass below
+        // (the records are queued before the flags are known: one host round trip instead of two at the end of a request)
         uint32_t h[3] = {0, 1, 1};
         MH_HIP(hipMemcpyAsync(h, c->pp_misc.p, 12, hipMemcpyDeviceToHost, s));
+        MH_TRY(pour_finish_dev(c->pp_key.as<unsigned long long>(), c->pp_tiles.as<unsigned long long>(), cdiv(H, 64) * cdiv(W, 64), c->nlabels, W,
+                               c->pour.as<mhip_index_record>(), s));
         MH_HIP(stream_sync(s));
-        if (!h[1] && !h[2]) {
-            MH_TRY(pour_finish_dev(c->pp_key.as<unsigned long long>(), c->pp_tiles.as<unsigned long long>(), cdiv(H, 64) * cdiv(W, 64), c->nlabels, W,
-                                   c->pour.as<mhip_index_record>(), s));
-            from_keys = true;
-        }
+        from_keys = !h[1] && !h[2];
     }
     c->pour_algorithm = from_keys ? 1 : 0;
     if (from_keys) {

@@ -14,6 +14,8 @@
 // "an edge cell lies on my downstream path" so that labelled terminals without an edge cell are ignored.
 // Flow cycles (on which the reference does not terminate when they contain an edge cell) never resolve and
 // keep `unassigned`; the number of rounds is capped at 40 (> log2 of any int32-indexable path).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace mh {
@@ -403,7 +405,7 @@ namespace {
 __global__ __launch_bounds__(1024) void pour_key0_kernel(const unsigned long long *__restrict__ tile_key0, int64_t ntiles, unsigned long long *key)
 {
     unsigned long long best = 0;
-    for (int64_t t = threadIdx.x; t < ntiles; t += 1024) best = tile_key0[t] > best ? tile_key0[t] : best;
+    for (int64_t t = (int64_t)blockIdx.x * 1024 + threadIdx.x; t < ntiles; t += (int64_t)gridDim.x * 1024) best = tile_key0[t] > best ? tile_key0[t] : best;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long ob = __shfl_xor(best, o);
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) void pour_finish_kernel(const unsigned long lo
 int pour_finish_dev(unsigned long long *d_key, const unsigned long long *d_tile_key0, int64_t ntiles, int64_t nlab, int64_t W, mhip_index_record *d_rec,
                     hipStream_t s)
 {
-    hipLaunchKernelGGL(pour_key0_kernel, dim3(1), dim3(1024), 0, s, d_tile_key0, ntiles, d_key);
+    hipLaunchKernelGGL(pour_key0_kernel, dim3((unsigned)std::min<int64_t>(cdiv(ntiles, 1024), 64)), dim3(1024), 0, s, d_tile_key0, ntiles, d_key);
     hipLaunchKernelGGL(pour_finish_kernel, dim3((unsigned)cdiv(nlab + 1, 256)), dim3(256), 0, s, d_key, nlab + 1, W, d_rec);
     MH_HIP(hipGetLastError());
     return MHIP_OK;

@@ -512,6 +512,10 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
         for (uint32_t i = tid; i < cnt; i += ATN) {
             const uint2 e = pc.list[off + i];
             const uint32_t gr = e.x / (uint32_t)W, gc = e.x - gr * (uint32_t)W;
+            if (e.y > pc.nlab) {
+                bad = true;
+                continue;
+            }
             atomicMax(&pc.key[e.y], key_of((int)(gr - (uint32_t)r0), (int)(gc - (uint32_t)c0), &bad));
         }
         if (bad) pc.flags[1] = 1u;

@@ -1695,6 +1695,7 @@ static int pour_link_buffers(mhip_ctx *c, PourLink *pl, hipStream_t s)
     pl->dev.flags = c->pp_misc.as<uint32_t>() + 1;
     pl->dev.components = c->labels_components ? 1 : 0;
     pl->dev.key = c->pp_key.as<unsigned long long>();
+    pl->dev.nlab = (uint32_t)c->nlabels;
     pl->ev = c->ev_cand;
     return MHIP_OK;
 }

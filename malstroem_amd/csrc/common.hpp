@@ -319,6 +319,7 @@ struct PourCandDev {             // device side, tile = 64 x 64 cells as in accu
     uint32_t *flags = nullptr;   // [0] a tile's list overflowed, [1] an unresolved cell
     int components = 0;          // the labels are 8-connected components: two neighbouring labelled cells share their label
     unsigned long long *key = nullptr;   // [nlabels + 1], zeroed
+    uint32_t nlab = 0;           // a candidate with a label outside [0, nlab] (uploaded labels) raises flags[1]: the general pass reports it
 };
 constexpr uint32_t POUR_TILE_CAP = 512;
 struct PourLink {                // host side: hand-over between the thread of the watersheds and the thread of the accumulation

@@ -111,7 +111,7 @@ template <bool FINAL, bool WIDE, bool STOREL = false>
 #ifdef ACC_WAVES
 __attribute__((amdgpu_waves_per_eu(ACC_WAVES, ACC_WAVES)))
 #endif
-__global__ __launch_bounds__(ATN) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
+__global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H,
                                                         int64_t W, int ntc, Nodes nd, int fixed_top, int fixed_bot, int halo_zero)
 {
     using sum_t = typename std::conditional<WIDE, unsigned long long, uint32_t>::type;

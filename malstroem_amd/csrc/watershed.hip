@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
             lb[k] = in ? lab[r * W + cbase + k] : unassigned;
         }
     }
+    uint32_t lmask = 0;      // my labelled cells
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int li = lr * WT + lc0 + k;
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
         int32_t v = NONE;
         if (r < H && c < W) {
             if (lb[k] != unassigned) {
+                lmask |= 1u << k;
                 v = (int32_t)(r * W + c);               // labelled: a fixed point
             } else if (code[k] <= 7u) {
                 const int64_t nr = r + dir_dr((int)code[k]), nc = c + dir_dc((int)code[k]);
@@ -189,28 +191,40 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
     }
     __syncthreads();
     if (pc.mask0) {
+        // (labels and directions are NOT kept in registers across the barrier above -- 32 registers that cost the kernel a third of
+        // its resident workgroups: the directions are read again, 16 bytes the tile has just pulled through the cache; "labelled"
+        // is a bit per cell; a label's value is only needed for the few candidates)
+        uint32_t cw[4] = {0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+        if (vec) {
+            const uint4 cv = *reinterpret_cast<const uint4 *>(fd + r * W + cbase);
+            cw[0] = cv.x; cw[1] = cv.y; cw[2] = cv.z; cw[3] = cv.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (r < H && cbase + k < W) cw[k >> 2] = (cw[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((uint32_t)fd[r * W + cbase + k] << (8 * (k & 3)));
+        }
+        const uint32_t Wu = (uint32_t)W, Hu = (uint32_t)H, r0u = (uint32_t)r0, c0u = (uint32_t)c0;
         uint32_t m0 = 0, ml = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int64_t c = cbase + k;
-            if (!(r < H && c < W)) continue;
-            const int32_t l = lb[k];
+            if (!(r < H && cbase + k < W)) continue;
+            const unsigned cd = (cw[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const bool mylab = (lmask >> k) & 1u;
             bool same = false;         // the downstream cell carries my label (unlabelled: it is unlabelled as well)
-            if (code[k] <= 7u) {
-                const int64_t nr = r + dir_dr((int)code[k]), nc = c + dir_dc((int)code[k]);
-                if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
-                    const int64_t lr2 = nr - r0, lc2 = nc - c0, gd = nr * W + nc;
-                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) {
-                        const bool labelled_d = val[lr2 * WT + lc2] == (int32_t)gd;
-                        if (pc.components) same = labelled_d == (l != unassigned);
-                        else same = (labelled_d ? lab[gd] : unassigned) == l;
-                    } else {
-                        same = lab[gd] == l;
-                    }
+            if (cd <= 7u) {
+                const int lr2 = lr + dir_dr((int)cd), lc2 = lc0 + k + dir_dc((int)cd);
+                const uint32_t nr = r0u + (uint32_t)lr2, nc = c0u + (uint32_t)lc2;      // (wraps to a huge value left of / above the raster)
+                if (nr < Hu && nc < Wu) {
+                    const uint32_t gd = nr * Wu + nc;
+                    bool labelled_d;
+                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) labelled_d = val[lr2 * WT + lc2] == (int32_t)gd;
+                    else labelled_d = lab[gd] != unassigned;
+                    if (pc.components) same = labelled_d == mylab;
+                    else same = (labelled_d ? lab[gd] : unassigned) == (mylab ? lab[(uint32_t)(r * W + cbase + k)] : unassigned);
                 }
             }
             if (!same) {
-                if (l == unassigned) m0 |= 1u << k;
+                if (!mylab) m0 |= 1u << k;
                 else ml |= 1u << k;
             }
         }
@@ -240,7 +254,10 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
             for (int w = 0; w < wave; ++w) o += wsum[w];
 #pragma unroll
             for (int k = 0; k < 16; ++k)
-                if ((ml >> k) & 1u) pc.list[o++] = make_uint2((uint32_t)(r * W + cbase + k), (uint32_t)lb[k]);
+                if ((ml >> k) & 1u) {
+                    const uint32_t cell = (uint32_t)(r * W + cbase + k);
+                    pc.list[o++] = make_uint2(cell, (uint32_t)lab[cell]);
+                }
         }
     }
     for (int round = 0; round < 13; ++round) {

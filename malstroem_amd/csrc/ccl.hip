@@ -132,6 +132,14 @@ __device__ __forceinline__ void unite_l(uint32_t *par, uint32_t a, uint32_t b)
     }
 }
 
+// (the union and the flatten phase four rows at a time, not sixteen: 19 instead of 94 VGPRs -- eight workgroups per CU instead of five;
+// all of the kernel's phases wait on LDS round trips, residency is what pays)
+#ifndef CCL_U2
+#define CCL_U2 4
+#endif
+#ifndef CCL_U3
+#define CCL_U3 4
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t H, int64_t W, int ntc,
                                                        int32_t *__restrict__ rootlist, int32_t *__restrict__ rootcount)
@@ -143,24 +151,24 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ dat
     const int ti = blockIdx.x / ntc, tj = blockIdx.x - ti * ntc;
     const int64_t r0 = (int64_t)ti * CT, c0 = (int64_t)tj * CT;
     const int64_t cc = c0 + lane;
-    uint64_t fgrow[CT / 4];   // foreground masks of my rows (wave-uniform)
+    // (the foreground masks of the rows are not kept for the union phase -- sixteen 64-bit values per wavefront that held the kernel
+    // at 94 VGPRs: a row's mask is a ballot over its parents, which are LBG exactly on the background)
 #pragma unroll
     for (int k = 0; k < CT / 4; ++k) {
         const int r = wave + 4 * k;
         const bool fg = (r0 + r) < H && cc < W && is_fg(data[(r0 + r) * W + cc]);
         const uint64_t m = __ballot(fg);
-        fgrow[k] = m;
         // first lane of my run: the highest run start at or below my lane
         const uint64_t starts = m & ~(m << 1);
         const uint64_t below = starts & ((2ull << lane) - 1ull);
         par[r * CT + lane] = fg ? (uint32_t)(r * CT + (63 - __builtin_clzll(below))) : LBG;
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll CCL_U2
     for (int k = 0; k < CT / 4; ++k) {
         const int r = wave + 4 * k;
         if (r == 0) continue;
-        const uint64_t m = fgrow[k];
+        const uint64_t m = __ballot(par[r * CT + lane] != LBG);
         const uint32_t pn = par[(r - 1) * CT + lane];
         const uint64_t up = __ballot(pn != LBG);
         if (!((m >> lane) & 1ull)) continue;
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ dat
         }
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll CCL_U3
     for (int k = 0; k < CT / 4; ++k) {
         const int r = wave + 4 * k;
         if ((r0 + r) >= H || cc >= W) continue;

@@ -120,7 +120,10 @@ template <int TS> __device__ __forceinline__ int table_slot(int *keys, int key)
 // COMPONENTS: the caller vouches that the labels are the 8-connected components of a raster this one is a row range of.  A label
 // none of whose cells in the tile lies on the tile's outline (or on the raster's last row) then lives in this tile alone and
 // its record is WRITTEN instead of merged by a load and up to four atomics.
-constexpr int STATS_TS = 1024;
+#ifndef MH_STATS_TS
+#define MH_STATS_TS 512
+#endif
+constexpr int STATS_TS = MH_STATS_TS;      // (512 slots = 12 KB: the table does not limit the resident workgroups; a tile that holds more labels goes to the global atomics)
 // EMIT: the labels do not exist yet -- the kernel is the last pass of the connected-component labelling (ccl.hip) as well: it
 // turns parent[] (cell -> root of its tile piece -> root of its component) into ranks, WRITES the label raster and reduces on
 // the way, which saves the labelling's own emit pass the statistics would read back (4 + 4 B per cell and a launch).

@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
                                                      int64_t W, int ntc, int32_t unassigned, PourCandDev pc, int32_t *__restrict__ Pn)
 {
     __shared__ uint16_t ptr[WT * WT];
-    __shared__ int32_t val[WT * WT];     // of a terminal: its own index (labelled), NONE, or the entry cell its path continues at
+    // of a terminal, one byte (the global index it stands for is put together when it is needed: 12 instead of 24 KB of LDS, the
+    // table no longer limits the resident workgroups): V_LAB labelled (its own index), V_NONE the path ends unlabelled, else the
+    // direction 0..7 in which the path leaves the tile -- the entry cell is that neighbour
+    __shared__ uint8_t val[WT * WT];
+    constexpr uint8_t V_LAB = 8, V_NONE = 9;
     const int ti = blockIdx.x / ntc, tj = blockIdx.x - ti * ntc;
     const int64_t r0 = (int64_t)ti * WT, c0 = (int64_t)tj * WT;
     // global I/O: a thread owns 16 consecutive cells of a tile row (one 16-byte load of the directions, four of the labels, four
@@ -172,17 +176,17 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
         const int li = lr * WT + lc0 + k;
         const int64_t c = cbase + k;
         uint16_t p = (uint16_t)li;
-        int32_t v = NONE;
+        uint8_t v = V_NONE;
         if (r < H && c < W) {
             if (lb[k] != unassigned) {
                 lmask |= 1u << k;
-                v = (int32_t)(r * W + c);               // labelled: a fixed point
+                v = V_LAB;                              // labelled: a fixed point
             } else if (code[k] <= 7u) {
                 const int64_t nr = r + dir_dr((int)code[k]), nc = c + dir_dc((int)code[k]);
                 if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
                     const int64_t lr2 = nr - r0, lc2 = nc - c0;
                     if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) p = (uint16_t)(lr2 * WT + lc2);
-                    else v = (int32_t)(nr * W + nc);    // leaves the tile: the path continues at that entry cell
+                    else v = code[k];                   // leaves the tile: the path continues at that entry cell
                 }
             }
         }
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
                 if (nr < Hu && nc < Wu) {
                     const uint32_t gd = nr * Wu + nc;
                     bool labelled_d;
-                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) labelled_d = val[lr2 * WT + lc2] == (int32_t)gd;
+                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) labelled_d = val[lr2 * WT + lc2] == V_LAB;
                     else labelled_d = lab[gd] != unassigned;
                     if (pc.components) same = labelled_d == mylab;
                     else same = (labelled_d ? lab[gd] : unassigned) == (mylab ? lab[(uint32_t)(r * W + cbase + k)] : unassigned);
@@ -281,8 +285,11 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
         const int64_t gt = (r0 + (t >> 6)) * W + c0 + (t & 63);
         if (ptr[t] != t) out[k] = (int32_t)gt;              // a flow cycle inside the tile: never resolves
         else {
-            const int32_t v = val[t];
-            out[k] = (v == (int32_t)gt && t != li) ? (v | DONE) : v;   // v: own index (a labelled cell keeps P == self), NONE, or an entry cell
+            const unsigned vb = val[t];
+            int32_t v = NONE;
+            if (vb == V_LAB) v = (int32_t)gt;
+            else if (vb <= 7u) v = (int32_t)((r0 + (t >> 6) + dir_dr((int)vb)) * W + c0 + (t & 63) + dir_dc((int)vb));
+            out[k] = (vb == V_LAB && t != li) ? (v | DONE) : v;   // v: own index (a labelled cell keeps P == self), NONE, or an entry cell
         }
         const int slot = ws_perim_slot(lr, lc0 + k);
         if (slot >= 0) Pn[(int64_t)blockIdx.x * 256 + slot] = (r < H && cbase + k < W) ? out[k] : NONE;

@@ -99,3 +99,34 @@ _Zinside:
     p.write_text(asm)
     res = lint_exec_spills.lint(str(p))
     assert [r[0] for r in res] == ["_Zbad"]
+
+
+def _residency(asm_text):
+    """kernel name -> (VGPRs, LDS bytes, threads, resident workgroups per CU) from the code object's metadata (MI355X: 512 VGPRs per
+    SIMD lane in granules of 8, 160 KB of LDS, at most 8 wavefronts per SIMD)"""
+    import re
+    out = {}
+    pat = (r"\.group_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.max_flat_workgroup_size:\s+(\d+)\n\s+\.name:\s+(\S+)\n(?:.*\n)*?"
+           r"\s+\.vgpr_count:\s+(\d+)")
+    for m in re.finditer(pat, asm_text):
+        lds, wg, name, vg = int(m.group(1)), int(m.group(2)), m.group(3), int(m.group(4))
+        waves = wg // 64
+        by_v = min(8, 512 // max(8, (vg + 7) // 8 * 8)) * 4 // waves
+        by_l = (160 * 1024) // lds if lds else 99
+        out[name] = (vg, lds, wg, min(by_v, by_l, 32 // waves))
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_tile_kernels_keep_their_resident_workgroups(tmp_path):
+    """The tile kernels of the tail wait on LDS round trips and barriers: workgroups per CU is what their speed hangs on, and a few
+    registers or kilobytes too many cost a quarter of it without a test failing (end of round 3: the labelling's tile union-find ran
+    5 of 8 workgroups, the statistics 6, the watersheds' tile pass 4 after the pour-point candidates were added)."""
+    want = {"ccl.hip": {"ccl_tile_kernelIf": 8}, "label_ops.hip": {"stats_kernelILb1ELb1E": 8}, "watershed.hip": {"ws_tile_kernel": 8},
+            "accum.hip": {"accum_tile_kernelILb0ELb0ELb1E": 4, "accum_final_walk_kernel": 6}}
+    for fn, kernels in want.items():
+        res = _residency(_isa(CSRC / fn, tmp_path / (fn + ".s")).read_text())
+        for frag, n in kernels.items():
+            hit = [v for k, v in res.items() if frag in k]
+            assert hit, (fn, frag, sorted(res)[:5])
+            assert all(v[3] >= n for v in hit), (fn, frag, hit)

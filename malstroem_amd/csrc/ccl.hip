@@ -142,7 +142,7 @@ __device__ __forceinline__ void unite_l(uint32_t *par, uint32_t a, uint32_t b)
 #endif
 template <typename T>
 __global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ data, int32_t *__restrict__ parent, int64_t H, int64_t W, int ntc,
-                                                       int32_t *__restrict__ rootlist, int32_t *__restrict__ rootcount)
+                                                       int32_t *__restrict__ rootlist, int32_t *__restrict__ rootcount, int32_t *__restrict__ colpar)
 {
     __shared__ uint32_t par[CT * CT];
     __shared__ int s_nroots;
@@ -186,9 +186,20 @@ __global__ __launch_bounds__(256) void ccl_tile_kernel(const T *__restrict__ dat
 #pragma unroll CCL_U3
     for (int k = 0; k < CT / 4; ++k) {
         const int r = wave + 4 * k;
-        if ((r0 + r) >= H || cc >= W) continue;
-        const uint32_t p = par[r * CT + lane];
+        const bool inside = (r0 + r) < H && cc < W;
+        const uint32_t p = inside ? par[r * CT + lane] : LBG;
         int32_t out = -1;
+        // the tile's first and last column also go to a compact array (512 B per tile): the unions across the VERTICAL seams
+        // read their operands there, 64 rows per 256-byte line, instead of a sector per cell in the raster
+        if (lane == 0 || lane == CT - 1) {
+            int32_t e = -1;
+            if (p != LBG) {
+                const uint32_t rt = find_root_l(par, p);
+                e = (int32_t)((r0 + (rt >> 6)) * W + c0 + (rt & 63u));
+            }
+            colpar[((int64_t)blockIdx.x * 2 + (lane ? 1 : 0)) * CT + r] = e;
+        }
+        if (!inside) continue;
         if (p != LBG) {
             const uint32_t root = find_root_l(par, p);
             out = (int32_t)((r0 + (root >> 6)) * W + c0 + (root & 63u));
@@ -285,7 +296,8 @@ __global__ __launch_bounds__(256) void ccl_emit_ranked_kernel(const int32_t *__r
 // unions across the tile seams.  Horizontal seams (rows that start a tile): the rule of ccl_merge_kernel for N / NW / NE.
 // Vertical seams (columns that start a tile): W; NW and SW only when W is background (else W is united with them -- inside
 // its tile, or by the horizontal-seam rule of its own row).
-__global__ __launch_bounds__(256) void ccl_seam_kernel(int32_t *parent, int64_t H, int64_t W, int64_t nh, int64_t total)
+__global__ __launch_bounds__(256) void ccl_seam_kernel(int32_t *parent, int64_t H, int64_t W, int64_t nh, int64_t total, const int32_t *__restrict__ colpar,
+                                                       int64_t ntc)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= total) return;
@@ -301,17 +313,26 @@ __global__ __launch_bounds__(256) void ccl_seam_kernel(int32_t *parent, int64_t 
         const bool hasNE = c + 1 < W && parent[i - W + 1] >= 0;
         if (hasNW && !hasW) unite(parent, (int32_t)i, (int32_t)(i - W - 1));
         if (hasNE) unite(parent, (int32_t)i, (int32_t)(i - W + 1));
-    } else {                                        // cell (r, c) of a seam column c = 64, 128, ...
+    } else {                                        // row r of the seam between tile columns sj and sj + 1: the cell right of it
         const int64_t q = k - nh;
-        const int64_t r = q % H, c = (q / H + 1) * CT;
-        const int64_t i = r * W + c;
-        if (parent[i] < 0) return;
-        if (parent[i - 1] >= 0) {
-            unite(parent, (int32_t)i, (int32_t)(i - 1));
+        const int64_t r = q % H, sj = q / H;
+        const int64_t ti = r / CT, lr = r - ti * CT;
+        const int32_t *left = colpar + ((ti * ntc + sj) * 2 + 1) * CT, *right = colpar + ((ti * ntc + sj + 1) * 2 + 0) * CT;
+        const int32_t me = right[lr];               // (the tile-local root of the cell: where a find would start anyway)
+        if (me < 0) return;
+        const int32_t w = left[lr];
+        if (w >= 0) {
+            unite(parent, me, w);
             return;
         }
-        if (r > 0 && parent[i - W - 1] >= 0) unite(parent, (int32_t)i, (int32_t)(i - W - 1));
-        if (r + 1 < H && parent[i + W - 1] >= 0) unite(parent, (int32_t)i, (int32_t)(i + W - 1));
+        if (r > 0) {
+            const int32_t nw = lr > 0 ? left[lr - 1] : colpar[(((ti - 1) * ntc + sj) * 2 + 1) * CT + CT - 1];
+            if (nw >= 0) unite(parent, me, nw);
+        }
+        if (r + 1 < H) {
+            const int32_t sw = lr < CT - 1 ? left[lr + 1] : colpar[(((ti + 1) * ntc + sj) * 2 + 1) * CT];
+            if (sw >= 0) unite(parent, me, sw);
+        }
     }
 }
 
@@ -445,7 +466,8 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
         // everything in between works on the tile roots and on one bit per cell
         const int64_t ntr = cdiv(H, CT), ntc = cdiv(W, CT), ntiles = ntr * ntc;
         const int64_t nwords = cdiv(n, 64), nwb = cdiv(nwords, WB);
-        DevBuf roots, rcount, bits, wprefix, bcounts;
+        DevBuf roots, rcount, bits, wprefix, bcounts, colpar;
+        MH_TRY(colpar.alloc(4 * 2 * CT * (size_t)ntiles));
         MH_TRY(roots.alloc(4 * (size_t)ntiles * MAXROOTS));
         MH_TRY(rcount.alloc(4 * (size_t)ntiles));
         MH_TRY(bits.alloc(8 * (size_t)nwords));
@@ -453,10 +475,10 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
         MH_TRY(bcounts.alloc(4 * (size_t)nwb));
         MH_HIP(hipMemsetAsync(bits.p, 0, 8 * (size_t)nwords, s));
         hipLaunchKernelGGL((ccl_tile_kernel<T>), dim3((unsigned)ntiles), dim3(256), 0, s, d_data, parent, H, W, (int)ntc, roots.as<int32_t>(),
-                           rcount.as<int32_t>());
+                           rcount.as<int32_t>(), colpar.as<int32_t>());
         const int64_t nh = (ntr - 1) * W, nv = (ntc - 1) * H;
         if (nh + nv > 0)
-            hipLaunchKernelGGL(ccl_seam_kernel, dim3((unsigned)cdiv(nh + nv, 256)), dim3(256), 0, s, parent, H, W, nh, nh + nv);
+            hipLaunchKernelGGL(ccl_seam_kernel, dim3((unsigned)cdiv(nh + nv, 256)), dim3(256), 0, s, parent, H, W, nh, nh + nv, colpar.as<int32_t>(), ntc);
         hipLaunchKernelGGL(ccl_flatten_roots_kernel, dim3((unsigned)cdiv(ntiles, 4)), dim3(256), 0, s, parent, roots.as<int32_t>(),
                            rcount.as<int32_t>(), ntiles, bits.as<unsigned long long>());
         hipLaunchKernelGGL(ccl_bits_count_kernel, dim3((unsigned)nwb), dim3(WB), 0, s, bits.as<unsigned long long>(), nwords, bcounts.as<uint32_t>());

@@ -568,11 +568,18 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
 #pragma unroll
             for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
         }
-        int so = 0;
+        // (a window that lies inside the raster -- every tile but the bottom row's -- takes its rows at fixed multiples of the pitch: the
+        // clamped row offsets below cost a dozen scalar instructions and two saved masks per row, again in front of every store)
+        if (last_row == WN - 1) {
 #pragma unroll
-        for (int r = 0; r < WN; ++r) {
-            d[r] = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), so * 4, 0);
-            so = r < last_row ? so + Wi : so;
+            for (int r = 0; r < WN; ++r) d[r] = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), r * Wi * 4, 0);
+        } else {
+            int so = 0;
+#pragma unroll
+            for (int r = 0; r < WN; ++r) {
+                d[r] = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), so * 4, 0);
+                so = r < last_row ? so + Wi : so;
+            }
         }
     }
     ++visits;
@@ -596,9 +603,14 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     if (changed) {
         const bool lane_ok = (lane >= 1) & (lane <= TI) & (cc < W - 1);
         if (lane_ok) {
+            if (last_row == WN - 1) {
 #pragma unroll
-            for (int r = 1; r <= TI; ++r)
-                if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(d[r], rd, lane * 4, r * Wi * 4, 0);   // row H - 1 is a border row
+                for (int r = 1; r <= TI; ++r) __builtin_amdgcn_raw_buffer_store_b32(d[r], rd, lane * 4, r * Wi * 4, 0);
+            } else {
+#pragma unroll
+                for (int r = 1; r <= TI; ++r)
+                    if (r < last_row) __builtin_amdgcn_raw_buffer_store_b32(d[r], rd, lane * 4, r * Wi * 4, 0);   // row H - 1 is a border row
+            }
         }
     }
     if (capped) wake |= 1u << 4;

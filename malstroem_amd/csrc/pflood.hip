@@ -179,17 +179,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         // no-flats fill: a separate pass over the DEM next to this kernel cost it 0.4 ms): keys of the cells inside the raster,
         // all ones for a NaN (np.amax / np.amin propagate it)
         uint32_t klo = 0xffffffffu, khi = 0u;
+        // (all of the strip's loads first: issued between the cells' classification -- 64-bit compares and branches -- each was waited
+        // for before the next went out, eight round trips in a row)
+        float vq[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            vq[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdem, lane_b * 4, so * 4, 0));
+            so = k + 1 < nrow_in ? so + Wi : so;
+        }
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int wr = wr0 + k;
             const uint8_t c = cell_class(g, wr * WN + wc);
             clsw |= (uint32_t)c << (4 * k);
-            const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdem, lane_b * 4, so * 4, 0));
+            const float v = vq[k];
             zk[wr * WN + wc] = c ? dem_key(v) : KINV;
             const uint32_t kv = v != v ? 0xffffffffu : f32_key(v);
             klo = c && kv < klo ? kv : klo;
             khi = c && kv > khi ? kv : khi;
-            so = k + 1 < nrow_in ? so + Wi : so;
         }
         if (a.mm) {
 #pragma unroll

@@ -138,14 +138,21 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
         arrived_l[tid] = nd.arrived[(int64_t)tile * NODE_STRIDE + tid];
     }
     const bool wide = (W % 16) == 0 && c0 + AT <= W;   // c0 is a multiple of 64: chunks are 16-byte aligned in global memory
-    for (int q = tid; q < (AT + 2) * 6; q += ATN) {
+    // (the loads of a thread's items first, then the LDS writes: one round trip instead of one per item)
+    constexpr int NWQ = ((AT + 2) * 6 + ATN - 1) / ATN;
+    uint4 wv[NWQ];
+    uint8_t wb[NWQ];
+#pragma unroll
+    for (int u = 0; u < NWQ; ++u) {
+        const int q = tid + u * ATN;
         const int wr = q / 6, k = q - wr * 6;
         const int64_t rr = r0 + wr - 1;
-        const bool row_in = rr >= 0 && rr < H;
+        const bool row_in = q < (AT + 2) * 6 && rr >= 0 && rr < H;
+        wv[u] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
+        wb[u] = 8;
         if (k < 4) {
-            uint4 v = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
             if (row_in) {
-                if (wide) v = *reinterpret_cast<const uint4 *>(fd + rr * W + c0 + 16 * k);
+                if (wide) wv[u] = *reinterpret_cast<const uint4 *>(fd + rr * W + c0 + 16 * k);
                 else {
                     uint8_t b[16];
 #pragma unroll
@@ -153,14 +160,21 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
                         const int64_t cc = c0 + 16 * k + t;
                         b[t] = cc < W ? fd[rr * W + cc] : (uint8_t)8;
                     }
-                    memcpy(&v, b, 16);
+                    memcpy(&wv[u], b, 16);
                 }
             }
-            *reinterpret_cast<uint4 *>(&win[wr * FS + WOFF + 16 * k]) = v;
         } else {
             const int64_t cc = k == 4 ? c0 - 1 : c0 + AT;
-            win[wr * FS + (k == 4 ? WOFF - 1 : WOFF + AT)] = (row_in && cc >= 0 && cc < W) ? fd[rr * W + cc] : (uint8_t)8;
+            if (row_in && cc >= 0 && cc < W) wb[u] = fd[rr * W + cc];
         }
+    }
+#pragma unroll
+    for (int u = 0; u < NWQ; ++u) {
+        const int q = tid + u * ATN;
+        if (q >= (AT + 2) * 6) continue;
+        const int wr = q / 6, k = q - wr * 6;
+        if (k < 4) *reinterpret_cast<uint4 *>(&win[wr * FS + WOFF + 16 * k]) = wv[u];
+        else win[wr * FS + (k == 4 ? WOFF - 1 : WOFF + AT)] = wb[u];
     }
     __syncthreads();
     MH_ASTAMP(0);
@@ -412,15 +426,32 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
     const bool wide = (W % 16) == 0 && c0 + AT <= W;
     // local sums and pointers: a lane takes four cells of a row (16 lanes per row: 256 B of sums, 64 B of directions), 16 rows
     // per step of the workgroup; LDS in 16- / 8-byte writes
-    for (int q = tid; q < AT * 16; q += ATN) {
-        const int r = q >> 4, c4 = (q & 15) * 4;
+    constexpr int NQ = AT * 16 / ATN;      // steps of the workgroup over the tile's 64 rows (16 lanes per row)
+    static_assert(AT * 16 % ATN == 0, "whole steps");
+    // (all loads of the tile first: a step's loads were waited for before the next step's went out -- four round trips in a row)
+    uint2 lq[NQ];
+    uint32_t fq[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int q = tid + u * ATN, r = q >> 4, c4 = (q & 15) * 4;
+        const int64_t rr = r0 + r;
+        lq[u] = make_uint2(0x80008000u, 0x80008000u);
+        fq[u] = 0x08080808u;
+        if (rr < H && wide) {
+            lq[u] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(out + rr * W + c0) + c4);
+            fq[u] = *reinterpret_cast<const uint32_t *>(fd + rr * W + c0 + c4);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+        const int q = tid + u * ATN, r = q >> 4, c4 = (q & 15) * 4;
         const int64_t rr = r0 + r;
         uint32_t l[4];
         uint8_t b[4];
         if (rr < H && wide) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(out + rr * W + c0) + c4);
+            const uint2 v = lq[u];
             l[0] = v.x & 0xffffu; l[1] = v.x >> 16; l[2] = v.y & 0xffffu; l[3] = v.y >> 16;
-            const uint32_t f = *reinterpret_cast<const uint32_t *>(fd + rr * W + c0 + c4);
+            const uint32_t f = fq[u];
             memcpy(b, &f, 4);
         } else {
 #pragma unroll

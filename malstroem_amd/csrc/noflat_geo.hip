@@ -74,9 +74,10 @@ __device__ __forceinline__ float fright(float v)
 // biased float64-exponent class of the values just ABOVE V (where the flat's values live), 255: no class
 __device__ __forceinline__ uint32_t class_above(float V)
 {
+    // (selects, no branches: the classification calls this once per row in a loop that is unrolled 64 times)
     const uint32_t b = __float_as_uint(V), ex = (b >> 23) & 0xffu;
-    if (ex == 0u || ex == 255u) return 255u;                 // zero, denormal, inf, NaN
-    return ((b >> 31) && (b & 0x7fffffu) == 0u) ? ex - 1u : ex;   // V = -2**k: the values above it are one binade down
+    const uint32_t e = ((b >> 31) && (b & 0x7fffffu) == 0u) ? ex - 1u : ex;   // V = -2**k: the values above it are one binade down
+    return (ex == 0u || ex == 255u) ? 255u : e;                               // zero, denormal, inf, NaN
 }
 // ulp of class e (float32 bias 127 -> float64 bias 1023, 52 mantissa bits)
 __device__ __forceinline__ double class_ulp(uint32_t e) { return __longlong_as_double((long long)(e + 1023u - 127u - 52u) << 52); }

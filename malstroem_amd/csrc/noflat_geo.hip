@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -411,12 +412,17 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         const float PINF = __builtin_inff();
         const int border_row = (int)(H - 1 - r0 < 2 * WN ? H - 1 - r0 : 2 * WN);   // window row of the raster's last row (or beyond the window)
         uint32_t lake_any = 0, nirr = 0, nfatal = 0;
-        {
+        // INNER: the window lies inside the raster and touches none of its border rows / columns (all tiles but the outermost ring): no
+        // clamped row offsets, no border tests -- each of them a scalar compare and a live SGPR pair per row of a loop that is short of
+        // SGPRs (the compiler parks them in VGPR lanes: 1200 v_readlane / v_writelane in the general version)
+        auto classify = [&](auto inner_tag) {
+            constexpr bool INNER = decltype(inner_tag)::value;
+            const bool lane_in_c = INNER ? ((lane >= 1) & (lane <= TI)) : lane_in;
             float f[WN];
             int so = 0;
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
-                f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, (int)(lane_c * 4u), so * 4, 0));
+                f[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rf, (int)((INNER ? (uint32_t)lane : lane_c) * 4u), INNER ? r * Wi * 4 : so * 4, 0));
                 so = r < last_row ? so + Wi : so;
             }
             float upl = PINF, up = PINF, upr = PINF, cul = fleft(f[0]), cur = fright(f[0]);
@@ -427,14 +433,14 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 const bool lower = (upl < V) | (up < V) | (upr < V) | (cul < V) | (cur < V) | (dnl < V) | (dn < V) | (dnr < V);
                 // raster border rows are sources; a band's halo rows are the neighbour's cells (ring-like: never moved here, known
                 // only as far as this window can tell); window rows beyond the local raster are nothing
-                const bool border = lane_border | (ti == 0 && r == 0 && !a.fixed_top) | (r == border_row && !a.fixed_bot) | (r > border_row);
+                const bool border = INNER ? false : (lane_border | (ti == 0 && r == 0 && !a.fixed_top) | (r == border_row && !a.fixed_bot) | (r > border_row));
                 const bool src = lower | border;
-                const bool ring = (r == 0) | (r == WN - 1) | ring_lane | (r >= border_row);
+                const bool ring = (r == 0) | (r == WN - 1) | ring_lane | (INNER ? false : (r >= border_row));
                 // (no branches on per-lane values here: selects only -- see tools/lint_exec_spills.py)
                 const uint32_t adj = (up == V ? 1u : 0u) | (upr == V ? 2u : 0u) | (cur == V ? 4u : 0u) | (dnr == V ? 8u : 0u) |
                                      (dn == V ? 16u : 0u) | (dnl == V ? 32u : 0u) | (cul == V ? 64u : 0u) | (upl == V ? 128u : 0u);
                 const uint32_t e = class_above(V);
-                const bool cell = lane_in & !border & !ring;     // an interior raster cell of this tile
+                const bool cell = lane_in_c & !border & !ring;     // an interior raster cell of this tile
                 const bool flat = cell & !src;
                 const bool regular = flat & (adj != 0u) & (e != 255u) & (tab_l[e & 0xffu] != 0u);
                 const bool nan = cell & (V != V);
@@ -448,12 +454,14 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 // the start distance goes straight to memory (the first relaxation is a visit of the next launch): 0 for a source,
                 // "not reached" for a flat cell, D_IRR for a flat cell of an irregular level
                 const uint32_t d0 = irregular ? D_IRR : (unreached ? DINF : 0u);
-                if (r >= 1 && r <= TI && r < last_row && lane_in) __builtin_amdgcn_raw_buffer_store_b32(d0, rd, lane * 4, r * Wi * 4, 0);
+                if (r >= 1 && r <= TI && (INNER || r < last_row) && lane_in_c) __builtin_amdgcn_raw_buffer_store_b32(d0, rd, lane * 4, r * Wi * 4, 0);
                 upl = cul; up = V; upr = cur;
                 cul = dnl; cur = dnr;
                 __builtin_amdgcn_sched_barrier(0);   // row by row: every comparison is a live SGPR pair until its select has been issued
             }
-        }
+        };
+        if (ti > 0 && tj > 0 && H - 1 - r0 > WN - 1 && c0 + WN - 1 < W - 1) classify(std::true_type{});
+        else classify(std::false_type{});
         {
             uint32_t tot = nirr | (nfatal << 16);      // (at most 62 x 62 of either per window)
 #pragma unroll

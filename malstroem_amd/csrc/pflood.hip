@@ -122,11 +122,14 @@ constexpr int EPT = HE / NT;       // (compacted) basin pairs per thread in the 
 struct WinGeom {
     int64_t r0, c0, H, W;
     int fixed_top, fixed_bot;
+    bool inner;      // the window touches no border row / column of the raster: a cell's class is its position in the window
 };
 // class of window cell ci: valid / raster border / window ring (the last two exclude each other)
 __device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
 {
     const int wr = ci >> 6, wc = ci & 63;
+    // (all windows but the outermost ring of them: no 64-bit compares and branches per cell)
+    if (g.inner) return (wr == 0 || wr == WN - 1 || wc == 0 || wc == WN - 1) ? (uint8_t)(C_VALID | C_RING) : (uint8_t)C_VALID;
     const int64_t rr = g.r0 + wr, cc = g.c0 + wc;
     if (rr >= g.H || cc >= g.W) return 0;
     // (a band's halo rows sit on window ring rows -- PfRun::begin checks the alignment -- and are ring cells like any other)
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
     WinGeom g;
     g.r0 = (int64_t)ti * TI; g.c0 = (int64_t)tj * TI; g.H = a.H; g.W = a.W; g.fixed_top = a.fixed_top; g.fixed_bot = a.fixed_bot;
+    g.inner = g.r0 > 0 && g.c0 > 0 && g.r0 + WN - 1 < g.H - 1 && g.c0 + WN - 1 < g.W - 1;      // (wave-uniform)
     const int64_t W = a.W;
     uint32_t *hk = hkv, *hv = hkv + HE;
     static_assert(2 * HE == NC, "plateau ids / drains (one 16-bit word per cell each) share the hash arrays");

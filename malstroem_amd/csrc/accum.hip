@@ -198,15 +198,19 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
     // my CPT cells: i = tid + ATN j (consecutive lanes = consecutive LDS words)
     sum_t sreg[CPT];      // my cells' sums as of the last barrier (what I push)
     uint32_t preg[CPT];   // ... and their A | R << 13
+    // (a tile that lies inside the raster and holds no halo row -- all but the last row / column of tiles -- needs none of the bounds
+    // and halo tests below: a dozen 64-bit compares per cell)
+    auto init_cells = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int i = tid + ATN * j;
         const int r = i / AT, c = i - r * AT;
-        const bool inside = (r0 + r) < H && (c0 + c) < W;
+        const bool inside = FULL || ((r0 + r) < H && (c0 + c) < W);
         const int slot = perim_slot(r, c);
         unsigned deg_ext = slot >= 0 ? dext_l[slot] : 0u;
         sum_t v = inside ? (sum_t)1 : TAINT_S;   // not a raster cell: nothing flows into it (its neighbours see NODIR... it has none)
-        const bool halo = inside && halo_row(r0 + r);
+        const bool halo = !FULL && inside && halo_row(r0 + r);
         if (halo) {  // the neighbouring band's cell: known (> 0) = a source of that much flux, else it blocks its path
             // boundary pass of the band protocol (halo_zero): a known source of NO flux -- the local sums then are the band's own
             // contribution, and the halo cell's path is traced to where it leaves the band (accum_band_exit_kernel)
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
         uint32_t nx = SENT13;
         if (inside && code <= 7u) {
             const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
-            if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr))
+            if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (FULL || ((r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr))))
                 nx = (uint32_t)(nr * AT + nc);
         }
         const uint32_t pw = nx | ((uint32_t)i << R_SHIFT);
@@ -232,6 +236,9 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
         sreg[j] = v;
         preg[j] = pw;
     }
+    };
+    if (r0 + AT <= H && c0 + AT <= W && !fixed_top && !fixed_bot) init_cells(std::true_type{});
+    else init_cells(std::false_type{});
     __syncthreads();
     MH_ASTAMP(1);
 

@@ -16,6 +16,8 @@
 // keep `unassigned`; the number of rounds is capped at 40 (> log2 of any int32-indexable path).
 #include <algorithm>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mh {
@@ -171,28 +173,39 @@ __global__ __launch_bounds__(256) void ws_tile_kernel(const uint8_t *__restrict_
         }
     }
     uint32_t lmask = 0;      // my labelled cells
+    // (INNER: the tile touches no border of the raster -- every cell and every downstream cell is a raster cell: no 64-bit bounds
+    // tests per cell, local coordinates only)
+    auto init_cells = [&](auto inner_tag) {
+        constexpr bool INNER = decltype(inner_tag)::value;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int li = lr * WT + lc0 + k;
-        const int64_t c = cbase + k;
-        uint16_t p = (uint16_t)li;
-        uint8_t v = V_NONE;
-        if (r < H && c < W) {
-            if (lb[k] != unassigned) {
-                lmask |= 1u << k;
-                v = V_LAB;                              // labelled: a fixed point
-            } else if (code[k] <= 7u) {
-                const int64_t nr = r + dir_dr((int)code[k]), nc = c + dir_dc((int)code[k]);
-                if (nr >= 0 && nr < H && nc >= 0 && nc < W) {
-                    const int64_t lr2 = nr - r0, lc2 = nc - c0;
-                    if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) p = (uint16_t)(lr2 * WT + lc2);
-                    else v = code[k];                   // leaves the tile: the path continues at that entry cell
+        for (int k = 0; k < 16; ++k) {
+            const int li = lr * WT + lc0 + k;
+            const int64_t c = cbase + k;
+            uint16_t p = (uint16_t)li;
+            uint8_t v = V_NONE;
+            if (INNER || (r < H && c < W)) {
+                if (lb[k] != unassigned) {
+                    lmask |= 1u << k;
+                    v = V_LAB;                              // labelled: a fixed point
+                } else if (code[k] <= 7u) {
+                    const int lr2 = lr + dir_dr((int)code[k]), lc2 = lc0 + k + dir_dc((int)code[k]);
+                    bool in_raster = true;
+                    if (!INNER) {
+                        const int64_t nr = r0 + lr2, nc = c0 + lc2;
+                        in_raster = nr >= 0 && nr < H && nc >= 0 && nc < W;
+                    }
+                    if (in_raster) {
+                        if (lr2 >= 0 && lr2 < WT && lc2 >= 0 && lc2 < WT) p = (uint16_t)(lr2 * WT + lc2);
+                        else v = code[k];                   // leaves the tile: the path continues at that entry cell
+                    }
                 }
             }
+            ptr[li] = p;
+            val[li] = v;
         }
-        ptr[li] = p;
-        val[li] = v;
-    }
+    };
+    if (r0 > 0 && c0 > 0 && r0 + WT < H && c0 + WT < W) init_cells(std::true_type{});
+    else init_cells(std::false_type{});
     __syncthreads();
     if (pc.mask0) {
         // (labels and directions are NOT kept in registers across the barrier above -- 32 registers that cost the kernel a third of

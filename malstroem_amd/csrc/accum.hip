@@ -449,13 +449,16 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
             fq[u] = *reinterpret_cast<const uint32_t *>(fd + rr * W + c0 + c4);
         }
     }
+    // (FULL: the tile lies inside the raster -- no bounds tests per cell)
+    auto build = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
         const int q = tid + u * ATN, r = q >> 4, c4 = (q & 15) * 4;
         const int64_t rr = r0 + r;
         uint32_t l[4];
         uint8_t b[4];
-        if (rr < H && wide) {
+        if (FULL || (rr < H && wide)) {
             const uint2 v = lq[u];
             l[0] = v.x & 0xffffu; l[1] = v.x >> 16; l[2] = v.y & 0xffffu; l[3] = v.y >> 16;
             const uint32_t f = fq[u];
@@ -478,12 +481,15 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
             nx[t] = (uint16_t)SENT13;
             if (code <= 7u && !(l[t] & TAINT32)) {
                 const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
-                if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W) nx[t] = (uint16_t)(nr * AT + nc);
+                if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (FULL || ((r0 + nr) < H && (c0 + nc) < W))) nx[t] = (uint16_t)(nr * AT + nc);
             }
         }
         *reinterpret_cast<uint4 *>(&S[r * AT + c4]) = make_uint4(l[0], l[1], l[2], l[3]);
         *reinterpret_cast<uint2 *>(&P[r * AT + c4]) = make_uint2((uint32_t)nx[0] | ((uint32_t)nx[1] << 16), (uint32_t)nx[2] | ((uint32_t)nx[3] << 16));
     }
+    };
+    if (wide && r0 + AT <= H) build(std::true_type{});
+    else build(std::false_type{});
     __syncthreads();
     // the walkers: every entry with its inflow (bit 31: the inflow never arrived -- the path is tainted)
     if (tid < PERIM && (fl & F_ENTRY)) {

@@ -204,12 +204,22 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
                 int32_t gq[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) gq[u] = lq[u] >= 0 ? em.parent[lq[u]] : -1;
+                // (the four rows' prefix words and root bits in flight together as well: looked up row by row inside the `>= 0` branch,
+                // each pair was waited for before the next row's went out)
+                uint32_t wp[4];
+                unsigned long long rb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t gg = gq[u] >= 0 ? gq[u] : 0;
+                    wp[u] = em.wordprefix[gg >> 6];
+                    rb[u] = em.rootbits[gg >> 6];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int64_t i = (tr * TR + r4 + u) * g.W + col;
                     const bool valid = col < g.W && i < g.n;
                     const int32_t gg = gq[u];
-                    const int32_t l = gg >= 0 ? (int32_t)(em.wordprefix[gg >> 6] + (uint32_t)__popcll(em.rootbits[gg >> 6] & ((1ull << (gg & 63)) - 1ull))) + 1 : 0;
+                    const int32_t l = gg >= 0 ? (int32_t)(wp[u] + (uint32_t)__popcll(rb[u] & ((1ull << (gg & 63)) - 1ull))) + 1 : 0;
                     if (valid) em.labels[i] = l;
                     lq[u] = valid ? l : -1;
                 }

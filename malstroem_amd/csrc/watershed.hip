@@ -368,7 +368,43 @@ __global__ __launch_bounds__(256) void ws_assign_hop_kernel(const int32_t *__res
         }
         return p & ~DONE;
     };
-    if (i0 + 4 <= n) {
+    if (i0 + 4 <= n && copy) {
+        // (out of place, the usual call: the own labels, the four entry nodes and then the four labels each in flight together -- cell by
+        // cell the look-ups were four + four round trips in a row)
+        const int4 p4 = *reinterpret_cast<const int4 *>(P + i0);
+        int4 v = *reinterpret_cast<const int4 *>(src + i0);
+        const int32_t pq[4] = {p4.x, p4.y, p4.z, p4.w};
+        int64_t nd[4];
+        int32_t q[4], t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool hop = pq[k] >= 0 && pq[k] != NONE && pq[k] != (int32_t)(i0 + k);
+            nd[k] = hop ? ws_node_of(pq[k], (uint32_t)W, ntc) : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = nd[k] >= 0 ? Pn[nd[k]] : NONE;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int32_t pp = pq[k];
+            t[k] = -1;
+            if (pp == NONE || pp == (int32_t)(i0 + k)) continue;           // flows out unlabelled, or labelled
+            if (pp >= 0) {                                                 // an entry cell: what its node has been resolved to
+                if (nd[k] < 0) continue;                                   // (a flow cycle inside the tile)
+                if (q[k] == pp) pp = q[k] | DONE;                          // the entry cell is labelled itself
+                else if (q[k] < 0) pp = q[k];                              // resolved through the entry cell
+                else continue;                                             // NONE, or a flow cycle: stays unassigned
+            }
+            t[k] = pp & ~DONE;
+        }
+        int32_t lv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lv[k] = src[t[k] >= 0 ? t[k] : 0];
+        if (t[0] >= 0) v.x = lv[0];
+        if (t[1] >= 0) v.y = lv[1];
+        if (t[2] >= 0) v.z = lv[2];
+        if (t[3] >= 0) v.w = lv[3];
+        *reinterpret_cast<int4 *>(lab + i0) = v;
+    } else if (i0 + 4 <= n) {
         const int4 p = *reinterpret_cast<const int4 *>(P + i0);
         const int32_t t0 = target(i0, p.x), t1 = target(i0 + 1, p.y), t2 = target(i0 + 2, p.z), t3 = target(i0 + 3, p.w);
         if (copy) {

@@ -859,17 +859,28 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     long long pk0 = __builtin_amdgcn_s_memtime(), pk1 = 0, pk2 = 0;
     int pk_it = 0;
 #endif
+    // ---- levels of the region (a thread's nine words in flight together, next to the relaxations: as a rolled loop with its bounds
+    // branch every word was loaded, waited for and written to LDS before the next one went out -- nine round trips per visit)
+    {
+        constexpr int NLV = RT * RT * NSMAX / ST;
+        static_assert(RT * RT * NSMAX % ST == 0, "whole words per thread");
+        uint32_t lv[NLV];
+#pragma unroll
+        for (int u = 0; u < NLV; ++u) {
+            const int i = t + u * ST;
+            const int rt = i / NSMAX, k = i - rt * NSMAX;
+            const int p = bi * BT + rt / RT - 1, q = bj * BT + rt % RT - 1;
+            const bool ok = p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
+            lv[u] = EMPTY;
+            if (ok) lv[u] = a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k];
+        }
+#pragma unroll
+        for (int u = 0; u < NLV; ++u) L[t + u * ST] = lv[u];
+    }
     // ---- the block's relaxations: registers for the whole visit (EMAX / ST = 6 per thread); in flight together with the levels
     unsigned long long er[EMAX / ST];
 #pragma unroll
     for (int k = 0; k < EMAX / ST; ++k) er[k] = sa.eblk[(size_t)blk * EMAX + t + k * ST];
-    // ---- levels of the region
-    for (int i = t; i < RT * RT * NSMAX; i += ST) {
-        const int rt = i / NSMAX, k = i - rt * NSMAX;
-        const int p = bi * BT + rt / RT - 1, q = bj * BT + rt % RT - 1;
-        const bool ok = p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
-        L[i] = ok ? a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k] : EMPTY;
-    }
     __syncthreads();
     for (int i = t; i < BT * BT * NSMAX; i += ST) {
         const int bt = i / NSMAX, k = i - bt * NSMAX;

@@ -665,11 +665,15 @@ __device__ __forceinline__ void round_body(const GeoArgs &a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t scr_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lds + wave * (WN * (WN + 1)));
     uint32_t *tab_l = lds + 4 * (WN * (WN + 1));
-    for (int i = threadIdx.x; i < 512; i += 256) tab_l[i] = a.tab[i];
+    // (the table's two words per thread and the round's tile count in flight together: as a loop, then the count behind the barrier, they
+    // were three dependent round trips in front of every launch)
+    const uint32_t tw0 = a.tab[threadIdx.x], tw1 = a.tab[threadIdx.x + 256];
+    const int n = FIRST ? a.nt : (int)__builtin_amdgcn_readfirstlane((int)*a.count);
+    tab_l[threadIdx.x] = tw0;
+    tab_l[threadIdx.x + 256] = tw1;
     __syncthreads();
     const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
     unsigned visits = 0, cycles = 0;
-    const int n = FIRST ? a.nt : (int)__builtin_amdgcn_readfirstlane((int)*a.count);
     for (int i = gw; i < n; i += nwaves) {
         const int t = FIRST ? i : __builtin_amdgcn_readfirstlane(a.list[i]);
         visit<FIRST>(a, t, tab_l, scr_b, lane, visits, cycles);

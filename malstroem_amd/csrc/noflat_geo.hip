@@ -148,6 +148,17 @@ struct UniformW {   // every flat cell of the window is of one class: scalar wei
     uint32_t S, Dg;
     __device__ __forceinline__ void get(uint32_t, const uint32_t *, uint32_t &s, uint32_t &g) const { s = S; g = Dg; }
 };
+struct TwoW {       // the window's flat cells are of TWO classes (a seventh of the benchmark's tiles: it straddles one power of two): a select
+    uint32_t c1, S1, G1, S2, G2;        // instead of LaneW's two LDS reads per row, whose latency every row of a pass waited for
+    __device__ __forceinline__ void get(uint32_t mword, const uint32_t *, uint32_t &s, uint32_t &g) const
+    {
+        uint32_t c = c1;
+        asm volatile("" : "+s"(c));      // (or the compares of all rows are hoisted out of the cycles: 62 lane masks, spilled)
+        const bool first = ((mword >> 8) & 0xffu) == c;
+        s = first ? S1 : S2;
+        g = first ? G1 : G2;
+    }
+};
 struct LaneW {      // classes differ inside the window (it straddles a power of two): weights by the cell's own class
     __device__ __forceinline__ void get(uint32_t mword, const uint32_t *tab_l, uint32_t &s, uint32_t &g) const
     {
@@ -373,7 +384,7 @@ __device__ __forceinline__ void relax_open(uint32_t (&d)[WN], const uint32_t S, 
 // cleared, column layout transposed in, adjacency inverted -- and kept for all later visits as a 16 KB block per tile together
 // with a header word (seams, class, "holds a flat cell at all"); distances start from the classification alone.  Later visits
 // (ng_round_kernel) load header, block and distances and go straight to the passes.
-constexpr uint32_t HDR_ACTIVE = 1u << 31, HDR_UNIFORM = 1u << 9, HDR_OPEN = 1u << 10;
+constexpr uint32_t HDR_ACTIVE = 1u << 31, HDR_UNIFORM = 1u << 9, HDR_OPEN = 1u << 10, HDR_TWO = 1u << 11;   // (HDR_TWO: bits 24..30 = second class - first + 64)
 template <bool FIRST>
 __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *tab_l, uint32_t scr_b, int lane, unsigned &visits, unsigned &cycles)
 {
@@ -548,7 +559,27 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             seams |= (br & B62) ? 1u << 8 : 0u;
         }
         const bool uniform = !__any(mism != 0u);
-        hdr = HDR_ACTIVE | seams | (uniform ? HDR_UNIFORM : 0u) | ((uniform && open_tile) ? HDR_OPEN : 0u) | (eref << 16);
+        // exactly two classes?  (the second one as a difference to the first: windows span neighbouring binades)
+        uint32_t two = 0;
+        if (!uniform) {
+            uint32_t e2 = 255u;
+#pragma unroll
+            for (int r = 1; r <= TI; ++r) {
+                const uint32_t e = (ni[r] >> 8) & 0xffu;
+                e2 = ((ni[r] & 0xffu) != 0xffu && e != eref) ? e : e2;
+            }
+            const uint64_t has2 = __ballot(e2 != 255u);       // (not uniform: some lane holds a second class)
+            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)e2, (int)__builtin_ctzll(has2 ? has2 : 1ull));
+            uint32_t m2 = 0;
+#pragma unroll
+            for (int r = 1; r <= TI; ++r) {
+                const uint32_t e = (ni[r] >> 8) & 0xffu;
+                m2 |= ((ni[r] & 0xffu) != 0xffu && e != eref && e != c2) ? 1u : 0u;
+            }
+            const int delta = (int)c2 - (int)eref;
+            if (has2 && !__any(m2 != 0u) && delta >= -64 && delta < 64) two = HDR_TWO | ((uint32_t)(delta + 64) << 24);
+        }
+        hdr = HDR_ACTIVE | seams | (uniform ? HDR_UNIFORM : 0u) | ((uniform && open_tile) ? HDR_OPEN : 0u) | (eref << 16) | two;
         __builtin_amdgcn_sched_barrier(0);
         // the block: packed for a window of one class (relax_pk), the full words otherwise; none for a tile that is one flat
         if (uniform && !open_tile) {
@@ -603,7 +634,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     bool changed = false, capped = false;
     if (hdr & HDR_OPEN) relax_open(d, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     else if (hdr & HDR_UNIFORM) relax_pk(d, pk, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
-    else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    else if (hdr & HDR_TWO) {
+        const uint32_t c2 = eref + ((hdr >> 24) & 0x7fu) - 64u;
+        const auto sc = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)tab_l[i]); };      // (scalars: the window's registers are full)
+        relax(d, ni, TwoW{eref, sc(eref), sc(256 + eref), sc(c2 & 0xffu), sc(256 + (c2 & 0xffu))}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    } else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     wake &= hdr & 0x1ffu;
 #ifdef NG_PROFILE
     const long long tp3 = __builtin_amdgcn_s_memtime();

@@ -51,7 +51,9 @@ constexpr int TI = 62;  // tile edge
 constexpr uint32_t DINF = 0xE0000000u;     // "not reached yet"; every weight is < 2**28, so DINF + weight does not wrap
 constexpr uint32_t WMAX = 1u << 28;
 constexpr uint32_t D_IRR = 0xFFFFFFFFu;    // distance word of a flat cell of an irregular level: not part of the transform (see GeoRun::end)
-constexpr uint32_t M_NOFLAT = 0xFF00u;     // class 255: not a flat cell (a source), or a flat cell of a level without integer weights (counted)
+constexpr uint32_t M_NOFLAT = 0xFF00u;     // class 255: not a flat cell (a source)
+constexpr uint32_t M_IRR = 0xFD00u;        // a flat cell of a level without integer weights (counted)
+constexpr uint32_t M_WALL = 0xFE00u;       // a source that some flat cell next to it is NOT adjacent to (pass_wl)
 constexpr int DPP_WF_SL1 = 0x130;          // lane i <- lane i+1
 constexpr int DPP_WF_SR1 = 0x138;          // lane i <- lane i-1
 #ifndef NG_MAXCYC
@@ -243,43 +245,99 @@ __device__ __forceinline__ void relax(uint32_t (&d)[WN], uint32_t (&ni)[WN], con
     }
 }
 
-// ---- a window of ONE class (nearly every tile): the passes need no class bytes, and the two layouts' inverted adjacency bytes
-// of TWO register rows share a word:  pk[k] = A(2k) | B(2k) << 8 | A(2k + 1) << 16 | B(2k + 1) << 24  (A: the row layout's byte
-// of register row r, B: the transposed layout's).  Half the block (8 instead of 16 KB per visit), 32 instead of 64 registers, 32
-// instead of 64 loads, and no rotation of the words after a transpose: a pass picks its bits by a compile-time offset.
-template <bool DOWN, int PH>
-__device__ __forceinline__ void pass_pk(uint32_t (&d)[WN], uint32_t (&pk)[WN / 2], const uint32_t S, const uint32_t G, uint32_t &acc_all, uint32_t &acc_first,
-                                        uint32_t &acc_last)
+// ---- a window of ONE class (six of seven tiles): no adjacency bits at all.  A flat cell has no lower neighbour, so a neighbour it is
+// NOT adjacent to (another level) is higher, has the flat cell as a lower neighbour and is therefore a source -- distance 0, fixed.
+// Such a source reads as "not reached" in the window's registers (a WALL: its candidates never win), and the flat cells of its own
+// level that it would have fed start from their step weight instead (the seeds, ng_first).  With the walls in place every candidate
+// of a flat cell that can win comes from a cell it is adjacent to: the passes need one bit per cell -- may it move (a regular flat
+// cell of this tile's interior) -- instead of three adjacency bits per cell and pass.  Block of such a window, nine words per lane:
+// mk[0..1] immovable / mk[2..3] wall bits by register row of the row layout, mk[4..7] the same of the transposed layout,
+// mk[8] = bit 0 / 1: row 1 / 62 of this lane is adjacent to something across the seam (row layout), bits 2 / 3: transposed layout.
+constexpr int NMK = 9;
+// One row of a pass as text: 8 instructions in 8 issue slots.  A DPP operand must not have been written by one of the two instructions in
+// front of the DPP instruction (the compiler pads with s_nop; left to itself it spent 13 slots on the row -- and turned the bit test into
+// and + compare + select with two more wait states): `b`, the row behind, is written by the v_bfi of the row before, the v_bitop3 and
+// the v_add stand between.  O: the row's new value (not one of the inputs), I: its old one, BIT: its bit in the mask word.
+#define NG_DPP " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define NG_ROW(O, I, B, BIT)                                                                                                                 \
+    "v_add_u32 %[u], %[" B "], %[S]\n\t"                                                                                                    \
+    "v_add_u32_dpp %[t], %[" B "], %[G] wave_shr:1" NG_DPP                                                                                   \
+    "v_add_u32_dpp %[k], %[" B "], %[G] wave_shl:1" NG_DPP                                                                                   \
+    "v_min3_u32 %[t], %[u], %[t], %[k]\n\t"                                                                                                 \
+    "v_bfe_i32 %[k], %[m], " BIT ", 1\n\t"                                                                                                  \
+    "v_min_u32 %[" O "], %[t], %[" I "]\n\t"                                                                                                \
+    "v_bfi_b32 %[" O "], %[k], %[" I "], %[" O "]\n\t"                                                                                      \
+    "v_bitop3_b32 %[acc], %[" O "], %[acc], %[" I "] bitop3:0xde\n\t"
+// rows R, R + dir, .. R + 5 dir from the row behind R (six rows a block: the compiler puts an s_nop in front of every block)
+template <int R, int DIR>
+__device__ __forceinline__ void rows6_wl(uint32_t (&d)[WN], const uint32_t m, const uint32_t S, const uint32_t G, uint32_t &acc)
 {
-    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
-    constexpr int bC = DOWN ? 0 : 4, bL = DOWN ? 7 : 5, bR = DOWN ? 1 : 3;
-#pragma unroll
-    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]));
-#pragma unroll
-    for (int r = 0; r < WN / 2; ++r) asm volatile("" : "+v"(pk[r]));
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int r = first + dir * i;
-        const int base = 16 * (r & 1) + 8 * PH;
-        const uint32_t behind = d[r - dir];
-        const uint32_t bl = from_left(behind), br = from_right(behind);
-        const uint32_t w = pk[r >> 1];
-        const uint32_t c0 = (behind + S) | (uint32_t)__builtin_amdgcn_sbfe((int)w, base + bC, 1);
-        const uint32_t c1 = (bl + G) | (uint32_t)__builtin_amdgcn_sbfe((int)w, base + bL, 1);
-        const uint32_t c2 = (br + G) | (uint32_t)__builtin_amdgcn_sbfe((int)w, base + bR, 1);
-        const uint32_t cu = d[r];
-        const uint32_t nv = min(min(c0, c1), min(c2, cu));
-        const uint32_t x = nv ^ cu;
-        acc_all |= x;
-        asm volatile("" : "+v"(acc_all));
-        if (r == 1) acc_first |= (w & (0x83u << base)) != (0x83u << base) ? x : 0u;
-        if (r == TI) acc_last |= (w & (0x38u << base)) != (0x38u << base) ? x : 0u;
-        d[r] = nv;
+    static_assert((R >> 5) == ((R + 5 * DIR) >> 5), "one mask word a block");
+    uint32_t o0, o1, o2, o3, o4, o5, u, t, k;
+    if constexpr (DIR > 0)
+        asm volatile(NG_ROW("o0", "i0", "b", "%[bit]") NG_ROW("o1", "i1", "o0", "%[bit]+1") NG_ROW("o2", "i2", "o1", "%[bit]+2")
+                     NG_ROW("o3", "i3", "o2", "%[bit]+3") NG_ROW("o4", "i4", "o3", "%[bit]+4") NG_ROW("o5", "i5", "o4", "%[bit]+5")
+                     : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5), [u] "=&v"(u), [t] "=&v"(t),
+                       [k] "=&v"(k), [acc] "+v"(acc)
+                     : [b] "v"(d[R - DIR]), [i0] "v"(d[R]), [i1] "v"(d[R + DIR]), [i2] "v"(d[R + 2 * DIR]), [i3] "v"(d[R + 3 * DIR]),
+                       [i4] "v"(d[R + 4 * DIR]), [i5] "v"(d[R + 5 * DIR]), [S] "v"(S), [G] "v"(G), [m] "v"(m), [bit] "n"(R & 31));
+    else
+        asm volatile(NG_ROW("o0", "i0", "b", "%[bit]") NG_ROW("o1", "i1", "o0", "%[bit]-1") NG_ROW("o2", "i2", "o1", "%[bit]-2")
+                     NG_ROW("o3", "i3", "o2", "%[bit]-3") NG_ROW("o4", "i4", "o3", "%[bit]-4") NG_ROW("o5", "i5", "o4", "%[bit]-5")
+                     : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5), [u] "=&v"(u), [t] "=&v"(t),
+                       [k] "=&v"(k), [acc] "+v"(acc)
+                     : [b] "v"(d[R - DIR]), [i0] "v"(d[R]), [i1] "v"(d[R + DIR]), [i2] "v"(d[R + 2 * DIR]), [i3] "v"(d[R + 3 * DIR]),
+                       [i4] "v"(d[R + 4 * DIR]), [i5] "v"(d[R + 5 * DIR]), [S] "v"(S), [G] "v"(G), [m] "v"(m), [bit] "n"(R & 31));
+    d[R] = o0; d[R + DIR] = o1; d[R + 2 * DIR] = o2; d[R + 3 * DIR] = o3; d[R + 4 * DIR] = o4; d[R + 5 * DIR] = o5;
+}
+// one row on its own (rows 1 and 62: their differences are looked at separately); returns old ^ new
+template <int R, int DIR>
+__device__ __forceinline__ uint32_t row1_wl(uint32_t (&d)[WN], const uint32_t m, const uint32_t S, const uint32_t G, uint32_t &acc)
+{
+    uint32_t o0, u, t, k;
+    const uint32_t cu = d[R];
+    asm volatile("s_nop 1\n\t" NG_ROW("o0", "i0", "b", "%[bit]") "s_nop 1"
+                 : [o0] "=&v"(o0), [u] "=&v"(u), [t] "=&v"(t), [k] "=&v"(k), [acc] "+v"(acc)
+                 : [b] "v"(d[R - DIR]), [i0] "v"(cu), [S] "v"(S), [G] "v"(G), [m] "v"(m), [bit] "n"(R & 31));
+    d[R] = o0;
+    return o0 ^ cu;
+}
+template <int R, int DIR, int N>
+__device__ __forceinline__ void blocks_wl(uint32_t (&d)[WN], const uint32_t lo, const uint32_t hi, const uint32_t S, const uint32_t G, uint32_t &acc)
+{
+    if constexpr (N > 0) {
+        rows6_wl<R, DIR>(d, R < 32 ? lo : hi, S, G, acc);
         __builtin_amdgcn_sched_barrier(0);
+        blocks_wl<R + 6 * DIR, DIR, N - 1>(d, lo, hi, S, G, acc);
     }
 }
+template <bool DOWN>
+__device__ __forceinline__ void pass_wl(uint32_t (&d)[WN], const uint32_t imm_lo, const uint32_t imm_hi, const uint32_t S, const uint32_t G,
+                                        const bool edge_first, const bool edge_last, uint32_t &acc_all, uint32_t &acc_first, uint32_t &acc_last)
+{
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]));
+    uint32_t lo = imm_lo, hi = imm_hi;
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    if constexpr (DOWN) {
+        const uint32_t x1 = row1_wl<1, 1>(d, lo, S, G, acc_all);
+        acc_first |= edge_first ? x1 : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_wl<2, 1, 10>(d, lo, hi, S, G, acc_all);              // rows 2 .. 61
+        const uint32_t x2 = row1_wl<TI, 1>(d, hi, S, G, acc_all);
+        acc_last |= edge_last ? x2 : 0u;
+    } else {
+        const uint32_t x2 = row1_wl<TI, -1>(d, hi, S, G, acc_all);
+        acc_last |= edge_last ? x2 : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_wl<TI - 1, -1, 10>(d, lo, hi, S, G, acc_all);         // rows 61 .. 2
+        const uint32_t x1 = row1_wl<1, -1>(d, lo, S, G, acc_all);
+        acc_first |= edge_first ? x1 : 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
 
-__device__ __forceinline__ void relax_pk(uint32_t (&d)[WN], uint32_t (&pk)[WN / 2], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc,
+__device__ __forceinline__ void relax_wl(uint32_t (&d)[WN], const uint32_t (&mk)[NMK], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc,
                                          unsigned &wake, bool &changed, bool &capped, unsigned &cycles)
 {
     const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
@@ -290,8 +348,8 @@ __device__ __forceinline__ void relax_pk(uint32_t (&d)[WN], uint32_t (&pk)[WN / 
         ++cycles;
         {   // lane = column, first / last = row 1 / 62
             uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
-            pass_pk<true, 0>(d, pk, S, G, acc_all, acc_first, acc_last);
-            pass_pk<false, 0>(d, pk, S, G, acc_all, acc_first, acc_last);
+            pass_wl<true>(d, mk[0], mk[1], S, G, (mk[8] & 1u) != 0u, (mk[8] & 2u) != 0u, acc_all, acc_first, acc_last);
+            pass_wl<false>(d, mk[0], mk[1], S, G, (mk[8] & 1u) != 0u, (mk[8] & 2u) != 0u, acc_all, acc_first, acc_last);
             const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
             chg |= all;
             const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
@@ -302,8 +360,8 @@ __device__ __forceinline__ void relax_pk(uint32_t (&d)[WN], uint32_t (&pk)[WN / 
         }
         {   // lane = row, first / last = column 1 / 62
             uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
-            pass_pk<true, 1>(d, pk, S, G, acc_all, acc_first, acc_last);
-            pass_pk<false, 1>(d, pk, S, G, acc_all, acc_first, acc_last);
+            pass_wl<true>(d, mk[4], mk[5], S, G, (mk[8] & 4u) != 0u, (mk[8] & 8u) != 0u, acc_all, acc_first, acc_last);
+            pass_wl<false>(d, mk[4], mk[5], S, G, (mk[8] & 4u) != 0u, (mk[8] & 8u) != 0u, acc_all, acc_first, acc_last);
             const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
             chg |= all;
             const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
@@ -407,7 +465,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.blk + (int64_t)t * (WN * WN)), 0, WN * WN * 4, 0x00020000);
     const int Wi = (int)W;
     const int last_row = (int)(H - 1 - r0 < WN - 1 ? H - 1 - r0 : WN - 1);   // last window row inside the raster
-    uint32_t ni[WN], d[WN], pk[WN / 2];
+    uint32_t ni[WN], d[WN], mk[NMK];
     uint32_t hdr;
     if constexpr (FIRST) {
         // ---- classification of the window from the plain fill F (adjacency bits = AGNPS direction codes of common.hpp:
@@ -453,22 +511,61 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 const uint32_t e = class_above(V);
                 const bool cell = lane_in_c & !border & !ring;     // an interior raster cell of this tile
                 const bool flat = cell & !src;
-                const bool regular = flat & (adj != 0u) & (e != 255u) & (tab_l[e & 0xffu] != 0u);
+                const bool regular = flat & (adj != 0u) & (e < 253u) & (tab_l[e & 0xffu] != 0u);     // (253 .. 255: M_IRR, M_WALL, M_NOFLAT)
                 const bool nan = cell & (V != V);
                 const bool irregular = flat & !regular & !nan;     // a level without integer weights: left to the float64 relaxation
                 nirr += irregular ? 1u : 0u;
                 nfatal += nan ? 1u : 0u;                            // NaN cells: not for this path at all
-                const uint32_t w = regular ? (adj | (e << 8)) : M_NOFLAT;
-                const bool unreached = regular | (ring & !src);
+                const uint32_t w = regular ? (adj | (e << 8)) : (irregular ? M_IRR : M_NOFLAT);
                 lake_any |= w;
                 ni[r] = w;
-                // the start distance goes straight to memory (the first relaxation is a visit of the next launch): 0 for a source,
-                // "not reached" for a flat cell, D_IRR for a flat cell of an irregular level
-                const uint32_t d0 = irregular ? D_IRR : (unreached ? DINF : 0u);
-                if (r >= 1 && r <= TI && (INNER || r < last_row) && lane_in_c) __builtin_amdgcn_raw_buffer_store_b32(d0, rd, lane * 4, r * Wi * 4, 0);
                 upl = cul; up = V; upr = cur;
                 cul = dnl; cur = dnr;
                 __builtin_amdgcn_sched_barrier(0);   // row by row: every comparison is a live SGPR pair until its select has been issued
+            }
+            // ---- the walls: a cell that some regular flat cell next to it is not adjacent to.  q = the directions in which a flat cell
+            // has such a neighbour; a cell collects the bits that point at it from its 8 neighbours (A: one word per row with the bits
+            // of the cell itself, of its left and of its right neighbour, by the rows they matter to)
+            {
+                auto arow = [&](int r) -> uint32_t {
+                    if (r < 0 || r >= WN) return 0u;
+                    const uint32_t q = (ni[r] & 0xffu) != 0u ? (~ni[r] & 0xffu) : 0u;
+                    return (q & 0x11u) | (from_left(q) & 0x0eu) | (from_right(q) & 0xe0u);
+                };
+                uint32_t Ap = 0u, Ac = arow(0);
+#pragma unroll
+                for (int r = 0; r < WN; ++r) {
+                    const uint32_t An = arow(r + 1);
+                    const uint32_t hit = (An & 0x83u) | (Ap & 0x38u) | (Ac & 0x44u);
+                    ni[r] = (hit != 0u && (ni[r] & 0xffu) == 0u) ? M_WALL : ni[r];
+                    Ap = Ac; Ac = An;
+                    asm volatile("" : "+v"(ni[r]), "+v"(Ap), "+v"(Ac));      // (the row is finished here, not after the loop)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- the start distances, straight to memory (the first relaxation is a visit of the next launch): 0 for a source, D_IRR
+            // for a flat cell of an irregular level; a regular flat cell starts "not reached" -- or, next to a wall of its own level,
+            // from the step that wall would have given it
+            {
+                auto trow = [&](int r) -> uint32_t {      // wall bits of (r, lane) | (r, lane - 1) << 1 | (r, lane + 1) << 2
+                    const uint32_t c = (ni[r] & 0xff00u) == M_WALL ? 1u : 0u;
+                    return c | (from_left(c) << 1) | (from_right(c) << 2);
+                };
+                uint32_t P = trow(0), C = trow(1);
+#pragma unroll
+                for (int r = 1; r <= TI; ++r) {
+                    const uint32_t N = trow(r + 1);
+                    const uint32_t nb = (P & 1u) | ((P & 4u) >> 1) | (C & 4u) | ((N & 4u) << 1) | ((N & 1u) << 4) | ((N & 2u) << 4) | ((C & 2u) << 5) | ((P & 2u) << 6);
+                    const uint32_t w = ni[r], sb = w & nb;        // (w & 0xff = the adjacency of a regular flat cell, 0 otherwise)
+                    const uint32_t e = (w >> 8) & 0xffu;
+                    const uint32_t S = tab_l[e], G = tab_l[256 + e];
+                    const uint32_t seeded = min((sb & 0x55u) ? S : DINF, (sb & 0xaau) ? G : DINF);
+                    const uint32_t d0 = (w & 0xffu) != 0u ? seeded : ((w & 0xff00u) == M_IRR ? D_IRR : 0u);
+                    if ((INNER || r < last_row) && lane_in_c) __builtin_amdgcn_raw_buffer_store_b32(d0, rd, lane * 4, r * Wi * 4, 0);
+                    P = C; C = N;
+                    asm volatile("" : "+v"(P), "+v"(C));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         };
         if (ti > 0 && tj > 0 && H - 1 - r0 > WN - 1 && c0 + WN - 1 < W - 1) classify(std::true_type{});
@@ -525,12 +622,20 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         }
         __builtin_amdgcn_sched_barrier(0);
         // one class in the whole window?  (from the words that stay live anyway: the adjacency byte is inverted by now)
+        // (new names for the words in front of every loop over them: what one loop extracts from a word -- its class byte, a compare -- must
+        // not be kept for the next loop: 62 live registers each time, i.e. spills)
+        auto fresh = [&]() {
+#pragma unroll
+            for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(ni[r]));
+        };
         uint32_t esel = 255u;
+        fresh();
 #pragma unroll
         for (int r = 1; r <= TI; ++r) esel = (ni[r] & 0xffu) != 0xffu ? (ni[r] >> 8) & 0xffu : esel;
         const uint64_t has = __ballot(esel != 255u);
         const uint32_t eref = (uint32_t)__builtin_amdgcn_readlane((int)esel, (int)__builtin_ctzll(has));   // has != 0: the tile holds a flat cell
         uint32_t mism = 0;
+        fresh();
 #pragma unroll
         for (int r = 1; r <= TI; ++r) mism |= (ni[r] & 0xffu) != 0xffu ? ((ni[r] >> 8) & 0xffu) ^ eref : 0u;
         // which of the 8 neighbouring tiles share a flat with this one at all?  (bit numbering of `wake`)
@@ -538,6 +643,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         bool open_tile = false;
         {
             uint32_t l_or = 0xffu;   // AND of the inverted bytes over rows 1..62 = inverted OR of the adjacency
+            fresh();
 #pragma unroll
             for (int r = 1; r <= TI; ++r) l_or &= ni[r];
             uint32_t any_gap = 0;    // OR of the inverted bytes: a cell that lacks one of its 8 neighbours on its level
@@ -563,6 +669,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         uint32_t two = 0;
         if (!uniform) {
             uint32_t e2 = 255u;
+            fresh();
 #pragma unroll
             for (int r = 1; r <= TI; ++r) {
                 const uint32_t e = (ni[r] >> 8) & 0xffu;
@@ -571,6 +678,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             const uint64_t has2 = __ballot(e2 != 255u);       // (not uniform: some lane holds a second class)
             const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)e2, (int)__builtin_ctzll(has2 ? has2 : 1ull));
             uint32_t m2 = 0;
+            fresh();
 #pragma unroll
             for (int r = 1; r <= TI; ++r) {
                 const uint32_t e = (ni[r] >> 8) & 0xffu;
@@ -583,9 +691,21 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         __builtin_amdgcn_sched_barrier(0);
         // the block: packed for a window of one class (relax_pk), the full words otherwise; none for a tile that is one flat
         if (uniform && !open_tile) {
+            uint32_t mk[NMK] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            fresh();
 #pragma unroll
-            for (int k = 0; k < WN / 2; ++k)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(ni[2 * k + 1], ni[2 * k], 0x06040200u), rb, lane * 4, k * WN * 4, 0);
+            for (int r = 0; r < WN; ++r) {
+                const uint32_t w = ni[r], bit = 1u << (r & 31);
+                const int h = r >> 5;
+                mk[0 + h] |= (w & 0xffu) == 0xffu ? bit : 0u;                  // (the adjacency bytes are inverted by now: 0xff = none)
+                mk[2 + h] |= (w & 0xff00u) == M_WALL ? bit : 0u;
+                mk[4 + h] |= (w & 0xff0000u) == 0xff0000u ? bit : 0u;
+                mk[6 + h] |= (w >> 24) == (M_WALL >> 8) ? bit : 0u;
+            }
+            mk[8] = ((ni[1] & 0x83u) != 0x83u ? 1u : 0u) | ((ni[TI] & 0x38u) != 0x38u ? 2u : 0u) |
+                    ((ni[1] & 0x830000u) != 0x830000u ? 4u : 0u) | ((ni[TI] & 0x380000u) != 0x380000u ? 8u : 0u);
+#pragma unroll
+            for (int k = 0; k < NMK; ++k) __builtin_amdgcn_raw_buffer_store_b32(mk[k], rb, lane * 4, k * WN * 4, 0);
         } else if (!uniform) {
 #pragma unroll
             for (int r = 0; r < WN; ++r) __builtin_amdgcn_raw_buffer_store_b32(ni[r], rb, lane * 4, r * WN * 4, 0);
@@ -601,9 +721,9 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         hdr = __builtin_amdgcn_readfirstlane(a.hdr[t]);
         if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
         if (hdr & HDR_OPEN) {              // (a tile that is one flat needs no words)
-        } else if (hdr & HDR_UNIFORM) {    // packed: two register rows per word
+        } else if (hdr & HDR_UNIFORM) {    // one class: bit masks (pass_wl)
 #pragma unroll
-            for (int k = 0; k < WN / 2; ++k) pk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
+            for (int k = 0; k < NMK; ++k) mk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
         } else {
 #pragma unroll
             for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
@@ -633,7 +753,15 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     unsigned wake = 0;
     bool changed = false, capped = false;
     if (hdr & HDR_OPEN) relax_open(d, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
-    else if (hdr & HDR_UNIFORM) relax_pk(d, pk, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+    else if (hdr & HDR_UNIFORM) {
+#pragma unroll
+        for (int r = 0; r < WN; ++r) d[r] |= (uint32_t)__builtin_amdgcn_sbfe((int)mk[2 + (r >> 5)], r & 31, 1) & DINF;      // the walls (0 in memory)
+        relax_wl(d, mk, tab_l[eref], tab_l[256 + eref], scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+        if (changed) {
+#pragma unroll
+            for (int r = 1; r <= TI; ++r) d[r] &= ~(uint32_t)__builtin_amdgcn_sbfe((int)mk[2 + (r >> 5)], r & 31, 1);
+        }
+    }
     else if (hdr & HDR_TWO) {
         const uint32_t c2 = eref + ((hdr >> 24) & 0x7fu) - 64u;
         const auto sc = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)tab_l[i]); };      // (scalars: the window's registers are full)
@@ -1001,6 +1129,10 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
                                (int)((m.nt + 7) / 8), m.d_list, m.d_any + m.round);
         if (m.light) {
             const bool odd = ((m.round - m.light_from) & 1) != 0;
+            {
+                static const char *et = dev_env("MHIP_NG_TAILCYC");
+                if (et && atoi(et) >= 1) a.maxcyc = atoi(et);
+            }
             a.append = 1;
             a.round_next = m.round + 1;
             a.list = odd ? m.d_list2 : m.d_list;

@@ -558,8 +558,11 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                     const uint32_t nb = (P & 1u) | ((P & 4u) >> 1) | (C & 4u) | ((N & 4u) << 1) | ((N & 1u) << 4) | ((N & 2u) << 4) | ((C & 2u) << 5) | ((P & 2u) << 6);
                     const uint32_t w = ni[r], sb = w & nb;        // (w & 0xff = the adjacency of a regular flat cell, 0 otherwise)
                     const uint32_t e = (w >> 8) & 0xffu;
-                    const uint32_t S = tab_l[e], G = tab_l[256 + e];
-                    const uint32_t seeded = min((sb & 0x55u) ? S : DINF, (sb & 0xaau) ? G : DINF);
+                    uint32_t seeded = DINF;
+                    if (__any(sb != 0u)) {        // (a row without a seed -- two of three -- does not wait for the table)
+                        const uint32_t S = tab_l[e], G = tab_l[256 + e];
+                        seeded = min((sb & 0x55u) ? S : DINF, (sb & 0xaau) ? G : DINF);
+                    }
                     const uint32_t d0 = (w & 0xffu) != 0u ? seeded : ((w & 0xff00u) == M_IRR ? D_IRR : 0u);
                     if ((INNER || r < last_row) && lane_in_c) __builtin_amdgcn_raw_buffer_store_b32(d0, rd, lane * 4, r * Wi * 4, 0);
                     P = C; C = N;
@@ -718,16 +721,9 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         // two phases together do not fit the register file and the compiler spills in both)
         return;
     } else {
-        hdr = __builtin_amdgcn_readfirstlane(a.hdr[t]);
-        if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
-        if (hdr & HDR_OPEN) {              // (a tile that is one flat needs no words)
-        } else if (hdr & HDR_UNIFORM) {    // one class: bit masks (pass_wl)
-#pragma unroll
-            for (int k = 0; k < NMK; ++k) mk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
-        } else {
-#pragma unroll
-            for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
-        }
+        // (the distances first: their addresses need nothing but the tile's number, the header -- which block, if any -- is one more
+        // round trip that the 64 row loads cover; in the tail rounds a launch is little more than the chain of such round trips)
+        const uint32_t hdr_m = a.hdr[t];
         // (a window that lies inside the raster -- every tile but the bottom row's -- takes its rows at fixed multiples of the pitch: the
         // clamped row offsets below cost a dozen scalar instructions and two saved masks per row, again in front of every store)
         if (last_row == WN - 1) {
@@ -740,6 +736,17 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 d[r] = __builtin_amdgcn_raw_buffer_load_b32(rd, (int)(lane_c * 4u), so * 4, 0);
                 so = r < last_row ? so + Wi : so;
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        hdr = __builtin_amdgcn_readfirstlane(hdr_m);
+        if (!(hdr & HDR_ACTIVE)) return;   // woken by a neighbour whose flat ends on my ring: nothing of mine can move
+        if (hdr & HDR_OPEN) {              // (a tile that is one flat needs no words)
+        } else if (hdr & HDR_UNIFORM) {    // one class: bit masks (pass_wl)
+#pragma unroll
+            for (int k = 0; k < NMK; ++k) mk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
         }
     }
     ++visits;
@@ -830,15 +837,16 @@ __device__ __forceinline__ void round_body(const GeoArgs &a)
     uint32_t *tab_l = lds + 4 * (WN * (WN + 1));
     // (the table's two words per thread and the round's tile count in flight together: as a loop, then the count behind the barrier, they
     // were three dependent round trips in front of every launch)
+    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
     const uint32_t tw0 = a.tab[threadIdx.x], tw1 = a.tab[threadIdx.x + 256];
     const int n = FIRST ? a.nt : (int)__builtin_amdgcn_readfirstlane((int)*a.count);
+    const int t_first = FIRST ? 0 : a.list[gw < a.nt ? gw : a.nt - 1];      // (this wave's first tile, if the round has that many: no fourth trip)
     tab_l[threadIdx.x] = tw0;
     tab_l[threadIdx.x + 256] = tw1;
     __syncthreads();
-    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
     unsigned visits = 0, cycles = 0;
     for (int i = gw; i < n; i += nwaves) {
-        const int t = FIRST ? i : __builtin_amdgcn_readfirstlane(a.list[i]);
+        const int t = FIRST ? i : __builtin_amdgcn_readfirstlane(i == gw ? t_first : a.list[i]);
         visit<FIRST>(a, t, tab_l, scr_b, lane, visits, cycles);
     }
     if (lane == 0 && visits) {

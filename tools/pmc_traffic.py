@@ -24,7 +24,7 @@ import sys
 # compulsory HBM bytes per cell and step of the streaming kernels (each input read once, each output written once)
 COMPULSORY = {
     "d8s_kernel": (8, 1), "d8_kernel": (8, 1), "minmax_kernel": (4, 0), "pf_apply_check_kernel": (6, 8), "pf_apply_kernel": (6, 8),
-    "pf_tile_kernel": (4, 2), "ng_first_kernel": (4, 6.2), "ng_finish_kernel": (12, 8), "ccl_tile_kernel": (4, 4),
+    "pf_tile_kernel": (4, 2), "ng_first_kernel": (4, 5.1), "ng_finish_kernel": (12, 8), "ccl_tile_kernel": (4, 4),
     "ccl_emit_ranked_kernel": (4, 4), "stats_kernel": (8, 0), "count_kernel": (4, 0), "ws_tile_kernel": (5, 4), "ws_assign_hop_kernel": (8, 4),
     "arg_packed_kernel": (12, 0), "accum_tile_kernel": (1, 2), "accum_final_walk_kernel": (3, 8), "fill_check_kernel": (8, 0), "depths_kernel": (8, 4),
 }

@@ -56,6 +56,20 @@ def test_levels_in_many_binades_negative_elevations_and_minus_powers_of_two():
     check(dem * 1e4 + 7.0, algorithm=2)
 
 
+@pytest.mark.parametrize("n,levels,smooth,seed", [(200, 4, 6, 21), (333, 9, 10, 22), (640, 3, 14, 23)])
+def test_terraces_spill_cells_next_to_the_lower_lake(n, levels, smooth, seed):
+    """Natural flats on a few levels that touch each other: the sources a flat cell is NOT adjacent to (walls of pass_wl) and the
+    flat cells those sources feed on their own level (the seeds of ng_first) in every tile, across the tile seams (CPU model of the
+    argument: test_noflat_walls_model.py)."""
+    rng = np.random.default_rng(seed)
+    z = rng.random((n, n))
+    for _ in range(smooth):
+        z = (z + np.roll(z, 1, 0) + np.roll(z, -1, 0) + np.roll(z, 1, 1) + np.roll(z, -1, 1)) / 5.0
+    z = (z - z.min()) / (z.max() - z.min())
+    check(np.floor(z * levels) + 3.0, algorithm=2)                  # one binade class (3 .. 3 + levels < 8 for the first case) ...
+    check(np.floor(z * levels) * 3.0 + 1.0, algorithm=2)            # ... and several in a window
+
+
 def test_quantised_terrain_large_natural_flats():
     dem = np.round(fbm(800, 800, beta=2.5, seed=12) / 2) * 2 + 10
     check(dem, algorithm=2)

@@ -150,17 +150,6 @@ struct UniformW {   // every flat cell of the window is of one class: scalar wei
     uint32_t S, Dg;
     __device__ __forceinline__ void get(uint32_t, const uint32_t *, uint32_t &s, uint32_t &g) const { s = S; g = Dg; }
 };
-struct TwoW {       // the window's flat cells are of TWO classes (a seventh of the benchmark's tiles: it straddles one power of two): a select
-    uint32_t c1, S1, G1, S2, G2;        // instead of LaneW's two LDS reads per row, whose latency every row of a pass waited for
-    __device__ __forceinline__ void get(uint32_t mword, const uint32_t *, uint32_t &s, uint32_t &g) const
-    {
-        uint32_t c = c1;
-        asm volatile("" : "+s"(c));      // (or the compares of all rows are hoisted out of the cycles: 62 lane masks, spilled)
-        const bool first = ((mword >> 8) & 0xffu) == c;
-        s = first ? S1 : S2;
-        g = first ? G1 : G2;
-    }
-};
 struct LaneW {      // classes differ inside the window (it straddles a power of two): weights by the cell's own class
     __device__ __forceinline__ void get(uint32_t mword, const uint32_t *tab_l, uint32_t &s, uint32_t &g) const
     {
@@ -337,7 +326,7 @@ __device__ __forceinline__ void pass_wl(uint32_t (&d)[WN], const uint32_t imm_lo
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void relax_wl(uint32_t (&d)[WN], const uint32_t (&mk)[NMK], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc,
+__device__ __forceinline__ void relax_wl(uint32_t (&d)[WN], const uint32_t (&mk)[13], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc,
                                          unsigned &wake, bool &changed, bool &capped, unsigned &cycles)
 {
     const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
@@ -362,6 +351,137 @@ __device__ __forceinline__ void relax_wl(uint32_t (&d)[WN], const uint32_t (&mk)
             uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
             pass_wl<true>(d, mk[4], mk[5], S, G, (mk[8] & 4u) != 0u, (mk[8] & 8u) != 0u, acc_all, acc_first, acc_last);
             pass_wl<false>(d, mk[4], mk[5], S, G, (mk[8] & 4u) != 0u, (mk[8] & 8u) != 0u, acc_all, acc_first, acc_last);
+            const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
+            chg |= all;
+            const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
+            const unsigned l1 = (all & B1) ? 1u : 0u, l62 = (all & B62) ? 1u : 0u;
+            const unsigned f1 = (fst & B1) ? 1u : 0u, f62 = (fst & B62) ? 1u : 0u, g1 = (lst & B1) ? 1u : 0u, g62 = (lst & B62) ? 1u : 0u;
+            wake |= (e_first << 3) | (e_last << 5) | (l1 << 1) | (l62 << 7) | (f1 << 0) | (f62 << 6) | (g1 << 2) | (g62 << 8);
+            transpose32(d, scr_b, lane);
+        }
+        changed |= chg != 0;
+        if (!chg) {
+            capped = false;
+            break;
+        }
+    }
+}
+
+// ---- a window of TWO classes (a seventh of the benchmark's tiles: it straddles one power of two): the same passes with one more bit per
+// cell -- is it of the second class -- that selects the row's weights (11 instructions a row).  Two flat cells next to each other are on
+// one level, so of one class: the weights are the target's, whatever the neighbour.  mk[9..10] / mk[11..12]: the class bits of the two layouts.
+constexpr int NMK2 = 13;
+#define NG_ROW2(O, I, B, BIT)                                                                                                                \
+    "v_bfe_i32 %[k], %[c], " BIT ", 1\n\t"                                                                                                  \
+    "v_bfi_b32 %[g], %[k], %[G2], %[G1]\n\t"                                                                                                \
+    "v_bfi_b32 %[s], %[k], %[S2], %[S1]\n\t"                                                                                                \
+    "v_add_u32 %[u], %[" B "], %[s]\n\t"                                                                                                    \
+    "v_add_u32_dpp %[t], %[" B "], %[g] wave_shr:1" NG_DPP                                                                                   \
+    "v_add_u32_dpp %[k], %[" B "], %[g] wave_shl:1" NG_DPP                                                                                   \
+    "v_min3_u32 %[t], %[u], %[t], %[k]\n\t"                                                                                                 \
+    "v_bfe_i32 %[k], %[m], " BIT ", 1\n\t"                                                                                                  \
+    "v_min_u32 %[" O "], %[t], %[" I "]\n\t"                                                                                                \
+    "v_bfi_b32 %[" O "], %[k], %[" I "], %[" O "]\n\t"                                                                                      \
+    "v_bitop3_b32 %[acc], %[" O "], %[acc], %[" I "] bitop3:0xde\n\t"
+struct TwoWeights {
+    uint32_t S1, G1, S2, G2;
+};
+template <int R, int DIR>
+__device__ __forceinline__ void rows6_wl2(uint32_t (&d)[WN], const uint32_t m, const uint32_t c, const TwoWeights w, uint32_t &acc)
+{
+    static_assert((R >> 5) == ((R + 5 * DIR) >> 5), "one mask word a block");
+    uint32_t o0, o1, o2, o3, o4, o5, u, t, k, sw, gw;
+    if constexpr (DIR > 0)
+        asm volatile(NG_ROW2("o0", "i0", "b", "%[bit]") NG_ROW2("o1", "i1", "o0", "%[bit]+1") NG_ROW2("o2", "i2", "o1", "%[bit]+2")
+                     NG_ROW2("o3", "i3", "o2", "%[bit]+3") NG_ROW2("o4", "i4", "o3", "%[bit]+4") NG_ROW2("o5", "i5", "o4", "%[bit]+5")
+                     : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5), [u] "=&v"(u), [t] "=&v"(t),
+                       [k] "=&v"(k), [s] "=&v"(sw), [g] "=&v"(gw), [acc] "+v"(acc)
+                     : [b] "v"(d[R - DIR]), [i0] "v"(d[R]), [i1] "v"(d[R + DIR]), [i2] "v"(d[R + 2 * DIR]), [i3] "v"(d[R + 3 * DIR]),
+                       [i4] "v"(d[R + 4 * DIR]), [i5] "v"(d[R + 5 * DIR]), [S1] "v"(w.S1), [G1] "v"(w.G1), [S2] "v"(w.S2), [G2] "v"(w.G2), [m] "v"(m),
+                       [c] "v"(c), [bit] "n"(R & 31));
+    else
+        asm volatile(NG_ROW2("o0", "i0", "b", "%[bit]") NG_ROW2("o1", "i1", "o0", "%[bit]-1") NG_ROW2("o2", "i2", "o1", "%[bit]-2")
+                     NG_ROW2("o3", "i3", "o2", "%[bit]-3") NG_ROW2("o4", "i4", "o3", "%[bit]-4") NG_ROW2("o5", "i5", "o4", "%[bit]-5")
+                     : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5), [u] "=&v"(u), [t] "=&v"(t),
+                       [k] "=&v"(k), [s] "=&v"(sw), [g] "=&v"(gw), [acc] "+v"(acc)
+                     : [b] "v"(d[R - DIR]), [i0] "v"(d[R]), [i1] "v"(d[R + DIR]), [i2] "v"(d[R + 2 * DIR]), [i3] "v"(d[R + 3 * DIR]),
+                       [i4] "v"(d[R + 4 * DIR]), [i5] "v"(d[R + 5 * DIR]), [S1] "v"(w.S1), [G1] "v"(w.G1), [S2] "v"(w.S2), [G2] "v"(w.G2), [m] "v"(m),
+                       [c] "v"(c), [bit] "n"(R & 31));
+    d[R] = o0; d[R + DIR] = o1; d[R + 2 * DIR] = o2; d[R + 3 * DIR] = o3; d[R + 4 * DIR] = o4; d[R + 5 * DIR] = o5;
+}
+template <int R, int DIR>
+__device__ __forceinline__ uint32_t row1_wl2(uint32_t (&d)[WN], const uint32_t m, const uint32_t c, const TwoWeights w, uint32_t &acc)
+{
+    uint32_t o0, u, t, k, sw, gw;
+    const uint32_t cu = d[R];
+    asm volatile("s_nop 1\n\t" NG_ROW2("o0", "i0", "b", "%[bit]") "s_nop 1"
+                 : [o0] "=&v"(o0), [u] "=&v"(u), [t] "=&v"(t), [k] "=&v"(k), [s] "=&v"(sw), [g] "=&v"(gw), [acc] "+v"(acc)
+                 : [b] "v"(d[R - DIR]), [i0] "v"(cu), [S1] "v"(w.S1), [G1] "v"(w.G1), [S2] "v"(w.S2), [G2] "v"(w.G2), [m] "v"(m), [c] "v"(c),
+                   [bit] "n"(R & 31));
+    d[R] = o0;
+    return o0 ^ cu;
+}
+template <int R, int DIR, int N>
+__device__ __forceinline__ void blocks_wl2(uint32_t (&d)[WN], const uint32_t lo, const uint32_t hi, const uint32_t clo, const uint32_t chi, const TwoWeights w,
+                                           uint32_t &acc)
+{
+    if constexpr (N > 0) {
+        rows6_wl2<R, DIR>(d, R < 32 ? lo : hi, R < 32 ? clo : chi, w, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_wl2<R + 6 * DIR, DIR, N - 1>(d, lo, hi, clo, chi, w, acc);
+    }
+}
+template <bool DOWN>
+__device__ __forceinline__ void pass_wl2(uint32_t (&d)[WN], const uint32_t imm_lo, const uint32_t imm_hi, const uint32_t cls_lo, const uint32_t cls_hi,
+                                         const TwoWeights w, const bool edge_first, const bool edge_last, uint32_t &acc_all, uint32_t &acc_first,
+                                         uint32_t &acc_last)
+{
+#pragma unroll
+    for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]));
+    uint32_t lo = imm_lo, hi = imm_hi, clo = cls_lo, chi = cls_hi;
+    asm volatile("" : "+v"(lo), "+v"(hi), "+v"(clo), "+v"(chi));
+    if constexpr (DOWN) {
+        const uint32_t x1 = row1_wl2<1, 1>(d, lo, clo, w, acc_all);
+        acc_first |= edge_first ? x1 : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_wl2<2, 1, 10>(d, lo, hi, clo, chi, w, acc_all);
+        const uint32_t x2 = row1_wl2<TI, 1>(d, hi, chi, w, acc_all);
+        acc_last |= edge_last ? x2 : 0u;
+    } else {
+        const uint32_t x2 = row1_wl2<TI, -1>(d, hi, chi, w, acc_all);
+        acc_last |= edge_last ? x2 : 0u;
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_wl2<TI - 1, -1, 10>(d, lo, hi, clo, chi, w, acc_all);
+        const uint32_t x1 = row1_wl2<1, -1>(d, lo, clo, w, acc_all);
+        acc_first |= edge_first ? x1 : 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void relax_wl2(uint32_t (&d)[WN], const uint32_t (&mk)[NMK2], const TwoWeights w, uint32_t scr_b, int lane, int maxcyc, unsigned &wake,
+                                          bool &changed, bool &capped, unsigned &cycles)
+{
+    const uint64_t INNER = ((1ull << TI) - 1) << 1, B1 = 2ull, B62 = 1ull << TI;
+    capped = true;
+#pragma nounroll
+    for (int cyc = 0; cyc < maxcyc; ++cyc) {
+        uint64_t chg = 0;
+        ++cycles;
+        {   // lane = column, first / last = row 1 / 62
+            uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
+            pass_wl2<true>(d, mk[0], mk[1], mk[9], mk[10], w, (mk[8] & 1u) != 0u, (mk[8] & 2u) != 0u, acc_all, acc_first, acc_last);
+            pass_wl2<false>(d, mk[0], mk[1], mk[9], mk[10], w, (mk[8] & 1u) != 0u, (mk[8] & 2u) != 0u, acc_all, acc_first, acc_last);
+            const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
+            chg |= all;
+            const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
+            const unsigned l1 = (all & B1) ? 1u : 0u, l62 = (all & B62) ? 1u : 0u;
+            const unsigned f1 = (fst & B1) ? 1u : 0u, f62 = (fst & B62) ? 1u : 0u, g1 = (lst & B1) ? 1u : 0u, g62 = (lst & B62) ? 1u : 0u;
+            wake |= (e_first << 1) | (e_last << 7) | (l1 << 3) | (l62 << 5) | (f1 << 0) | (f62 << 2) | (g1 << 6) | (g62 << 8);
+            transpose32(d, scr_b, lane);
+        }
+        {   // lane = row, first / last = column 1 / 62
+            uint32_t acc_all = 0, acc_first = 0, acc_last = 0;
+            pass_wl2<true>(d, mk[4], mk[5], mk[11], mk[12], w, (mk[8] & 4u) != 0u, (mk[8] & 8u) != 0u, acc_all, acc_first, acc_last);
+            pass_wl2<false>(d, mk[4], mk[5], mk[11], mk[12], w, (mk[8] & 4u) != 0u, (mk[8] & 8u) != 0u, acc_all, acc_first, acc_last);
             const uint64_t all = __ballot(acc_all != 0), fst = __ballot(acc_first != 0), lst = __ballot(acc_last != 0);
             chg |= all;
             const unsigned e_first = (fst & INNER) ? 1u : 0u, e_last = (lst & INNER) ? 1u : 0u;
@@ -465,7 +585,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.blk + (int64_t)t * (WN * WN)), 0, WN * WN * 4, 0x00020000);
     const int Wi = (int)W;
     const int last_row = (int)(H - 1 - r0 < WN - 1 ? H - 1 - r0 : WN - 1);   // last window row inside the raster
-    uint32_t ni[WN], d[WN], mk[NMK];
+    uint32_t ni[WN], d[WN], mk[NMK2];
     uint32_t hdr;
     if constexpr (FIRST) {
         // ---- classification of the window from the plain fill F (adjacency bits = AGNPS direction codes of common.hpp:
@@ -669,7 +789,7 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         }
         const bool uniform = !__any(mism != 0u);
         // exactly two classes?  (the second one as a difference to the first: windows span neighbouring binades)
-        uint32_t two = 0;
+        uint32_t two = 0, c2v = 0;
         if (!uniform) {
             uint32_t e2 = 255u;
             fresh();
@@ -689,12 +809,13 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             }
             const int delta = (int)c2 - (int)eref;
             if (has2 && !__any(m2 != 0u) && delta >= -64 && delta < 64) two = HDR_TWO | ((uint32_t)(delta + 64) << 24);
+            c2v = c2;
         }
         hdr = HDR_ACTIVE | seams | (uniform ? HDR_UNIFORM : 0u) | ((uniform && open_tile) ? HDR_OPEN : 0u) | (eref << 16) | two;
         __builtin_amdgcn_sched_barrier(0);
         // the block: packed for a window of one class (relax_pk), the full words otherwise; none for a tile that is one flat
-        if (uniform && !open_tile) {
-            uint32_t mk[NMK] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        if ((uniform && !open_tile) || two) {
+            uint32_t mk[NMK2] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             fresh();
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
@@ -704,11 +825,19 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 mk[2 + h] |= (w & 0xff00u) == M_WALL ? bit : 0u;
                 mk[4 + h] |= (w & 0xff0000u) == 0xff0000u ? bit : 0u;
                 mk[6 + h] |= (w >> 24) == (M_WALL >> 8) ? bit : 0u;
+                if (two) {        // (flat cells only: the others never move)
+                    mk[9 + h] |= ((w & 0xffu) != 0xffu && ((w >> 8) & 0xffu) == c2v) ? bit : 0u;
+                    mk[11 + h] |= ((w & 0xff0000u) != 0xff0000u && (w >> 24) == c2v) ? bit : 0u;
+                }
             }
             mk[8] = ((ni[1] & 0x83u) != 0x83u ? 1u : 0u) | ((ni[TI] & 0x38u) != 0x38u ? 2u : 0u) |
                     ((ni[1] & 0x830000u) != 0x830000u ? 4u : 0u) | ((ni[TI] & 0x380000u) != 0x380000u ? 8u : 0u);
 #pragma unroll
             for (int k = 0; k < NMK; ++k) __builtin_amdgcn_raw_buffer_store_b32(mk[k], rb, lane * 4, k * WN * 4, 0);
+            if (two) {
+#pragma unroll
+                for (int k = NMK; k < NMK2; ++k) __builtin_amdgcn_raw_buffer_store_b32(mk[k], rb, lane * 4, k * WN * 4, 0);
+            }
         } else if (!uniform) {
 #pragma unroll
             for (int r = 0; r < WN; ++r) __builtin_amdgcn_raw_buffer_store_b32(ni[r], rb, lane * 4, r * WN * 4, 0);
@@ -744,6 +873,9 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         } else if (hdr & HDR_UNIFORM) {    // one class: bit masks (pass_wl)
 #pragma unroll
             for (int k = 0; k < NMK; ++k) mk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
+        } else if (hdr & HDR_TWO) {        // two classes: the class bits as well (pass_wl2)
+#pragma unroll
+            for (int k = 0; k < NMK2; ++k) mk[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, k * WN * 4, 0);
         } else {
 #pragma unroll
             for (int r = 0; r < WN; ++r) ni[r] = __builtin_amdgcn_raw_buffer_load_b32(rb, lane * 4, r * WN * 4, 0);
@@ -770,9 +902,14 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
         }
     }
     else if (hdr & HDR_TWO) {
-        const uint32_t c2 = eref + ((hdr >> 24) & 0x7fu) - 64u;
-        const auto sc = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)tab_l[i]); };      // (scalars: the window's registers are full)
-        relax(d, ni, TwoW{eref, sc(eref), sc(256 + eref), sc(c2 & 0xffu), sc(256 + (c2 & 0xffu))}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+        const uint32_t c2 = (eref + ((hdr >> 24) & 0x7fu) - 64u) & 0xffu;
+#pragma unroll
+        for (int r = 0; r < WN; ++r) d[r] |= (uint32_t)__builtin_amdgcn_sbfe((int)mk[2 + (r >> 5)], r & 31, 1) & DINF;
+        relax_wl2(d, mk, TwoWeights{tab_l[eref], tab_l[256 + eref], tab_l[c2], tab_l[256 + c2]}, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
+        if (changed) {
+#pragma unroll
+            for (int r = 1; r <= TI; ++r) d[r] &= ~(uint32_t)__builtin_amdgcn_sbfe((int)mk[2 + (r >> 5)], r & 31, 1);
+        }
     } else relax(d, ni, LaneW{}, tab_l, scr_b, lane, a.maxcyc, wake, changed, capped, cycles);
     wake &= hdr & 0x1ffu;
 #ifdef NG_PROFILE

@@ -583,7 +583,8 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
     const int64_t org = r0 * W + c0;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(a.d + org), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(a.blk + (int64_t)t * (WN * WN)), 0, WN * WN * 4, 0x00020000);
-    const int Wi = (int)W;
+    int Wi = (int)W;
+    asm volatile("" : "+s"(Wi));   // (a new name per tile: or the 64 row offsets r * Wi * 4 are hoisted out of the tile loop and live -- spilled into VGPR lanes -- through all of it)
     const int last_row = (int)(H - 1 - r0 < WN - 1 ? H - 1 - r0 : WN - 1);   // last window row inside the raster
     uint32_t ni[WN], d[WN], mk[NMK2];
     uint32_t hdr;

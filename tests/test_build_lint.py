@@ -28,18 +28,24 @@ def test_no_full_wave_value_is_spilled_under_narrowed_exec(tmp_path):
     assert len(srcs) >= 8
     with ThreadPoolExecutor(max_workers=4) as ex:
         outs = list(ex.map(lambda s: _isa(s, tmp_path / (s.stem + ".s")), srcs))
-    nkern, bad, scratch = 0, [], {}
+    nkern, bad, scratch, geo = 0, [], {}, {}
     for o in outs:
         nkern += sum(1 for _ in lint_exec_spills.kernels(str(o)))
         bad += lint_exec_spills.lint(str(o))
         if o.stem == "fill":
             scratch = lint_exec_spills.private_segments(str(o))
+        if o.stem == "noflat_geo":
+            geo = lint_exec_spills.private_segments(str(o))
     assert nkern >= 40            # the lint really saw the kernels
     assert not bad, bad
     # the fill kernels hold their 64 x 64 windows in registers by design: any private segment means the window spilled
     # (the build that faulted on 3 Oct had 100 bytes of it); every shipped fill kernel must have none
     assert sum("fill_round_kernel" in k for k in scratch) >= 5, scratch
     assert all(v == 0 for v in scratch.values()), scratch
+    # so do the geodesic no-flats kernels since the windows of one and two classes relax on bit masks (end of round 3: 64 registers of
+    # distances + 13 mask words; the full adjacency words only for windows of three or more classes)
+    hot = {k: v for k, v in geo.items() if "ng_round_kernel" in k or "ng_first_kernel" in k}
+    assert len(hot) == 2 and all(v == 0 for v in hot.values()), geo
 
 
 def test_lint_catches_the_pattern(tmp_path):

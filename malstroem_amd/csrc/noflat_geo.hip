@@ -501,29 +501,66 @@ __device__ __forceinline__ void relax_wl2(uint32_t (&d)[WN], const uint32_t (&mk
 // ---- a tile that is ONE flat (every cell of the 62 x 62 interior is adjacent to all of its 8 neighbours, one class): no masks --
 // the interior of the lakes the tail rounds spend their time in.  Per row: min(left, right of the row behind) + Dg, the cell
 // behind + S, min3 with the cell itself; the two ring lanes are put back (they belong to the neighbouring tiles).
+#define NG_ROW_OPEN(O, I, B)                                                                                                                 \
+    "v_add_u32 %[u], %[" B "], %[S]\n\t"                                                                                                    \
+    "v_add_u32_dpp %[t], %[" B "], %[G] wave_shr:1" NG_DPP                                                                                   \
+    "v_add_u32_dpp %[k], %[" B "], %[G] wave_shl:1" NG_DPP                                                                                   \
+    "v_min3_u32 %[t], %[u], %[t], %[k]\n\t"                                                                                                 \
+    "v_min_u32 %[" O "], %[t], %[" I "]\n\t"                                                                                                \
+    "v_cndmask_b32_e64 %[" O "], %[" O "], %[" I "], %[ring]\n\t"                                                                            \
+    "v_bitop3_b32 %[acc], %[" O "], %[acc], %[" I "] bitop3:0xde\n\t"
+template <int R, int DIR>
+__device__ __forceinline__ void rows6_open(uint32_t (&d)[WN], const uint64_t ring, const uint32_t S, const uint32_t G, uint32_t &acc)
+{
+    uint32_t o0, o1, o2, o3, o4, o5, u, t, k;
+    asm volatile(NG_ROW_OPEN("o0", "i0", "b") NG_ROW_OPEN("o1", "i1", "o0") NG_ROW_OPEN("o2", "i2", "o1") NG_ROW_OPEN("o3", "i3", "o2")
+                 NG_ROW_OPEN("o4", "i4", "o3") NG_ROW_OPEN("o5", "i5", "o4")
+                 : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [o4] "=&v"(o4), [o5] "=&v"(o5), [u] "=&v"(u), [t] "=&v"(t), [k] "=&v"(k),
+                   [acc] "+v"(acc)
+                 : [b] "v"(d[R - DIR]), [i0] "v"(d[R]), [i1] "v"(d[R + DIR]), [i2] "v"(d[R + 2 * DIR]), [i3] "v"(d[R + 3 * DIR]), [i4] "v"(d[R + 4 * DIR]),
+                   [i5] "v"(d[R + 5 * DIR]), [S] "v"(S), [G] "v"(G), [ring] "s"(ring));
+    d[R] = o0; d[R + DIR] = o1; d[R + 2 * DIR] = o2; d[R + 3 * DIR] = o3; d[R + 4 * DIR] = o4; d[R + 5 * DIR] = o5;
+}
+template <int R, int DIR>
+__device__ __forceinline__ uint32_t row1_open(uint32_t (&d)[WN], const uint64_t ring, const uint32_t S, const uint32_t G, uint32_t &acc)
+{
+    uint32_t o0, u, t, k;
+    const uint32_t cu = d[R];
+    asm volatile("s_nop 1\n\t" NG_ROW_OPEN("o0", "i0", "b") "s_nop 1"
+                 : [o0] "=&v"(o0), [u] "=&v"(u), [t] "=&v"(t), [k] "=&v"(k), [acc] "+v"(acc)
+                 : [b] "v"(d[R - DIR]), [i0] "v"(cu), [S] "v"(S), [G] "v"(G), [ring] "s"(ring));
+    d[R] = o0;
+    return o0 ^ cu;
+}
+template <int R, int DIR, int N>
+__device__ __forceinline__ void blocks_open(uint32_t (&d)[WN], const uint64_t ring, const uint32_t S, const uint32_t G, uint32_t &acc)
+{
+    if constexpr (N > 0) {
+        rows6_open<R, DIR>(d, ring, S, G, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_open<R + 6 * DIR, DIR, N - 1>(d, ring, S, G, acc);
+    }
+}
+// (the rows as text, like pass_wl: 7 instructions in 7 issue slots; the compiler's version had two s_nop in front of the DPP reads)
 template <bool DOWN>
 __device__ __forceinline__ void pass_open(uint32_t (&d)[WN], const uint32_t S, const uint32_t G, const bool ring_lane, uint32_t &acc_all, uint32_t &acc_first,
                                           uint32_t &acc_last)
 {
-    constexpr int first = DOWN ? 1 : TI, dir = DOWN ? 1 : -1;
 #pragma unroll
     for (int r = 0; r < WN; ++r) asm volatile("" : "+v"(d[r]));
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int r = first + dir * i;
-        const uint32_t behind = d[r - dir];
-        const uint32_t m2 = min(from_left(behind), from_right(behind));
-        const uint32_t cu = d[r];
-        uint32_t nv = min(min(behind + S, m2 + G), cu);
-        nv = ring_lane ? cu : nv;
-        const uint32_t x = nv ^ cu;
-        acc_all |= x;
-        asm volatile("" : "+v"(acc_all));
-        if (r == 1) acc_first |= x;
-        if (r == TI) acc_last |= x;
-        d[r] = nv;
+    const uint64_t ring = __ballot(ring_lane);
+    if constexpr (DOWN) {
+        acc_first |= row1_open<1, 1>(d, ring, S, G, acc_all);
         __builtin_amdgcn_sched_barrier(0);
+        blocks_open<2, 1, 10>(d, ring, S, G, acc_all);
+        acc_last |= row1_open<TI, 1>(d, ring, S, G, acc_all);
+    } else {
+        acc_last |= row1_open<TI, -1>(d, ring, S, G, acc_all);
+        __builtin_amdgcn_sched_barrier(0);
+        blocks_open<TI - 1, -1, 10>(d, ring, S, G, acc_all);
+        acc_first |= row1_open<1, -1>(d, ring, S, G, acc_all);
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ void relax_open(uint32_t (&d)[WN], const uint32_t S, const uint32_t G, uint32_t scr_b, int lane, int maxcyc, unsigned &wake,

@@ -136,3 +136,58 @@ def test_tile_kernels_keep_their_resident_workgroups(tmp_path):
             hit = [v for k, v in res.items() if frag in k]
             assert hit, (fn, frag, sorted(res)[:5])
             assert all(v[3] >= n for v in hit), (fn, frag, hit)
+
+
+def _dpp_hazards(asm_text, kernel_frag):
+    """DPP instructions of a kernel with a source VGPR written by one of the two instructions in front (gfx9: a VALU write needs two wait
+    states before a DPP read; the compiler pads its own code with s_nop but does not look inside inline-asm text)"""
+    import re
+    bad, inside, hist = [], False, []          # hist: (wait states this line provides, registers it writes)
+    for line in asm_text.splitlines():
+        if re.match(r"^_Z\w+:", line):
+            inside, hist = kernel_frag in line, []
+            continue
+        if not inside:
+            continue
+        t = line.strip()
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        if t.startswith("s_endpgm"):
+            inside = False
+            continue
+        op, _, rest = t.partition(" ")
+        ops = [o.strip() for o in rest.split(";")[0].split(",")]
+        if op == "s_nop":
+            hist.append((int(ops[0], 0) + 1, set()))
+            continue
+        regs = lambda o: (set(range(int(m.group(1)), int(m.group(2)) + 1)) if (m := re.match(r"v\[(\d+):(\d+)\]", o)) else
+                          ({int(o[1:])} if re.fullmatch(r"v\d+", o) else set()))
+        if "_dpp" in op or " wave_sh" in t or " row_sh" in t or "quad_perm" in t:
+            srcs = set().union(*[regs(o.split(" ")[0]) for o in ops[1:]]) if len(ops) > 1 else set()
+            need, k = 2, len(hist) - 1
+            while need > 0 and k >= 0:
+                ws, wr = hist[k]
+                if wr & srcs:
+                    bad.append(t)
+                    break
+                need -= ws
+                k -= 1
+        writes = regs(ops[0]) if op.startswith("v_") and ops else set()
+        hist.append((1, writes))
+        hist = hist[-6:]
+    return bad
+
+
+@pytest.mark.timeout(600)
+def test_no_dpp_read_within_two_slots_of_the_write_in_the_hand_written_rows(tmp_path):
+    """The no-flats passes are inline-asm text (NG_ROW, NG_ROW2, NG_ROW_OPEN in noflat_geo.hip) with the DPP hazard kept by instruction
+    order: the row behind is written by the last-but-one instruction of a row and read through DPP by the second of the next."""
+    text = _isa(CSRC / "noflat_geo.hip", tmp_path / "noflat_geo.s").read_text()
+    assert text.count("_dpp") > 500
+    assert _dpp_hazards(text, "ng_round_kernel") == []
+    assert _dpp_hazards(text, "ng_first_kernel") == []
+    # the checker sees the pattern
+    demo = "_Zdemo_kernel:\n\tv_bfi_b32 v5, v1, v2, v3\n\tv_add_u32 v6, v5, v7\n\tv_add_u32_dpp v8, v5, v9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_endpgm\n"
+    assert len(_dpp_hazards(demo, "demo_kernel")) == 1
+    demo_ok = demo.replace("\tv_add_u32 v6, v5, v7\n", "\tv_add_u32 v6, v5, v7\n\ts_nop 0\n")
+    assert _dpp_hazards(demo_ok, "demo_kernel") == []

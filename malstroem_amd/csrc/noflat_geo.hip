@@ -24,10 +24,14 @@
 // relaxation from scratch.
 //
 // Kernels.  ng_first (every tile once, one wavefront per 62 x 62 tile + ring): classifies the window from F -- per cell a 16-bit
-// word = same-level adjacency byte | binade class << 8 -- builds the words of both layouts the passes want and keeps them as a
-// 16 KB block per tile + a header; writes the start distances.  ng_round (one launch per round, tiles from a compacted list): a
+// word = same-level adjacency byte | binade class << 8 -- and keeps what the passes want as a block per tile + a header: for a
+// window of one or two classes (all but a handful) bit masks -- may the cell move, is it a WALL (a source that a flat cell next to it
+// is not adjacent to: see pass_wl), is it of the second class --, for three or more classes the words of both layouts (16 KB); writes
+// the start distances (a flat cell next to a wall of its own level starts from its step weight: the seeds).  ng_round (one launch
+// per round, tiles from a compacted list): a
 // wavefront holds the 64 x 64 window of distances in 64 VGPRs and relaxes it by row-sequential passes (down, up; transposed
-// through wave-private LDS: right, left) with DPP neighbours; a tile whose edge cells moved marks the neighbouring tiles it
+// through wave-private LDS: right, left) with DPP neighbours, the rows of a pass written out as text (NG_ROW: 8 instructions in 8
+// issue slots); a tile whose edge cells moved marks the neighbouring tiles it
 // shares a flat with (one byte per tile, plain stores); ng_compact turns the marks into the next round's list.  Once the rounds
 // are small (the tail) they append the woken tiles to the next round's list themselves and the compaction launch goes.
 // ng_finish (streaming): G = F + u * D assembled in registers, (*) checked against the eight neighbours, G written.
@@ -146,10 +150,6 @@ __device__ __forceinline__ void transpose32(uint32_t (&x)[WN], uint32_t scr_b, i
     for (int c = 0; c < WN; ++c) asm volatile("" : "+v"(x[c]));   // uses stay behind the wait
 }
 
-struct UniformW {   // every flat cell of the window is of one class: scalar weights
-    uint32_t S, Dg;
-    __device__ __forceinline__ void get(uint32_t, const uint32_t *, uint32_t &s, uint32_t &g) const { s = S; g = Dg; }
-};
 struct LaneW {      // classes differ inside the window (it straddles a power of two): weights by the cell's own class
     __device__ __forceinline__ void get(uint32_t mword, const uint32_t *tab_l, uint32_t &s, uint32_t &g) const
     {

@@ -1251,7 +1251,7 @@ struct GeoRun::Impl {
     unsigned long long irregular = 0;
 };
 namespace {
-constexpr int MAXR = 8192, BATCH = 16;
+constexpr int MAXR = 8192, BATCH = 32, BATCH_HEAD = 16;   // rounds per host read-back: in the tail (a read-back is ~30 us of idle device) / before it
 constexpr uint32_t LIGHT_TILES = 6144;     // a round of at most this many tiles appends to the next list (one atomic per wake)
 __global__ void ng_mark_row_kernel(uint8_t *mark, int ti, int ntc)
 {
@@ -1416,8 +1416,9 @@ int GeoRun::batch(hipStream_t s, bool *active)
     static const bool no_light = dev_env("MHIP_NG_NOLIGHT") != nullptr;   // development knob
     // rounds per host read-back; MHIP_NG_BATCH (tests): a small batch makes small rasters reach the self-listing tail rounds too
     const char *eb = dev_env("MHIP_NG_BATCH");
-    const int nb = eb && atoi(eb) >= 1 && atoi(eb) <= BATCH ? atoi(eb) : BATCH;
+    const int nb_env = eb && atoi(eb) >= 1 && atoi(eb) <= BATCH ? atoi(eb) : 0;
     for (;;) {
+        const int nb = nb_env ? nb_env : (m.light ? BATCH : BATCH_HEAD);
         if (m.round + BATCH > MAXR) {
             set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
             return MHIP_ENOTCONV;

@@ -653,11 +653,17 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 so = r < last_row ? so + Wi : so;
             }
             float upl = PINF, up = PINF, upr = PINF, cul = fleft(f[0]), cur = fright(f[0]);
+            float h_up = PINF, h_cu = fminf(fminf(cul, f[0]), cur);      // minimum of a row's three cells around this column: row r - 1, row r
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
                 const float V = f[r], dn = r + 1 < WN ? f[r + 1] : PINF;
                 const float dnl = r + 1 < WN ? fleft(dn) : PINF, dnr = r + 1 < WN ? fright(dn) : PINF;
-                const bool lower = (upl < V) | (up < V) | (upr < V) | (cul < V) | (cur < V) | (dnl < V) | (dn < V) | (dnr < V);
+                // (one compare with the minimum of the eight instead of eight compares and seven scalar ORs: the classification is bound by
+                // the instructions a wavefront issues; a NaN neighbour is no minimum and was never "lower" either)
+                const float h_dn = fminf(fminf(dnl, dn), dnr);
+                const bool lower = fminf(fminf(h_up, h_dn), fminf(cul, cur)) < V;
+                h_up = h_cu;
+                h_cu = h_dn;
                 // raster border rows are sources; a band's halo rows are the neighbour's cells (ring-like: never moved here, known
                 // only as far as this window can tell); window rows beyond the local raster are nothing
                 const bool border = INNER ? false : (lane_border | (ti == 0 && r == 0 && !a.fixed_top) | (r == border_row && !a.fixed_bot) | (r > border_row));

@@ -654,6 +654,8 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
             }
             float upl = PINF, up = PINF, upr = PINF, cul = fleft(f[0]), cur = fright(f[0]);
             float h_up = PINF, h_cu = fminf(fminf(cul, f[0]), cur);      // minimum of a row's three cells around this column: row r - 1, row r
+            // (the class's table entry one row ahead: read in the row before, or every row waits for its LDS round trip)
+            uint32_t e_cu = class_above(f[0]), tv_cu = tab_l[e_cu & 0xffu];
 #pragma unroll
             for (int r = 0; r < WN; ++r) {
                 const float V = f[r], dn = r + 1 < WN ? f[r + 1] : PINF;
@@ -672,10 +674,12 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
                 // (no branches on per-lane values here: selects only -- see tools/lint_exec_spills.py)
                 const uint32_t adj = (up == V ? 1u : 0u) | (upr == V ? 2u : 0u) | (cur == V ? 4u : 0u) | (dnr == V ? 8u : 0u) |
                                      (dn == V ? 16u : 0u) | (dnl == V ? 32u : 0u) | (cul == V ? 64u : 0u) | (upl == V ? 128u : 0u);
-                const uint32_t e = class_above(V);
+                const uint32_t e = e_cu, tv = tv_cu;
+                e_cu = r + 1 < WN ? class_above(dn) : 255u;
+                tv_cu = tab_l[e_cu & 0xffu];
                 const bool cell = lane_in_c & !border & !ring;     // an interior raster cell of this tile
                 const bool flat = cell & !src;
-                const bool regular = flat & (adj != 0u) & (e < 253u) & (tab_l[e & 0xffu] != 0u);     // (253 .. 255: M_IRR, M_WALL, M_NOFLAT)
+                const bool regular = flat & (adj != 0u) & (e < 253u) & (tv != 0u);     // (253 .. 255: M_IRR, M_WALL, M_NOFLAT)
                 const bool nan = cell & (V != V);
                 const bool irregular = flat & !regular & !nan;     // a level without integer weights: left to the float64 relaxation
                 nirr += irregular ? 1u : 0u;

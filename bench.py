@@ -52,6 +52,9 @@ ALG_BYTES = {"fill": 8, "noflat": 12, "flowdir": 9, "accum": 9, "label": 12 + 8 
 #   watershed : 9 B (1 + 4 R, 4 W) + label_count 4 B
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the device-copy ceiling is measured below
 STAGES = ["fill", "noflat", "flowdir", "accum", "label", "watershed", "pourpoints"]
+ENGINE_NOTE = ("fill_algorithm 1 = tiled priority-flood (0 iterative schedule, 4 flood + iterative repair); noflat_algorithm 2 = integer "
+               "geodesic transform (3 + float64 relaxation of irregular flats, 0 float64 relaxation); pour_algorithm 1 = keys out of the "
+               "accumulation's final pass (0 pass over accumulation + labels)")
 BAND_CELL_LIMIT = 2 ** 30   # cells per band context the bench aims for (hard limit of a context: 2**31 - 2)
 
 
@@ -123,20 +126,56 @@ STAGE_KERNELS = {"flowdir": ("d8_kernel", "d8s_kernel"), "fill": ("fill_round_ke
                  "pourpoints": ("arg_", "pour_")}
 
 
-def pmc_traffic(stage, n):
-    """HBM bytes of the stage's kernels from the newest committed rocprofv3 PMC table (profiles/*_pmc_hbm_traffic.json, made
-    by tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs at 16384^2)."""
-    tables = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
-    if n != 16384 or not tables or stage not in STAGE_KERNELS:
+FETCH_NOTE = ("FETCH_SIZE x 2 (calibrated on the streaming kernels of the same run, tools/pmc_traffic.py): exact for coalesced "
+              "streams, an UPPER BOUND for kernels that gather scattered sectors (ccl_*, ws_*, accum_*, ng_round, pf_link)")
+
+
+def lib_fingerprint():
+    """sha256 (16 hex digits) of the shipped libmalstroem_hip.so: the PMC table records the library it was collected with"""
+    import hashlib
+    from malstroem_amd import _lib
+    try:
+        return hashlib.sha256(Path(_lib.LIB_PATH).read_bytes()).hexdigest()[:16]
+    except Exception:
         return None
+
+
+def pmc_table(n):
+    """(rows, meta, path) of the newest committed rocprofv3 PMC table (profiles/*_pmc_hbm_traffic.json, made by
+    tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs of `bench.py --steps 1 --warmup 0` at 16384^2)."""
+    tables = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
+    if n != 16384 or not tables:
+        return None, None, None
     path = tables[-1]
-    tot = 0.0
-    for row in json.loads(path.read_text()):
+    doc = json.loads(path.read_text())
+    if isinstance(doc, dict):                      # round 4 on: {"meta": {...}, "kernels": [...]}
+        return doc["kernels"], doc.get("meta", {}), path
+    return doc, {}, path
+
+
+def pmc_traffic(stage, n):
+    """HBM bytes of the stage's kernels from the committed PMC table: per STEP for a stage (the table is one step of the chain),
+    per LAUNCH for the D8 stencil (every d8s_kernel launch of the profiled command is one full pass over the surface)."""
+    rows, meta, path = pmc_table(n)
+    if rows is None or stage not in STAGE_KERNELS:
+        return None
+    tot, launches = 0.0, 0
+    for row in rows:
         if row["kernel"].startswith(STAGE_KERNELS[stage]):
             tot += (row["fetch_size_kb"] * 2.0 + row["write_size_kb"]) * 1024.0
+            launches += int(row.get("launches", 1))
     if tot == 0.0:
         return None
-    return {"hbm_bytes_per_stage": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "source": "profiles/" + path.name}
+    fp = lib_fingerprint()
+    out = {"source": "profiles/" + path.name, "fetch_correction": FETCH_NOTE,
+           "table_library": meta.get("library_sha256_16"), "table_matches_this_library": bool(fp and meta.get("library_sha256_16") == fp)}
+    if stage == "flowdir":
+        tot /= max(launches, 1)
+        out.update({"hbm_bytes_per_launch": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "launches_in_table": launches})
+    else:
+        tot /= max(int(meta.get("steps", 1)), 1)
+        out.update({"hbm_bytes_per_step": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2)})
+    return out
 
 
 def host_cpu():
@@ -224,6 +263,9 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="2: 4096^2, fill + D8 only (BASELINE configs[1])")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true",
+                    help="band runs: after the timed steps compare every band's rasters (sha256 of its owned rows) and the label count with ONE "
+                         "undivided context on rank 0 (the DEM must fit one context: < 2**31 cells); exit code 6 on a difference")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -333,6 +375,12 @@ def main():
                 for s in ("fill", "noflat"):      # the stage's dominant kernel, HIP events around its launches inside the library
                     hot_ms[s] += pipe.get_float(s + "_hot_ms")
                     hot_launches[s] = pipe.get_int(s + "_hot_launches")
+                for k in engines_seen:            # EVERY timed step, not just the last one: an intermittent fall-back must not hide
+                    engines_seen[k].add(pipe.get_int(k))
+
+    engines_seen = {"fill_algorithm": set(), "noflat_algorithm": set()}
+    if not config2:
+        engines_seen["pour_algorithm"] = set()
 
     def barrier():
         if pipe is not None:
@@ -355,25 +403,97 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+    # A silent engine fall-back (capacity overflow of the flood, a rejected geodesic transform, pour points by the general pass)
+    # gives right results 2-3x slower: the line must not publish such a run as the design's number.  MALSTROEM_BENCH_ALLOW_FALLBACK=1
+    # reports it anyway (deliberate A/B runs; DEMs other than the default ones may legitimately take another engine).
+    allow_fallback = os.environ.get("MALSTROEM_BENCH_ALLOW_FALLBACK", "") == "1"
+    fell_back = []
+    if pipe is not None:
+        want = {"fill_algorithm": (1,), "noflat_algorithm": (2,)}
+        if not config2:
+            want["pour_algorithm"] = (1,)
+        fell_back = ["%s=%s" % (k, sorted(engines_seen[k])) for k, ok in want.items() if not engines_seen[k] <= set(ok)]
+    for w in workers:
+        if w.error is None and w.pipe is not None:
+            e = w.pipe.engines()
+            if e.get("fill") not in (1, None) or e.get("noflat") not in (2, 3, None):
+                fell_back.append("band %d: %r" % (w.pipe.comm.rank, e))
+    if fell_back and not allow_fallback:
+        print("bench.py: rank %d: a stage fell back to its slow engine (%s); no metric is reported "
+              "(MALSTROEM_BENCH_ALLOW_FALLBACK=1 reports it anyway)" % (rank, ", ".join(fell_back)), file=sys.stderr)
+        if workers:
+            workers[0].error = workers[0].error or RuntimeError("engine fall-back")
+        else:
+            shutdown(5)
     if failed():
         if rank == 0:
-            print("bench.py: the band chain failed on at least one rank; no metric is reported", file=sys.stderr)
+            print("bench.py: the band chain failed (or fell back to a slow engine) on at least one rank; no metric is reported", file=sys.stderr)
         shutdown(4)
+
+    check_note = None
+    if args.check and band_mode:
+        # the launch shapes the driver uses (N processes x k bands) rehearsed at a size one context holds: every band's rasters against
+        # the undivided result, bit for bit
+        import hashlib
+        names = ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")
+        mine = []
+        for w in workers:
+            p = w.pipe
+            mine.append((int(p.row0), int(p.nrows), int(p.nlabels), {k: hashlib.sha256(np.ascontiguousarray(p.download(k)).tobytes()).hexdigest() for k in names}))
+        everyone = [mine]
+        if dist is not None:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+        bad = []
+        if rank == 0:
+            assert cells < 2 ** 31 - 2, "--check needs a DEM that fits one context"
+            with HydroPipeline((n, n), device=device) as one:
+                one.upload("dem", src.rows(0, n))
+                one.run(*stage_names)
+                one.sync()
+                nlab = one.get_int("nlabels")
+                whole = {k: one.download(k) for k in names}
+            for per_rank in everyone:
+                for row0, nrows, nl, digests in per_rank:
+                    if nl != nlab:
+                        bad.append("rows %d..%d: %d labels, one context %d" % (row0, row0 + nrows, nl, nlab))
+                    for k in names:
+                        if hashlib.sha256(np.ascontiguousarray(whole[k][row0:row0 + nrows]).tobytes()).hexdigest() != digests[k]:
+                            bad.append("rows %d..%d: %s differs from the undivided context" % (row0, row0 + nrows, k))
+            check_note = "%d bands x 7 rasters + label count == one undivided context" % nbands if not bad else "; ".join(bad)
+        flag = 1.0 if bad else 0.0
+        if dist is not None:
+            import torch
+            t = torch.tensor([flag], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            flag = float(t[0])
+        if flag:
+            if rank == 0:
+                print("bench.py --check: the band run differs from one undivided context: %s" % check_note, file=sys.stderr)
+            shutdown(6)
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = cells * args.steps / elapsed / 1e6           # ONE DEM whatever N is: whole-job cells per second
     # The D8 stencil on its own (BASELINE's second figure): in the chain the no-flats fill's finishing pass writes the flow directions
     # from the surface it holds in registers and the `flowdir` stage is an empty interval, so the kernel is timed as a request of
     # its own on the resident surface, after the timed steps (HIP events on its stream, like every stage).
-    d8_alone_ms = None
+    d8_alone_ms = d8_single_ms = None
     if pipe is not None:
+        # steady-state stencil throughput: 16 launches back to back between ONE pair of HIP events on the kernel's stream
+        # (mhip_ctx_kernel_ms "d8_steady"), best-of-3 is NOT taken: the mean of three such batches
+        acc = 0.0
+        for _ in range(3):
+            ms, nl = pipe.kernel_ms("d8_steady")
+            acc += ms / nl
+        d8_alone_ms = acc / 3
+        # ... and, for comparison, one request bracketed by its own pair of events (what round 3 reported: + the event bracket)
         reps, acc = 5, 0.0
         for _ in range(reps):
-            for _ in range(4):           # back to back: the events of the last request bracket a launch on a busy device, like in the chain
+            for _ in range(4):
                 pipe.run("flowdir")
             pipe.sync()
             acc += pipe.stage_ms("flowdir")
-        d8_alone_ms = acc / reps
+        d8_single_ms = acc / reps
     if band_mode:
         for s in stage_names:
             stage_ms[s] = max(w.timings.get(s, 0.0) for w in workers) / args.steps   # host wall clock per stage, slowest band of this rank
@@ -382,7 +502,8 @@ def main():
             for k2, v in w.host_ms.items():
                 host_serial[k2] = max(host_serial.get(k2, 0.0), v / args.steps)
         info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands,
-                "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side),
+                "band_engines": [w.pipe.engines() for w in workers], "engines": ENGINE_NOTE,
+                "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side), "check": check_note,
                 # thread CPU time per step of the host-only sections of the boundary systems (label / accumulation / watershed
                 # seams), maximum over the bands of rank 0: what does not shrink with the number of GPUs
                 "host_serial_ms": {k2: round(v, 2) for k2, v in sorted(host_serial.items())},
@@ -392,11 +513,11 @@ def main():
             stage_ms[s] /= args.steps
         keys = ("fill_rounds", "noflat_rounds", "fill_tiles", "fill_visits", "fill_cycles", "noflat_visits", "noflat_cycles") + (() if config2 else ("nlabels",))
         info = {k: pipe.get_int(k) for k in keys}
-        for k in ("fill_algorithm", "fill_launches"):
-            try:
-                info[k] = pipe.get_int(k)
-            except Exception:
-                pass
+        for k in ("fill_algorithm", "fill_launches", "noflat_algorithm") + (() if config2 else ("pour_algorithm",)):
+            info[k] = pipe.get_int(k)
+        info["engines"] = ENGINE_NOTE
+        if info["noflat_algorithm"] not in (2, 3):
+            info["noflat_reject"] = {k: pipe.get_int("noflat_reject" + k) for k in ("", "_irregular", "_unreached", "_mismatch")}
     if rank == 0:
         stages = {}
         for s in stage_names:
@@ -417,7 +538,12 @@ def main():
                 stages["flowdir"].update({"achieved_GBs": None, "frac_of_hbm_peak": None,
                                           "fused_into": "noflat (ng_finish_kernel writes the directions; d8_roofline times the stencil on its own)"})
             gbs = ALG_BYTES["flowdir"] * cells / (d8_alone_ms * 1e-3) / 1e9
-            d8 = {"ms": round(d8_alone_ms, 3), "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+            d8 = {"ms": round(d8_alone_ms, 4), "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        if "pourpoints" in stages and info.get("pour_algorithm") == 1:
+            # the 12 B/cell pass over accumulation + labels does not run: the keys come out of the accumulation's final pass and the
+            # stage is pour_finish_kernel over one key per label
+            stages["pourpoints"].update({"achieved_GBs": None, "frac_of_hbm_peak": None, "alg_bytes_per_cell": None,
+                                         "fused_into": "accum (accum_final_walk_kernel writes one key per label; this stage turns keys into records)"})
         copy_gbs = read_gbs = None
         try:
             copy_gbs = round(pipe.copy_bandwidth(), 1) if pipe is not None else None
@@ -436,15 +562,22 @@ def main():
             kms = hot_ms[stage] / args.steps
             out_ = {"name": KERNEL_OF_STAGE[stage], "launches_per_step": hot_launches[stage], "ms_per_step": round(kms, 3),
                     "avg_launch_us": round(1e3 * kms / max(hot_launches[stage], 1), 1), "timed_by": "HIP events around the launches, on their stream"}
-            tables = sorted((ROOT / "profiles").glob("*_pmc_hbm_traffic.json"))
-            if n == 16384 and tables:
-                for row in json.loads(tables[-1].read_text()):
+            rows, meta, path = pmc_table(n)
+            fp = lib_fingerprint()
+            if rows is not None and fp and meta.get("library_sha256_16") == fp:
+                # counter-based figures (HBM bytes the kernel MOVED / its time), only when the table was collected with this very
+                # library: they are traffic, not the algorithmic fraction the `frac` keys of this line carry
+                for row in rows:
                     if row["kernel"].startswith(KERNEL_OF_STAGE[stage]):
-                        own = (2.0 * row["fetch_size_kb"] + row["write_size_kb"]) * 1024.0
-                        out_.update({"hbm_bytes_per_step": round(own), "hbm_bytes_per_cell": round(own / cells, 2),
-                                     "achieved_GBs": round(own / (kms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "traffic_source": "profiles/" + tables[-1].name})
+                        own = (2.0 * row["fetch_size_kb"] + row["write_size_kb"]) * 1024.0 / max(int(meta.get("steps", 1)), 1)
+                        out_.update({"traffic_bytes_per_step": round(own), "traffic_bytes_per_cell": round(own / cells, 2),
+                                     "traffic_GBs": round(own / (kms * 1e-3) / 1e9, 1),
+                                     "traffic_frac_of_hbm_peak": round(own / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "traffic_source": "profiles/" + path.name, "fetch_correction": FETCH_NOTE})
                         break
+            elif rows is not None:
+                out_["traffic_note"] = "profiles/%s was collected with another build of the library (%s != %s): no counter figures" % (
+                    path.name, meta.get("library_sha256_16"), fp)
             return out_
         out = {
             "metric": ("Mcells/s fill->D8 on %d^2 f32 DEM" if config2 else "Mcells/s fill->D8->accum->label on %d^2 f32 DEM") % n,
@@ -462,7 +595,10 @@ def main():
                          "measured_copy_peak_GBs": copy_gbs, "measured_read_peak_GBs": read_gbs,
                          "note": "dominant stage by %s; algorithmic bytes of the whole stage / stage time" % (
                              "host wall clock of the slowest band (rank 0)" if band_mode else "device time (HIP events on the stage's stream)")},
-            "d8_roofline": {"bound": "hbm", "kernel": "d8s_kernel", "ms": d8["ms"], "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
+            "d8_roofline": {"bound": "hbm", "kernel": "d8s_kernel", "ms": d8["ms"],
+                            "timed_by": "16 launches back to back between one pair of HIP events on the kernel's stream, mean of 3 batches",
+                            "ms_single_request": round(d8_single_ms, 4) if d8_single_ms else None,
+                            "achieved": d8["achieved_GBs"], "peak": HBM_PEAK_GBS * world,
                             "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "frac_of_measured_copy_peak": round(d8["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
                             "frac_of_measured_read_peak": round(d8["achieved_GBs"] / read_gbs, 4) if read_gbs else None,
                             "traffic": pmc_traffic("flowdir", n) if not band_mode else None},

@@ -59,7 +59,12 @@ constexpr int MAX_DOUBLINGS = 12;         // 2**12 = cells of a tile >= any simp
 constexpr int G_SHIFT = 44;
 constexpr uint64_t G_ONE = 1ull << G_SHIFT, G_SUM = G_ONE - 1, G_PEND = 0x7ffffull;
 
-enum : uint8_t { F_EXIT = 1, F_RESOLVED = 2, F_ENTRY = 4, F_DEXT_SHIFT = 3 };   // bits 3..5: external in-degree of the cell (at most 5)
+enum : uint8_t { F_EXIT = 1, F_RESOLVED = 2 };
+// The external in-degree of a perimeter cell (upstream neighbours outside its tile, at most 5) is PUSHED by the tiles the flux
+// comes from: an exit cell adds DEXT_ONE to the `arrived` word of the cell it flows into (phase 1; ~80 atomics per tile).  Reading
+// it -- the window's ring of neighbour codes, whose two columns cost a sector per cell: 4 B fetched per cell for 1 B of flow
+// directions -- is gone.  Low half of the word: the deliveries of phase 2.  A cell with an external in-degree is an ENTRY.
+constexpr uint32_t DEXT_ONE = 1u << 16, ARRIVED_MASK = 0xffffu;
 
 __device__ __forceinline__ bool flows_into(unsigned code, int k_from_me) { return code <= 7u && code == (unsigned)((k_from_me + 4) & 7); }
 
@@ -82,7 +87,7 @@ __device__ __forceinline__ void perim_cell(int p, int &r, int &c)
 struct Nodes {           // global perimeter-node arrays, index = tile * NODE_STRIDE + slot
     uint64_t *gstate;    // phase 2 walk state: pending | F
     uint64_t *inflow;    // per ENTRY cell: sum of delivered flux
-    uint32_t *arrived;   // per ENTRY cell: number of deliveries
+    uint32_t *arrived;   // per ENTRY cell: number of deliveries | external in-degree << 16 (zeroed before phase 1)
     int32_t *next;       // per EXIT cell: node index of the exit its flux continues to (-1: none)
     int32_t *dst;        // per EXIT cell: node index of the entry cell it flows into
     uint16_t *exit_of;   // per ENTRY cell: slot of the exit of its tile-local path (NO_EXIT: ends inside / leaves raster)
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
         const int q = tid + u * ATN;
         const int wr = q / 6, k = q - wr * 6;
         const int64_t rr = r0 + wr - 1;
-        const bool row_in = q < (AT + 2) * 6 && rr >= 0 && rr < H;
+        const bool row_in = q < (AT + 2) * 6 && wr >= 1 && wr <= AT && rr < H;   // (the ring stays NODIR: nothing reads the neighbours' codes)
         wv[u] = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u);
         wb[u] = 8;
         if (k < 4) {
@@ -163,9 +168,6 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
                     memcpy(&wv[u], b, 16);
                 }
             }
-        } else {
-            const int64_t cc = k == 4 ? c0 - 1 : c0 + AT;
-            if (row_in && cc >= 0 && cc < W) wb[u] = fd[rr * W + cc];
         }
     }
 #pragma unroll
@@ -179,20 +181,10 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
     __syncthreads();
     MH_ASTAMP(0);
 
-    // external in-degree of the perimeter cells (upstream neighbours outside the tile)
+    // external in-degree of the perimeter cells (upstream neighbours outside the tile): pushed by those neighbours' tiles in
+    // phase 1, read here by the final pass only
     __shared__ uint8_t dext_l[NODE_STRIDE];
-    if (tid < PERIM) {
-        int r, c;
-        perim_cell(tid, r, c);
-        unsigned d = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int nr = r + dir_dr(k), nc = c + dir_dc(k);
-            const bool in_tile = nr >= 0 && nr < AT && nc >= 0 && nc < AT;
-            d += (!in_tile && flows_into(win[(nr + 1) * FS + nc + WOFF], k)) ? 1u : 0u;
-        }
-        dext_l[tid] = (uint8_t)d;
-    }
+    if (tid < NODE_STRIDE) dext_l[tid] = FINAL ? (uint8_t)(arrived_l[tid] >> 16) : (uint8_t)0;
     __syncthreads();
 
     // my CPT cells: i = tid + ATN j (consecutive lanes = consecutive LDS words)
@@ -219,7 +211,7 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
             deg_ext = 0;
         }
         if (FINAL && deg_ext && inside) {
-            if (arrived_l[slot] == deg_ext) v += (sum_t)inflow_l[slot];
+            if ((arrived_l[slot] & ARRIVED_MASK) == deg_ext) v += (sum_t)inflow_l[slot];
             else v |= TAINT_S;  // some upstream flux never arrives (flow cycle upstream): stays unresolved => 0
         }
         // downstream cell: inside the tile, the raster and the band, else the path ends here
@@ -358,19 +350,12 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
                 dst = t2 * NODE_STRIDE + perim_slot((int)(gr % AT), (int)(gc % AT));
             }
         }
-        // entry cell?  follow its tile-local path to the cell where it leaves the tile
-        bool entry = false;
-        if (inside && !halo_row(r0 + r)) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int nr = r + dir_dr(k), nc = c + dir_dc(k);
-                if ((nr < 0 || nr >= AT || nc < 0 || nc >= AT) && flows_into(win[(nr + 1) * FS + nc + WOFF], k)) entry = true;
-            }
-        }
+        // a possible entry cell (whether a neighbouring tile flows into it is only known when every tile has pushed its exits):
+        // follow its tile-local path to the cell where it leaves the tile
+        const bool entry = inside && !halo_row(r0 + r);
         uint16_t ex = NO_EXIT;
         int32_t bex = -1;      // band mode: my path ends by flowing into a halo row from this cell of the first / last owned row
         if (entry) {
-            fl |= F_ENTRY;
             // the last in-tile cell of my path (doubling above); the path leaves through it iff that cell flows into a
             // raster cell outside the tile.  A path that ends in a sink, leaves the raster, continues in the neighbouring
             // band or runs into a flow cycle has no exit.
@@ -387,13 +372,12 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
             }
         }
         if (nd.bexit) nd.bexit[node] = bex;
-        nd.flags[node] = (uint8_t)(fl | (dext_l[tid] << F_DEXT_SHIFT));
+        nd.flags[node] = fl;
         nd.dst[node] = dst;
         nd.exit_of[node] = ex;
         nd.gstate[node] = ((resolved ? 0ull : 1ull) << G_SHIFT) | (unsigned long long)(s & ~TAINT_S);  // unresolved: blocks itself forever
-        nd.inflow[node] = 0;
-        nd.arrived[node] = 0;
         nd.next[node] = -1;
+        if (dst >= 0) atomicAdd(&nd.arrived[dst], DEXT_ONE);      // (inflow / arrived: zeroed by the host before this launch)
     }
     MH_ASTAMP(3);
 }
@@ -421,12 +405,10 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
     const int tid = threadIdx.x;
     if (tid == 0) wl_n = 0;
     // node data of my perimeter cell first (the longest dependent chain of the kernel starts here)
-    uint8_t fl = 0;
     uint64_t inflow = 0;
     uint32_t arrived = 0;
     if (tid < PERIM) {
         const int64_t node = (int64_t)tile * NODE_STRIDE + tid;
-        fl = nd.flags[node];
         inflow = nd.inflow[node];
         arrived = nd.arrived[node];
     }
@@ -492,13 +474,13 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
     else build(std::false_type{});
     __syncthreads();
     // the walkers: every entry with its inflow (bit 31: the inflow never arrived -- the path is tainted)
-    if (tid < PERIM && (fl & F_ENTRY)) {
-        const unsigned dext = (fl >> F_DEXT_SHIFT) & 7u;
+    const unsigned dext = arrived >> 16;
+    if (tid < PERIM && dext) {
         int r, c;
         perim_cell(tid, r, c);
         const uint32_t k = atomicAdd(&wl_n, 1u);
         wl_cell[k] = (uint32_t)(r * AT + c);
-        wl_add[k] = arrived == dext ? (uint32_t)inflow : TAINT32;
+        wl_add[k] = (arrived & ARRIVED_MASK) == dext ? (uint32_t)inflow : TAINT32;
     }
     __syncthreads();
     const uint32_t nw = wl_n;
@@ -698,6 +680,7 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     nd.halo_first = d_exit_map ? reinterpret_cast<int32_t *>(b + o_halo) : nullptr;
     nd.bexit = d_exit_map ? reinterpret_cast<int32_t *>(b + o_bexit) : nullptr;
     if (d_exit_map) MH_HIP(hipMemsetAsync(nd.halo_first, 0xff, 8 * (size_t)W, s));
+    MH_HIP(hipMemsetAsync(nd.inflow, 0, o_next - o_inflow, s));      // inflow | arrived: phase 1 pushes the external in-degrees into `arrived`
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
     // the local sums of phase 1 fit 32 bits unless halo cells bring the neighbouring band's flux in (the final pass of a row band)
     // the final pass as walks from the entry cells (accum_final_walk_kernel) wherever the sums fit 32 bits and no halo row is a source

@@ -61,6 +61,26 @@ std::multimap<std::pair<int, size_t>, void *> g_pool;
 size_t g_pool_bytes = 0;
 constexpr size_t POOL_CAP = 96ull << 30;  // MI355X has 288 GB of HBM3E; keep at most a third cached
 size_t round_size(size_t n) { return n < (1u << 20) ? ((n + 255) & ~size_t(255)) : ((n + (1u << 20) - 1) & ~size_t((1u << 20) - 1)); }
+// Under MHIP_DEVELOPER=1 (every test sets it) a block leaves the pool filled with 0xA5 bytes, fresh or recycled: a kernel that
+// reads what nobody wrote then sees the same garbage in a fresh process as after a long session (round 3's H = 62k+2 border
+// cells only showed with stale pool contents).  MHIP_POOL_POISON=0 keeps the blocks as they are (A/B timing runs).
+bool pool_poison()
+{
+    static const bool on = [] {
+        const char *d = getenv("MHIP_DEVELOPER");
+        if (!(d && d[0] == '1')) return false;
+        const char *e = getenv("MHIP_POOL_POISON");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+int poison_block(void *p, size_t rs)
+{
+    // the block's last user synchronised before releasing it; the fill is ordered before anything the caller queues by the sync
+    MH_HIP(hipMemsetAsync(p, 0xA5, rs, 0));
+    MH_HIP(hipStreamSynchronize(0));
+    return MHIP_OK;
+}
 }  // namespace
 
 int pool_alloc(void **p, size_t bytes)
@@ -69,13 +89,14 @@ int pool_alloc(void **p, size_t bytes)
     (void)hipGetDevice(&dev);
     const size_t rs = round_size(bytes);
     {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
+        std::unique_lock<std::mutex> lk(g_pool_mu);
         auto it = g_pool.find({dev, rs});
         if (it != g_pool.end()) {
             *p = it->second;
             g_pool.erase(it);
             g_pool_bytes -= rs;
-            return MHIP_OK;
+            lk.unlock();
+            return pool_poison() ? poison_block(*p, rs) : MHIP_OK;
         }
     }
     hipError_t e = hipMalloc(p, rs);
@@ -94,7 +115,7 @@ int pool_alloc(void **p, size_t bytes)
         set_error("hipMalloc(%zu) failed: %s", rs, hipGetErrorString(e));
         return MHIP_EHIP;
     }
-    return MHIP_OK;
+    return pool_poison() ? poison_block(*p, rs) : MHIP_OK;
 }
 
 void pool_free(void *p, size_t bytes)
@@ -1974,6 +1995,31 @@ int mhip_ctx_kernel_ms(mhip_ctx *c, const char *kernel, float *ms_total, int32_t
     if (k == "d8") {
         *launches = 1;
         return mhip_ctx_stage_ms(c, MHIP_STAGE_FLOWDIR, ms_total);
+    }
+    if (k == "d8_steady") {
+        // steady-state throughput of the D8 stencil: 16 launches back to back between ONE pair of events on the context's stream
+        // (a pair of events around a single 0.43 ms launch adds ~30 us of bracket to it); the resident surface and directions
+        MH_ARG(c->have[MHIP_R_NOFLAT] && !c->ht && !c->hb, "d8_steady needs the no-flats surface on an undivided context");
+        MH_HIP(hipSetDevice(c->device));
+        MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
+        MH_TRY(c->nodir_cnt.alloc(4));
+        constexpr int REPS = 16;
+        hipEvent_t *e0, *e1;
+        MH_TRY(ctx_events(c, 1 << 30, &e0, &e1));
+        hipStream_t s = c->stream;
+        MH_HIP(hipMemsetAsync(c->nodir_cnt.p, 0, 4, s));
+        for (int i = 0; i < REPS + 2; ++i) {
+            if (i == 2) MH_HIP(hipEventRecord(*e0, s));      // (two untimed launches first)
+            MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->H, c->W, 1, s, 0, c->H_global,
+                          c->nodir_cnt.as<unsigned int>()));
+        }
+        MH_HIP(hipEventRecord(*e1, s));
+        MH_HIP(hipEventSynchronize(*e1));
+        MH_HIP(hipEventElapsedTime(ms_total, *e0, *e1));
+        c->have[MHIP_R_FLOWDIR] = true;
+        c->nodir_valid = true;
+        *launches = REPS;
+        return MHIP_OK;
     }
     if (k == "fill_round") {
         *launches = c->fill_rounds;

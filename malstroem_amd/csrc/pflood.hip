@@ -702,7 +702,9 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
         const int xt = xi * a.ntc + xj, ot = oi * a.ntc + oj;
         if (x == 4 ? false : ot != tile) continue;
         const uint32_t labX = a.ringLab[(size_t)xt * 256 + p];
-        const int so = a.bslot[r * a.W + c];
+        // (a tile that gave up on a capacity wrote no slots: whatever the word holds must stay inside the tables; the result of
+        // the run is discarded anyway -- the overflow flag is up)
+        const int so = min((int)a.bslot[r * a.W + c], NBMAX - 1);
         const uint32_t labO = a.tabL[(size_t)ot * NBMAX + so];
         const uint32_t w = max(dem_key(a.dem[r * a.W + c]), a.tabV[(size_t)ot * NBMAX + so]);
         uint32_t mylab, nlab;
@@ -773,6 +775,7 @@ struct SolveArgs {
     int first;                             // 1: every block
     unsigned long long *eblk;              // [nbr * nbc][EMAX] the directed relaxations of every block, packed once (pf_pack_kernel)
     int row0;                              // pf_pack_kernel: first block row of the launch
+    int *ecount;                           // [nbr * nbc] used words of a block's packed relaxations
 };
 
 constexpr int ST = 512;                   // threads per block visit
@@ -793,9 +796,9 @@ __global__ __launch_bounds__(ST) void pf_pack_kernel(SolveArgs sa)
     if (t < BT * BT) {
         const int p = bi * BT + t / BT, q = bj * BT + t % BT;
         int nl = 0, ns = 0;
-        if (p < a.ntr && q < a.ntc) {
-            nl = a.tileNL[p * a.ntc + q];
-            ns = a.tileNS[p * a.ntc + q];
+        if (p < a.ntr && q < a.ntc) {     // (zero for a tile that gave up on a capacity: PfRun::begin clears the counts)
+            nl = min(max(a.tileNL[p * a.ntc + q], 0), LMAX);
+            ns = min(max(a.tileNS[p * a.ntc + q], 0), SPMAX);
         }
         s_nl[t] = nl;
         s_seg[t + 1] = nl + 2 * ns;
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(ST) void pf_pack_kernel(SolveArgs sa)
         if (t == 0) atomicOr(a.flags, 1u);
         return;
     }
+    if (t == 0 && sa.ecount) sa.ecount[blk] = s_seg[BT * BT];
     for (int idx = t; idx < BT * BT * (LMAX + SPMAX); idx += ST) {
         const int bt = idx / (LMAX + SPMAX), e0 = idx - bt * (LMAX + SPMAX);
         const int p = bi * BT + bt / BT, q = bj * BT + bt % BT;
@@ -959,6 +963,230 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
 #endif
     }   // the round's list
+}
+
+// ---- K3 as ONE launch: the same block visits, taken from a queue instead of from a list per round ---------------------------------
+// The rounds above are a Jacobi schedule: 53 launches at 16384^2 (33 of ~70 us while the levels travel from the raster border
+// inward one block per launch, then a chain of ~30 us launches with a handful of blocks each), 2.85 ms with most of the chip idle.
+// Here a resident grid takes block visits from ONE queue in global memory: a visit that lowered a seed its neighbour holds a link
+// to appends that neighbour (once: the mark word) and the next free workgroup visits it at once -- a hop costs a visit, not a
+// launch.  What crosses workgroups inside the launch:
+//   * levels: lowered with agent-scope atomic MINs (performed at the memory side: visible to every XCD), drained (`s_waitcnt vmcnt(0)` in every wave, workgroup
+//     barrier) BEFORE the wake-ups; read with sc1 loads (never L1) AFTER the visit's own mark was cleared by an agent-scope
+//     atomic -- a level that changes after it was read finds the mark cleared and queues the block again.  A stale read can only
+//     be an older, HIGHER level: the solve stays an upper bound, and the flood's result is proven cell by cell afterwards
+//     (check.hip) whatever this kernel did;
+//   * the queue: tickets from two agent-scope counters, a slot carries (generation | block) so that nobody resets slots; a visit
+//     hands out its wake-up tickets (`tail`) BEFORE it counts itself `finished`, so "finished == tail" -- `finished` read first,
+//     then `tail`: every ticket below that value was done when the first load returned, nobody was left to hand out another --
+//     is only ever true when the solve is over.
+// Every spin is bounded: a workgroup that waited PFQ_SPIN_LIMIT polls raises `abort`, everybody leaves and the host runs the
+// rounds above instead.  No workgroup waits for another to be resident (a ticket beyond the tail is only waited for while
+// finished < tail, i.e. while a RUNNING visit may still produce it).
+struct PfQueue {                   // (every counter on a line of its own: same-line atomics queue up behind each other at ~12 ns apiece --
+    unsigned int head;             //  with head, tail and a pending count in one line the 45 k visits of the benchmark waited 2 ms for them)
+    unsigned int pad0[63];         // tickets taken
+    unsigned int tail;             // tickets handed out
+    unsigned int pad1[63];
+    unsigned int finished;         // visits completed: the solve is over when finished == tail (read in THAT order: see the kernel)
+    unsigned int pad2[63];
+    unsigned int abort;            // a spin ran out, or the generations did
+    unsigned int cap_mask;         // slots - 1 (a power of two >= 2 * blocks + grid)
+    unsigned int pad3[62];
+    unsigned int slots[1];         // [cap]: (ticket / cap + 1) << 20 | block
+};
+constexpr unsigned int PFQ_SPIN_LIMIT = 1u << 21;    // polls of ~0.3-1 us each
+constexpr int PFQ_BLK_BITS = 20;
+
+__device__ __forceinline__ unsigned int ld_sc1(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(unsigned int *p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// mode 0: the blocks that hold a tile on the outline of the block grid (the only ones with an edge to OCEAN -- the raster border,
+// or a band's halo rows), in ring order; mode 1: the block rows `row_a` and `row_b` (a band whose halo links changed).  A block
+// nobody ever wakes holds no seed that a level could reach: its levels stay at +inf, as they would in the rounds.
+__global__ void pf_queue_init_kernel(PfQueue *q, unsigned int *mark, int nbr, int nbc, int mode, int row_a, int row_b, unsigned int cap_mask)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int n, blk;
+    if (mode == 0) {
+        const int h = nbr, w = nbc;
+        n = (h == 1 || w == 1) ? h * w : 2 * (w - 1) + 2 * (h - 1);
+        if (i >= n) return;
+        int bi, bj;
+        if (h == 1 || w == 1) { bi = w == 1 ? i : 0; bj = w == 1 ? 0 : i; }
+        else if (i < w - 1) { bi = 0; bj = i; }
+        else if (i < (w - 1) + (h - 1)) { bi = i - (w - 1); bj = w - 1; }
+        else if (i < 2 * (w - 1) + (h - 1)) { bi = h - 1; bj = w - 1 - (i - (w - 1) - (h - 1)); }
+        else { bi = h - 1 - (i - 2 * (w - 1) - (h - 1)); bj = 0; }
+        blk = bi * nbc + bj;
+    } else {
+        const int two = row_b != row_a ? 2 : 1;
+        n = two * nbc;
+        if (i >= n) return;
+        blk = (i < nbc ? row_a : row_b) * nbc + (i < nbc ? i : i - nbc);
+    }
+    mark[blk] = 1u;
+    q->slots[i] = (1u << PFQ_BLK_BITS) | (unsigned int)blk;
+    if (i == 0) {
+        q->head = 0u;
+        q->tail = (unsigned int)n;
+        q->finished = 0u;
+        q->cap_mask = cap_mask;
+    }
+}
+
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_solve_queue_kernel(SolveArgs sa, PfQueue *q, const int *__restrict__ ecount)
+{
+    __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
+    __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
+    __shared__ int s_wake, s_blk;
+    const PfArgs &a = sa.a;
+    const int t = threadIdx.x;
+    const unsigned int cap_mask = q->cap_mask, cap_shift = (unsigned int)__builtin_popcount(cap_mask);
+    for (;;) {
+        __syncthreads();                               // the LDS arrays (and s_blk) of the previous visit are free
+        if (t == 0) {
+            int blk = -1;
+            const unsigned int ticket = atomicAdd(&q->head, 1u);
+            const unsigned int gen = (ticket >> cap_shift) + 1u;
+            if (gen >= (1u << (32 - PFQ_BLK_BITS)) - 1u) atomicExch(&q->abort, 1u);       // (never: ~4000 x the blocks in visits)
+            else {
+                const unsigned int *slot = &q->slots[ticket & cap_mask];
+                for (unsigned int n = 0;; ++n) {
+                    const unsigned int v = ld_sc1(slot);
+                    if ((v >> PFQ_BLK_BITS) == gen) { blk = (int)(v & ((1u << PFQ_BLK_BITS) - 1u)); break; }
+                    if ((n & 7u) == 7u) {
+                        const unsigned int fin = ld_sc1(&q->finished);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // `finished` first, THEN `tail`
+                        if (fin == ld_sc1(&q->tail) || ld_sc1(&q->abort)) break;
+                    }
+                    if (n > PFQ_SPIN_LIMIT) { atomicExch(&q->abort, 1u); break; }
+                    if (n < 64u) __builtin_amdgcn_s_sleep(8);
+                    else __builtin_amdgcn_s_sleep(48);
+                }
+            }
+            // mark word of a block: bit 0 = queued, or (while bit 1 is up) woken again; bit 1 = a visit of it is running.  Returned
+            // before the barrier below: a level that changes from now on finds bit 0 clear and sets it
+            if (blk >= 0) (void)atomicExch(&sa.mark_cur[blk], 2u);
+            s_blk = blk;
+            s_wake = 0;
+        }
+        __syncthreads();
+        const int blk = s_blk;
+        if (blk < 0) return;                           // (block-uniform) the solve is over, or was called off
+        const int bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
+        // ---- levels of the region: sc1 loads (another workgroup of this launch may have written them), all in flight together
+        {
+            constexpr int NLV = RT * RT * NSMAX / ST;
+            uint32_t lv[NLV];
+#pragma unroll
+            for (int u = 0; u < NLV; ++u) {
+                const int i = t + u * ST;
+                const int rt = i / NSMAX, k = i - rt * NSMAX;
+                const int p = bi * BT + rt / RT - 1, qq = bj * BT + rt % RT - 1;
+                const bool ok = p >= 0 && p < a.ntr && qq >= 0 && qq < a.ntc;
+                lv[u] = EMPTY;
+                if (ok) lv[u] = ld_sc1(&a.Lv[(size_t)(p * a.ntc + qq) * NSMAX + k]);
+            }
+#pragma unroll
+            for (int u = 0; u < NLV; ++u) L[t + u * ST] = lv[u];
+        }
+        // ---- the block's relaxations (read-only during the solve): only the used part of the packed array
+        const int ne = ecount[blk];
+        unsigned long long er[EMAX / ST];
+#pragma unroll
+        for (int k = 0; k < EMAX / ST; ++k) {
+            er[k] = ~0ull;
+            if (t + k * ST < ne) er[k] = sa.eblk[(size_t)blk * EMAX + t + k * ST];
+        }
+        __syncthreads();
+        for (int i = t; i < BT * BT * NSMAX; i += ST) {
+            const int bt = i / NSMAX, k = i - bt * NSMAX;
+            Lold[i] = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
+        }
+        // ---- the block's fixed point (only the levels are read from LDS)
+        for (int it = 0; it < BT * BT * NSMAX; ++it) {
+            bool ch = false;
+#pragma unroll
+            for (int k = 0; k < EMAX / ST; ++k) {
+                const unsigned long long r = er[k];
+                if (r == ~0ull) continue;
+                const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
+                const uint32_t v = max((uint32_t)r, src == 0xFFFF ? 0u : L[src]);
+                if (v < L[dst]) {
+                    atomicMin(&L[dst], v);
+                    ch = true;
+                }
+            }
+            if (!__syncthreads_or(ch)) break;
+        }
+        // ---- write back (write-through), drain, then wake the neighbouring blocks that hold a link to a seed whose level dropped
+        bool moved = false;
+        for (int i = t; i < BT * BT * NSMAX; i += ST) {
+            const int bt = i / NSMAX, k = i - bt * NSMAX;
+            const int p = bi * BT + bt / BT, qq = bj * BT + bt % BT;
+            const uint32_t v = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
+            if (v < Lold[i] && p < a.ntr && qq < a.ntc) {
+                // an agent-scope MIN, not a store: a block can be in two visits at once (woken again while a visit of it is still
+                // running, taken by another workgroup), and the one that started from the older levels would put a seed back UP
+                // over what the other has just written -- nobody is woken for that, and the flood's proof fails (seen: 4 of 8 runs)
+                atomicMin(&a.Lv[(size_t)(p * a.ntc + qq) * NSMAX + k], v);
+                moved = true;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every writing wave, before the barrier the wake-ups sit behind
+        if (__syncthreads_or(moved)) {
+            unsigned wake = 0;
+#pragma unroll
+            for (int k = 0; k < EMAX / ST; ++k) {
+                const unsigned long long r = er[k];
+                const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
+                if (src == 0xFFFF) continue;                                       // also the ~0 placeholders
+                const int st = src / NSMAX, si = st / RT, sj = st % RT;             // region tile of the source
+                if (si >= 1 && si <= BT && sj >= 1 && sj <= BT) continue;          // inside the block
+                const int dt = dst / NSMAX, di_ = dt / RT - 1, dj_ = dt % RT - 1;   // block-local tile of the destination
+                if (L[dst] < Lold[(di_ * BT + dj_) * NSMAX + dst % NSMAX]) {
+                    const int wi2 = si == 0 ? 0 : (si == RT - 1 ? 2 : 1), wj = sj == 0 ? 0 : (sj == RT - 1 ? 2 : 1);
+                    wake |= 1u << (wi2 * 3 + wj);
+                }
+            }
+            if (wake) atomicOr(&s_wake, (int)wake);
+            __syncthreads();
+            wake = (unsigned)s_wake;
+            // one ticket range for all of this visit's wake-ups (a returning add: the tail is up before this visit counts as finished)
+            bool fresh = false;
+            int nb = 0;
+            if (t < 9 && ((wake >> t) & 1u)) {
+                const int p = bi + t / 3 - 1, qq = bj + t % 3 - 1;
+                if (p >= 0 && p < sa.nbr && qq >= 0 && qq < sa.nbc) {
+                    nb = p * sa.nbc + qq;
+                    fresh = atomicOr(&sa.mark_cur[nb], 1u) == 0u;      // (2: a visit of it is running -- that visit queues the block again when it ends)
+                }
+            }
+            if (t < 64) {
+                const unsigned long long bal = __ballot(fresh);
+                if (bal) {
+                    unsigned int base = 0;
+                    if (t == 0) base = atomicAdd(&q->tail, (unsigned int)__builtin_popcountll(bal));
+                    base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                    if (fresh) {
+                        const unsigned int tk = base + (unsigned int)__builtin_popcountll(bal & ((1ull << t) - 1ull));
+                        st_sc1(&q->slots[tk & cap_mask], (((tk >> cap_shift) + 1u) << PFQ_BLK_BITS) | (unsigned int)nb);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            // woken while this visit ran (by a level that may have changed after it was loaded): once more, through the queue -- one
+            // visit of a block at a time, none of them lost
+            if (atomicAnd(&sa.mark_cur[blk], ~2u) & 1u) {
+                const unsigned int tk = atomicAdd(&q->tail, 1u);
+                st_sc1(&q->slots[tk & cap_mask], (((tk >> cap_shift) + 1u) << PFQ_BLK_BITS) | (unsigned int)blk);
+            }
+            atomicAdd(&q->finished, 1u);
+        }
+    }
 }
 
 // ---- K4: final level of every basin, then the raster ---------------------------------------------------------------------
@@ -1269,6 +1497,12 @@ struct PfRun::Impl {
     unsigned int *any = nullptr;       // [round]: blocks in the list of that round
     unsigned long long *visits = nullptr;
     unsigned long long *eblk = nullptr;   // [nslots][EMAX] packed relaxations (pf_pack_kernel)
+    int *ecount = nullptr;                // [nslots] used words of each
+    PfQueue *queue = nullptr;             // the visit queue of pf_solve_queue_kernel
+    size_t queue_bytes = 0;
+    unsigned int queue_cap = 0;
+    unsigned long long queue_visits = 0;
+    bool solved_once = false;             // the first solve starts from the outline of the block grid, later ones from the band's first / last block rows
     int64_t ntiles = 0;
     size_t nslots = 0;
     int nbr = 0, nbc = 0, round = 0, launches = 0;
@@ -1299,18 +1533,55 @@ int PfRun::pack(hipStream_t s, int row0, int nrows)
     sa.nbr = m.nbr;
     sa.nbc = m.nbc;
     sa.eblk = m.eblk;
+    sa.ecount = m.ecount;
     sa.row0 = row0;
     hipLaunchKernelGGL(pf_pack_kernel, dim3((unsigned)m.nbc, (unsigned)nrows), dim3(ST), 0, s, sa);
     MH_HIP(hipGetLastError());
     return MHIP_OK;
 }
 
-// rounds of the seed-graph solve until a round appends nothing
+// the seed-graph solve: ONE launch that takes block visits from a queue (pf_solve_queue_kernel); the rounds below are the
+// fall-back when that launch calls itself off (a spin that ran out) and the A/B partner (MHIP_PF_SOLVE=rounds, development)
 int PfRun::solve(hipStream_t s)
 {
     Impl &m = *impl;
     std::vector<unsigned int> h_cnt(PF_BATCH + 1);
     unsigned int h_flag = 0;
+    static const bool use_rounds = [] { const char *e = dev_env("MHIP_PF_SOLVE"); return e && std::string(e) == "rounds"; }();
+    if (!use_rounds) {
+        const int mode = m.solved_once ? 1 : 0;
+        MH_HIP(hipMemsetAsync(m.queue, 0, m.queue_bytes, s));
+        const int n_init = mode == 0 ? ((m.nbr == 1 || m.nbc == 1) ? m.nbr * m.nbc : 2 * (m.nbc - 1) + 2 * (m.nbr - 1)) : 2 * m.nbc;
+        hipLaunchKernelGGL(pf_queue_init_kernel, dim3((unsigned)cdiv(n_init, 256)), dim3(256), 0, s, m.queue, m.mark, m.nbr, m.nbc, mode, 0, m.nbr - 1, m.queue_cap - 1u);
+        SolveArgs sa = {};
+        sa.a = m.a;
+        sa.mark_cur = m.mark;
+        sa.visits = m.visits;
+        sa.nbr = m.nbr;
+        sa.nbc = m.nbc;
+        sa.eblk = m.eblk;
+        hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
+        MH_HIP(hipGetLastError());
+        m.launches += 2;
+        unsigned int h_q[4] = {0, 0, 0, 0};      // head, tail, finished, abort
+        MH_HIP(hipMemcpyAsync(&h_q[0], &m.queue->head, 4, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(&h_q[1], &m.queue->tail, 4, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(&h_q[2], &m.queue->finished, 4, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(&h_q[3], &m.queue->abort, 4, hipMemcpyDeviceToHost, s));
+        MH_HIP(hipMemcpyAsync(&h_flag, m.a.flags, 4, hipMemcpyDeviceToHost, s));
+        if (!m.mm_valid) MH_HIP(hipMemcpyAsync(m.h_mm, m.mmout, 8, hipMemcpyDeviceToHost, s));
+        MH_HIP(stream_sync(s));
+        m.mm_valid = true;
+        m.solved_once = true;
+        if (h_flag) return MHIP_ELIMIT;
+        if (dev_env("MHIP_PF_DEBUG")) fprintf(stderr, "[pf_solve queue] tickets taken %u, handed out %u, visits finished %u, abort %u\n", h_q[0], h_q[1], h_q[2], h_q[3]);
+        m.queue_visits += h_q[2];
+        if (!h_q[3] && h_q[2] == h_q[1]) return MHIP_OK;
+        // called off (never seen): the levels are upper bounds of the solution all the same -- the rounds finish the job
+        MH_HIP(hipMemsetAsync(m.mark, 0, m.nslots * 2 * 4, s));
+        m.round = 0;
+        MH_HIP(hipMemsetAsync(m.any, 0, (size_t)(PF_MAXR + 2) * 4, s));
+    }
     for (;;) {
         if (m.round + PF_BATCH + 1 >= PF_MAXR) {
             set_error("priority-flood seed graph did not converge within %d rounds", PF_MAXR);
@@ -1382,28 +1653,40 @@ int PfRun::begin(hipStream_t s)
     const size_t o_bslot = off; off = al(off + n * 2);
     const size_t o_tabV = off; off = al(off + (size_t)ntiles * NBMAX * 4);
     const size_t o_tabL = off; off = al(off + (size_t)ntiles * NBMAX);
-    const size_t o_nb = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_ring = off; off = al(off + (size_t)ntiles * 256);
     const size_t o_spill = off; off = al(off + (size_t)ntiles * SPMAX * 8);
-    const size_t o_ns = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_links = off; off = al(off + (size_t)ntiles * LMAX * 8);
-    const size_t o_nl = off; off = al(off + (size_t)ntiles * 4);
-    const size_t o_nl0 = off; off = al(off + (size_t)ntiles * 4);
     const size_t o_lv = off; off = al(off + (size_t)ntiles * NSMAX * 4);
     // solve worklist: one active byte per block of BT x BT tiles, double buffered
     m.nbr = (int)cdiv(ntr, BT);
     m.nbc = (int)cdiv(ntc, BT);
     m.nslots = (size_t)m.nbr * m.nbc;
     m.ntiles = ntiles;
+    // cleared before every run, from here ...
+    const size_t o_nb = off; off = al(off + (size_t)ntiles * 4);
+    const size_t o_ns = off; off = al(off + (size_t)ntiles * 4);
+    const size_t o_nl = off; off = al(off + (size_t)ntiles * 4);
+    const size_t o_nl0 = off; off = al(off + (size_t)ntiles * 4);
+    const size_t o_ecnt = off; off = al(off + m.nslots * 4);
     const size_t o_act = off; off = al(off + m.nslots * 2 * 4);
     const size_t o_list = off; off = al(off + m.nslots * 2 * 4);
     const size_t o_cnt = off; off = al(off + (size_t)(PF_MAXR + 2) * 4 + 64 + 32 * 8);
+    // ... to here
     const size_t o_eblk = off; off = al(off + m.nslots * EMAX * 8);
     const size_t o_mm = off; off = al(off + (size_t)ntiles * (NT / 64) * 2 * 4 + 64);
+    // visit queue: a power of two of slots >= twice the blocks (a block is queued at most once) + the resident grid
+    m.queue_cap = 1024;
+    while (m.queue_cap < 2 * m.nslots + 1024) m.queue_cap <<= 1;
+    m.queue_bytes = sizeof(PfQueue) + (size_t)m.queue_cap * 4;
+    const size_t o_queue = off; off = al(off + m.queue_bytes);
     MH_TRY(m.ws.alloc(off));
     char *b = m.ws.as<char>();
-    MH_HIP(hipMemsetAsync(b + o_act, 0, o_eblk - o_act, s));              // active bytes, per-round words, flags, visits
+    MH_HIP(hipMemsetAsync(b + o_nb, 0, o_eblk - o_nb, s));               // per-tile / per-block counts, active bytes, per-round words, flags, visits
     MH_HIP(hipMemsetAsync(b + o_ring, NOLAB, (size_t)ntiles * 256, s));
+    // a tile that exceeds a capacity raises the overflow flag and returns at once; the kernels behind it in the queue still run
+    // (the flag is read with the solve's results): its counts must read "nothing here", not what the pool block held before --
+    // found by the poisoned pool (MHIP_DEVELOPER): pf_pack_kernel turned a stale tileNS into an offset 12 GB in front of its array
+    // (the counts sit in front of the worklist words: one clear for all of them, above)
     PfArgs &a = m.a;
     a.H = H; a.W = W; a.ntr = ntr; a.ntc = ntc; a.dem = dem; a.fixed_top = fixed_top; a.fixed_bot = fixed_bot; a.stop = 0;
     a.bslot = reinterpret_cast<uint16_t *>(b + o_bslot);
@@ -1426,6 +1709,10 @@ int PfRun::begin(hipStream_t s)
     m.eblk = reinterpret_cast<unsigned long long *>(b + o_eblk);
     a.mm = reinterpret_cast<uint32_t *>(b + o_mm);
     m.mmout = a.mm + (size_t)ntiles * (NT / 64) * 2;
+    m.ecount = reinterpret_cast<int *>(b + o_ecnt);
+    m.queue = reinterpret_cast<PfQueue *>(b + o_queue);
+    m.solved_once = false;
+    m.queue_visits = 0;
     m.mm_valid = false;
     {
         const uint32_t init[2] = {0xffffffffu, 0u};
@@ -1574,7 +1861,7 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
         MH_HIP(stream_sync(s));
         *st = FillStats();
         st->rounds = m.launches;
-        st->visits = (int64_t)h_vis;
+        st->visits = (int64_t)(h_vis + m.queue_visits);
         st->cycles = 0;
         st->tiles = m.ntiles;
         st->algorithm = 1;

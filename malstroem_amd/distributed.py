@@ -772,10 +772,14 @@ ACCUM_PAIR_DTYPE = np.dtype([("child", "<i4"), ("parent", "<i4"), ("own_child", 
 class BandPipeline(object):
     """One rank's share of a row-banded DEM.  Every rank calls the same methods in the same order (SPMD)."""
 
-    def __init__(self, comm, shape, device=0, backend_factory=None, rccl=None, align=True):
+    def __init__(self, comm, shape, device=0, backend_factory=None, rccl=None, align=True, rccl_side=False):
         """``align``: seams on the tile grid of the fill kernels (see ``band_rows``).  ``rccl``: True = the bands join an RCCL communicator inside the library and move their halo rows GPU -> GPU
         (one rank per GPU required), False = rows travel through ``comm`` as host buffers, None = RCCL whenever there is
-        more than one rank and the backend is the HIP one.  Creation is voted on: if any rank fails, every rank raises."""
+        more than one rank and the backend is the HIP one.  Creation is voted on: if any rank fails, every rank raises.
+        ``rccl_side``: the labelling thread of ``run_chain(overlap=True)`` gets an RCCL communicator of its own.  Off by default:
+        two communicators of one device driven from two host threads are only safe when every rank issues their operations in
+        the same order, which host-thread timing does not promise -- until that has run on two or more GPUs the labelling thread
+        trades its edge rows through the host communicator (a clone of ``comm``), whose order is its own."""
         self.comm = comm
         self.H, self.W = int(shape[0]), int(shape[1])
         self.row0, self.nrows = band_rows(self.H, comm.size, comm.rank, align)
@@ -785,8 +789,8 @@ class BandPipeline(object):
         self.rccl_error = None
         for attempt in (0, 1):
             self.band, err = None, None
+            uid = uid2 = None
             try:
-                uid = None
                 if rccl and comm.size > 1:
                     # every rank first says whether it can load RCCL at all (a cheap probe, no collective inside): a rank that
                     # cannot would return from the band creation at once while the others wait for it in ncclCommInitRank
@@ -798,7 +802,7 @@ class BandPipeline(object):
                     except Exception as e:
                         mine, err = None, e
                     mine2 = None
-                    if mine is not None:                    # a second id: the labelling thread gets a communicator of its own
+                    if mine is not None and rccl_side:      # a second id: the labelling thread gets a communicator of its own
                         try:
                             mine2 = getattr(factory, "new_unique_id", HipBand.new_unique_id)()
                         except Exception:
@@ -810,10 +814,18 @@ class BandPipeline(object):
                 self.band = factory(self.H, self.W, self.row0, self.nrows, device=device, rank=comm.rank, size=comm.size, **kw)
                 if uid is not None:                          # one collective before anything depends on the communicator
                     self.band.allreduce_max(float(comm.rank))
-                    if uid2 is not None and hasattr(self.band, "add_side_comm"):
-                        self.band.add_side_comm(uid2)
             except Exception as e:
                 err = err or e
+            if err is None and uid is not None and uid2 is not None and hasattr(self.band, "add_side_comm"):
+                # ncclCommInitRank is a collective: every rank says it got this far BEFORE any rank enters it (a rank that failed
+                # above would leave the others waiting inside); on a "no" the setup vote below takes every rank out together
+                if comm.allreduce_max(0.0) == 0.0:
+                    try:
+                        self.band.add_side_comm(uid2)
+                    except Exception as e:
+                        err = e
+            elif uid is not None and uid2 is not None:
+                comm.allreduce_max(1.0)                      # (this rank failed: the others must not enter the collective)
             if comm.allreduce_max(1.0 if err is not None else 0.0) == 0.0:
                 break
             if self.band is not None:
@@ -836,6 +848,19 @@ class BandPipeline(object):
 
     def close(self):
         self.band.close()
+
+    def engines(self):
+        """Which engine the last fill / no-flats fill of this band ran (``ctx_get_int``: fill 1 = tiled priority-flood, 0 = iterative
+        schedule, 4 = flood + iterative repair; no-flats 2 = integer geodesic transform, 3 = + float64 relaxation of irregular flats,
+        0 = float64 relaxation): a silent fall-back is 2-3x slower and ``bench.py`` refuses to report it.  ``None``: a stand-in
+        backend that does not say."""
+        out = {}
+        for name, key in (("fill", "fill_algorithm"), ("noflat", "noflat_algorithm")):
+            try:
+                out[name] = int(self.band.get_int(key))
+            except Exception:
+                out[name] = None
+        return out
 
     # ---- helpers
     def _allreduce_max(self, value):

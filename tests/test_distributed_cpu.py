@@ -308,7 +308,7 @@ from malstroem_amd.distributed import BandPipeline, SocketComm
 assert "torch" not in sys.modules
 comm = SocketComm.from_env()
 dem = fbm(90, 70, beta=2.0, seed=4)
-p = BandPipeline(comm, dem.shape, backend_factory=CpuBand, rccl=True)
+p = BandPipeline(comm, dem.shape, backend_factory=CpuBand, rccl=True, rccl_side=True)
 assert p.rccl and p.band.has_comm
 p.upload_dem(dem[p.row0:p.row0 + p.nrows])
 p.run_chain(); n = p.nlabels

@@ -61,7 +61,15 @@ def main():
             row["compulsory_read_bytes_per_cell"], row["compulsory_write_bytes_per_cell"] = cr, cw
             row["below_compulsory"] = bool(row["fetch_bytes_per_cell"] < 0.97 * cr)
         rows.append(row)
-    print(json.dumps(rows, indent=1))
+    # the library the counters were collected with (bench.py only attaches counter figures to a live time of the SAME build) and
+    # the number of chain steps in the profiled command (`--steps 1 --warmup 0`: one)
+    import hashlib
+    from pathlib import Path
+    lib = Path(__file__).resolve().parent.parent / "malstroem_amd" / "lib" / "libmalstroem_hip.so"
+    meta = {"library_sha256_16": hashlib.sha256(lib.read_bytes()).hexdigest()[:16] if lib.exists() else None,
+            "steps": int(sys.argv[4]) if len(sys.argv) > 4 else 1, "cells": n * n,
+            "fetch_correction": "fetch_bytes_per_cell = 2 x FETCH_SIZE: exact for coalesced streams, an UPPER BOUND for scattered gathers"}
+    print(json.dumps({"meta": meta, "kernels": rows}, indent=1))
 
 
 if __name__ == "__main__":

@@ -40,7 +40,8 @@ namespace {
 
 constexpr int WN = 64, TI = 62, NC = WN * WN;
 constexpr int NBMAX = 1024;        // basins per tile
-constexpr int HE = 2048;           // basin-pair hash entries
+constexpr int HE = 2048;           // basin-pair hash: words per half of the hash's memory ...
+constexpr int HEU = 2032;          // ... and entries in use (the last 16 words of the second half are the workgroup's scalars)
 constexpr int SE = 512;            // seed-pair hash entries
 constexpr int SPMAX = 192;         // spill edges stored per tile (unused entries hold ~0)
 constexpr int LMAX = 256;          // links stored per tile (unused entries hold ~0)
@@ -138,22 +139,30 @@ __device__ __forceinline__ uint8_t cell_class(const WinGeom &g, int ci)
     return C_VALID;
 }
 
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_tile_kernel(PfArgs a)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void pf_tile_kernel(PfArgs a)
 {
-    // LDS plan (49 KB: three workgroups = 24 wavefronts per CU -- which also takes <= 80 VGPRs, see the launch attribute; all
-    // phases but the pair fold are bound by LDS / barrier latency, not by LDS bandwidth, so residency is what pays):
+    // LDS plan: 40 KB to the byte -- FOUR workgroups = 32 wavefronts per CU (and <= 64 VGPRs, see the launch attribute); all
+    // phases but the pair fold are bound by LDS / barrier latency, not by LDS bandwidth, so residency is what pays (measured with
+    // one / two / three workgroups per CU: 11.9 / 6.9 / 4.6 ms; until round 4 the plan was 49 KB: three).
     //   zk   16 KB  elevation keys of the window                      -> after S5: the compacted basin pairs (ek | ew)
     //   ptr   8 KB  steepest-descent pointer -> pit (root) of a cell  -> S4: basin slot of a root -> S5: basin slot of a cell
-    //   hkv  16 KB  plateau ids | plateau drains (16 bit each, S2b)   -> basin-pair hash (keys | values, S5)
-    //                                                                  -> S6: seed map, seed-pair hash
-    //   bkey  8 KB + btype 1 KB  (level, seed) and kind of every basin
-    __shared__ uint32_t zk[NC];
-    __shared__ uint16_t ptr[NC];
-    __shared__ uint32_t hkv[2 * HE];
-    __shared__ unsigned long long bkey[NBMAX];
-    __shared__ uint8_t btype[NBMAX];      // 1: interior pit (level to be found), 0: ring pit or raster border (fixed)
-    __shared__ int s_scan[NT / 64];
-    __shared__ int s_cnt, s_ne;
+    //   X    16 KB  S2b: plateau ids | plateau drains (16 bit each)
+    //               S4:  bkey (8 KB: level | seed of every basin) + btype (1 KB)   -- parked in the tile's tables in global
+    //                    memory while the pair fold needs the room (the basins' kinds are rebuilt from the roots' classes) --
+    //               S5:  the basin-pair hash (keys | values, HEU = 2032 of 2048 entries each)
+    //               label-correcting, S6: bkey + btype again, seed map, seed-pair hash
+    //               the last 16 words: the workgroup's scalars (S2b keeps its plateau ids in `ptr` and leaves them alone)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_all[NC + NC / 2 + 2 * HE];
+    static_assert(sizeof(uint32_t) * (NC + NC / 2 + 2 * HE) == 40960, "four workgroups per CU: 160 KB / 4");
+    uint32_t *const zk = lds_all;
+    uint16_t *const ptr = reinterpret_cast<uint16_t *>(lds_all + NC);
+    uint32_t *const hkv = lds_all + NC + NC / 2;                                   // X
+    unsigned long long *const bkey = reinterpret_cast<unsigned long long *>(hkv); // [NBMAX], X[0 .. 2047]
+    uint8_t *const btype = reinterpret_cast<uint8_t *>(hkv + 2 * NBMAX);          // [NBMAX], X[2048 .. 2303]; 1: interior pit (level to be found), 0: ring pit or raster border (fixed)
+    int *const s_scan = reinterpret_cast<int *>(hkv + 2 * HE - 16);               // [NT / 64]
+    int &s_cnt = *reinterpret_cast<int *>(hkv + 2 * HE - 8), &s_ne = *reinterpret_cast<int *>(hkv + 2 * HE - 7);
+    int *const s_or = reinterpret_cast<int *>(hkv + 2 * HE - 6);                   // [3]: wg_or below
+    static_assert(2 * NBMAX + NBMAX / 4 + 64 + 256 + 2 * SE <= 2 * HE - 16 && HEU <= HE - 16 && NT / 64 <= 8, "X holds every phase's arrays in front of the scalars");
 
     const int t = threadIdx.x, wc = t & 63, q = __builtin_amdgcn_readfirstlane(t >> 6);
     const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
@@ -164,6 +173,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     uint32_t *hk = hkv, *hv = hkv + HE;
     static_assert(2 * HE == NC, "plateau ids / drains (one 16-bit word per cell each) share the hash arrays");
     const int wr0 = q * CPT;
+    // "does any thread of the workgroup say yes", one barrier per call like __syncthreads_or -- whose library implementation keeps
+    // 256 bytes of LDS of its own, the 256 bytes that decide between three and four workgroups per CU.  Three flag words take
+    // turns: call n raises s_or[n % 3] in front of its barrier, reads it behind, and thread 0 clears the word of call n + 2 there
+    // (its last readers left before call n's barrier, its next writers come behind call n + 1's).
+    int or_turn = 0;
+    auto wg_or = [&](bool p) -> bool {
+        if (__any(p) && wc == 0) s_or[or_turn] = 1;
+        __syncthreads();
+        const bool r = s_or[or_turn] != 0;
+        if (t == 0) s_or[or_turn == 0 ? 2 : or_turn - 1] = 0;
+        or_turn = or_turn == 2 ? 0 : or_turn + 1;
+        return r;
+    };
+    if (t == 0) { s_cnt = 0; s_ne = 0; s_or[0] = 0; s_or[1] = 0; s_or[2] = 0; }      // (in front of the barrier behind S1)
 #ifdef PF_PROFILE
     long long pf_t0_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -215,7 +238,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             }
         }
     }
-    if (t == 0) { s_cnt = 0; s_ne = 0; }
     __syncthreads();
     PF_STAMP(0);
 
@@ -259,17 +281,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     // Rare on float terrain, the rule on integer-valued DEMs.  Two 16-bit words per cell, each written by its own thread
     // only: the plateau id (smallest member index) and the plateau's drain (smallest candidate index), both found by min
     // propagation over equal neighbours with a jump through the current id.
-    if (__syncthreads_or(eqmask != 0)) {
-        uint16_t *comp = reinterpret_cast<uint16_t *>(hkv), *drain = comp + NC;
+    if (wg_or(eqmask != 0)) {
+        // (the ids live in the pointer array -- a thread keeps the pointers of its own cells in registers meanwhile --, the drains
+        // in the first half of X: the workgroup's scalars at the end of X stay valid)
+        uint16_t *comp = ptr, *drain = reinterpret_cast<uint16_t *>(hkv);
         constexpr uint16_t NODRAIN = 0xFFFF;
+        uint16_t keep[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int ci = (wr0 + k) * WN + wc;
+            keep[k] = ptr[ci];
             comp[ci] = (uint16_t)ci;
             uint16_t cand = NODRAIN;
             if ((eqmask >> k) & 1u) {
                 if (cls(k) & C_BORDER) cand = (uint16_t)ci;
-                else if ((lowmask >> k) & 1u) cand = ptr[ci];       // still the steepest-descent target
+                else if ((lowmask >> k) & 1u) cand = keep[k];       // still the steepest-descent target
             }
             drain[ci] = cand;
         }
@@ -299,19 +325,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     ch = true;
                 }
             }
-            if (!__syncthreads_or(ch)) break;
+            if (!wg_or(ch)) break;
         }
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            if (!((eqmask >> k) & 1u) || (cls(k) & C_BORDER)) continue;
+        for (int k = 0; k < CPT; ++k) {      // (own entries only: comp[ci] IS ptr[ci])
             const int ci = (wr0 + k) * WN + wc;
+            if (!((eqmask >> k) & 1u) || (cls(k) & C_BORDER)) {
+                ptr[ci] = keep[k];
+                continue;
+            }
             const uint16_t root = comp[ci];
             if (root != (uint16_t)ci) ptr[ci] = root;
             else ptr[ci] = drain[ci] != NODRAIN ? drain[ci] : (uint16_t)ci;
         }
         __syncthreads();
     }
-    for (int i = t; i < 2 * HE; i += NT) hkv[i] = EMPTY;   // the basin-pair hash
+    for (int i = t; i < 2 * HE - 16; i += NT) hkv[i] = EMPTY;   // (the pair hash is cleared again behind S4: bkey / btype use this memory first)
     __syncthreads();
     PF_STAMP(1);
 
@@ -327,7 +356,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 ch = true;
             }
         }
-        if (!__syncthreads_or(ch)) break;
+        if (!wg_or(ch)) break;
     }
     PF_STAMP(2);
 
@@ -344,6 +373,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             ++nroot;
         }
     }
+    // (the roots are remembered in the spare bit of the class nibbles: behind the pair fold the basins' kinds are rebuilt from them)
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) clsw |= ((rootmask >> k) & 1u) << (4 * k + 3);
     int incl = nroot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -389,6 +421,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         const int s = myslot[k];
         if (btype[s]) atomicMin(&bkey[s], ((unsigned long long)zk[wr * WN + wc] << 32) | (unsigned)ring_pos(wr, wc));
     }
+    __syncthreads();
+    // the pair fold needs X for its hash: (level, seed) of the basins wait in the tile's own tables in global memory (the level key
+    // as it is, the seed -- a ring position, OCEAN, or the 0xff.. of "not reached" -- as a byte), a thread's two basins each
+    for (int sI = t; sI < NB; sI += NT) {
+        const unsigned long long k64 = bkey[sI];
+        a.tabV[(size_t)tile * NBMAX + sI] = (uint32_t)(k64 >> 32);
+        a.tabL[(size_t)tile * NBMAX + sI] = (uint8_t)k64;
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * NBMAX + NBMAX / 4; i += NT) hkv[i] = EMPTY;    // (the rest of the hash has been EMPTY since S2b)
     __syncthreads();
     PF_STAMP(3);
     // ---- S5: min pass height between adjacent basins.  Neighbour slots / elevations of the strip come in one batch of
@@ -444,7 +486,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         unsigned pf_ncand = 0, pf_nlive = 0, pf_nslow = 0;
 #endif
         auto hash_insert = [&](uint32_t key, uint32_t w) {
-            unsigned hh = (key * 2654435761u) >> 21;
+            unsigned hh = __umulhi(key * 2654435761u, (unsigned)HEU);
 #pragma nounroll
             for (int probe = 0; probe < 64; ++probe) {
                 const uint32_t pv = atomicCAS(&hk[hh], EMPTY, key);
@@ -452,7 +494,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     atomicMin(&hv[hh], w);
                     return true;
                 }
-                hh = (hh + 1) & (HE - 1);
+                hh = hh + 1 == (unsigned)HEU ? 0u : hh + 1;
             }
             return false;
         };
@@ -493,7 +535,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             unsigned h[NCK];
 #pragma unroll
             for (int j = 0; j < NCK; ++j) {
-                h[j] = (ck[j] * 2654435761u) >> 21;
+                h[j] = __umulhi(ck[j] * 2654435761u, (unsigned)HEU);
                 prev[j] = EMPTY;
 #ifdef PF_PHASES
                 if (a.stop & 0x100) continue;
@@ -525,14 +567,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         atomicAdd(&a.prof[18], (unsigned long long)pf_nslow);
 #endif
     }
-    if (__syncthreads_or(overflow)) {
+    if (wg_or(overflow)) {
         if (t == 0) atomicOr(a.flags, 1u);
         return;
     }
     PF_STAMP(4);
     // compact the pairs into the memory of the elevation keys (every thread holds what it still needs in registers)
     uint32_t *ek = zk, *ew = zk + HE;
-    for (int h = t; h < HE; h += NT) {
+    for (int h = t; h < HEU; h += NT) {
         const uint32_t key = hk[h];
         if (key == EMPTY) continue;
         const int i = atomicAdd(&s_ne, 1);
@@ -541,6 +583,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
     __syncthreads();
     const int NE = s_ne;
+    // X is free again: the basins' (level, seed) come back from the tile's tables (each thread reads what it wrote itself), their
+    // kinds from the roots -- a basin whose root is a ring cell or a raster border cell is fixed, every other is an interior pit
+    for (int sI = t; sI < NB; sI += NT) {
+        const uint32_t hi = __hip_atomic_load(&a.tabV[(size_t)tile * NBMAX + sI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t lo = __hip_atomic_load(&a.tabL[(size_t)tile * NBMAX + sI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bkey[sI] = ((unsigned long long)hi << 32) | ((hi == 0xffffffffu && lo == 0xffu) ? 0xffffffffull : (unsigned long long)lo);
+        btype[sI] = 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+        if (((clsw >> (4 * k + 3)) & 1u) && (cls(k) & (C_BORDER | C_RING))) btype[ptr[(wr0 + k) * WN + wc]] = 0;
+    __syncthreads();
     PF_STAMP(5);
     // ---- label-correcting on the basin graph: (level, seed) of every interior-pit basin
     {
@@ -576,15 +631,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     if (cand < kb) { atomicMin(&bkey[e_sb[j]], cand); ch = true; }
                 }
             }
-            if (!__syncthreads_or(ch)) break;
+            if (!wg_or(ch)) break;
         }
     }
     PF_STAMP(6);
     // ---- S6: outputs.  The seeds in use (ring positions) get compact indices 0 .. NS-1 inside the tile; OCEAN stays 255.
     // The hash arrays are free again: seed map | in-use flags | seed-pair hash
-    uint8_t *cmap = reinterpret_cast<uint8_t *>(hkv);        // [256]
-    uint32_t *used = hkv + 64;                               // [256]
-    uint32_t *sk = hkv + 512, *sv = sk + SE;                 // [SE] each
+    uint8_t *cmap = reinterpret_cast<uint8_t *>(hkv + 2 * NBMAX + NBMAX / 4);   // [256]   (behind bkey and btype)
+    uint32_t *used = hkv + 2 * NBMAX + NBMAX / 4 + 64;                            // [256]
+    uint32_t *sk = used + 256, *sv = sk + SE;                                      // [SE] each
     for (int i = t; i < 256; i += NT) used[i] = 0u;
     for (int i = t; i < SE; i += NT) { sk[i] = EMPTY; sv[i] = EMPTY; }
     __syncthreads();
@@ -660,7 +715,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         if (i < SPMAX) a.spill[(size_t)tile * SPMAX + i] = ((unsigned long long)sk[h] << 32) | sv[h];
         else ov2 = true;
     }
-    if (__syncthreads_or(ov2)) {
+    if (wg_or(ov2)) {
         if (t == 0) atomicOr(a.flags, 1u);
         return;
     }
@@ -1039,9 +1094,21 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 {
     __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
     __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
-    __shared__ int s_wake, s_blk;
+    __shared__ int s_wake, s_blk, s_or[3];
     const PfArgs &a = sa.a;
     const int t = threadIdx.x;
+    // (one barrier per "does any thread say yes", three flag words taking turns: see pf_tile_kernel; the library's
+    // __syncthreads_or is a reduction through LDS with two)
+    int or_turn = 0;
+    auto wg_or = [&](bool p) -> bool {
+        if (__any(p) && (t & 63) == 0) s_or[or_turn] = 1;
+        __syncthreads();
+        const bool r = s_or[or_turn] != 0;
+        if (t == 0) s_or[or_turn == 0 ? 2 : or_turn - 1] = 0;
+        or_turn = or_turn == 2 ? 0 : or_turn + 1;
+        return r;
+    };
+    if (t == 0) { s_or[0] = 0; s_or[1] = 0; s_or[2] = 0; }      // (in front of the first barrier of the loop below)
     const unsigned int cap_mask = q->cap_mask, cap_shift = (unsigned int)__builtin_popcount(cap_mask);
     for (;;) {
         __syncthreads();                               // the LDS arrays (and s_blk) of the previous visit are free
@@ -1118,7 +1185,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     ch = true;
                 }
             }
-            if (!__syncthreads_or(ch)) break;
+            if (!wg_or(ch)) break;
         }
         // ---- write back (write-through), drain, then wake the neighbouring blocks that hold a link to a seed whose level dropped
         bool moved = false;
@@ -1135,7 +1202,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every writing wave, before the barrier the wake-ups sit behind
-        if (__syncthreads_or(moved)) {
+        if (wg_or(moved)) {
             unsigned wake = 0;
 #pragma unroll
             for (int k = 0; k < EMAX / ST; ++k) {

@@ -25,7 +25,7 @@ import zlib
 
 import numpy as np
 
-__all__ = ["RasterReader", "RasterWriter", "GeoKeys", "VectorReader", "VectorWriter"]
+__all__ = ["RasterReader", "RasterWriter", "BandRasterWriter", "GeoKeys", "VectorReader", "VectorWriter"]
 
 _TYPE_FMT = {1: "B", 2: "c", 3: "H", 4: "I", 5: "II", 6: "b", 7: "B", 8: "h", 9: "i", 10: "ii", 11: "f", 12: "d", 16: "Q", 17: "q", 18: "Q"}
 _TAG_WIDTH, _TAG_HEIGHT, _TAG_BITS, _TAG_COMPRESSION, _TAG_PHOTOMETRIC = 256, 257, 258, 259, 262
@@ -203,6 +203,177 @@ class RasterReader(object):
             r += n
 
 
+def _write_ifd(fh, big, shape, dtype, predictor, tile, offsets, counts, transform, crs, nodata):
+    """The image file directory of a tiled, deflate-compressed single-band GeoTIFF at the current position of ``fh`` (out-of-line
+    values first), and the pointer to it in the header."""
+    H, W = shape
+    kind = dtype.kind
+    entries = []     # (tag, type, values)
+    offtype = 16 if big else 4
+    entries += [(_TAG_WIDTH, 4, [W]), (_TAG_HEIGHT, 4, [H]), (_TAG_BITS, 3, [dtype.itemsize * 8]), (_TAG_COMPRESSION, 3, [8]),
+                (_TAG_PHOTOMETRIC, 3, [1]), (_TAG_SPP, 3, [1]), (_TAG_PLANAR, 3, [1]), (_TAG_PREDICTOR, 3, [predictor]),
+                (_TAG_TILE_W, 3, [tile]), (_TAG_TILE_H, 3, [tile]), (_TAG_TILE_OFFSETS, offtype, offsets),
+                (_TAG_TILE_COUNTS, offtype, counts), (_TAG_SAMPLE_FORMAT, 3, [{"u": 1, "i": 2, "f": 3}[kind]])]
+    if transform:
+        t = [float(v) for v in transform]
+        if t[2] == 0.0 and t[4] == 0.0:
+            entries += [(_TAG_PIXEL_SCALE, 12, [t[1], -t[5], 0.0]), (_TAG_TIEPOINT, 12, [0.0, 0.0, 0.0, t[0], t[3], 0.0])]
+        else:
+            entries.append((_TAG_TRANSFORMATION, 12, [t[1], t[2], 0.0, t[0], t[4], t[5], 0.0, t[3], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]))
+    if isinstance(crs, GeoKeys) and crs:
+        entries.append((_TAG_GEOKEYS, 3, list(crs.directory)))
+        if crs.doubles:
+            entries.append((_TAG_GEODOUBLES, 12, list(crs.doubles)))
+        if crs.ascii:
+            entries.append((_TAG_GEOASCII, 2, crs.ascii))
+    if nodata is not None:
+        entries.append((_TAG_NODATA, 2, ("%.17g" % nodata) + "\x00"))
+    entries.sort(key=lambda e: e[0])
+    # out-of-line values first, then the IFD
+    inline = 8 if big else 4
+    packed = []
+    for tag, typ, vals in entries:
+        if typ == 2:
+            data = vals.encode("latin-1")
+            count = len(data)
+        else:
+            fmt = _TYPE_FMT[typ]
+            data = struct.pack("<%d%s" % (len(vals), fmt), *vals)
+            count = len(vals)
+        if len(data) > inline:
+            if fh.tell() & 1:
+                fh.write(b"\x00")
+            off = fh.tell()
+            fh.write(data)
+            data = struct.pack("<Q" if big else "<I", off)
+        packed.append((tag, typ, count, data.ljust(inline, b"\x00")))
+    if fh.tell() & 1:
+        fh.write(b"\x00")
+    ifd = fh.tell()
+    if big:
+        fh.write(struct.pack("<Q", len(packed)))
+        for tag, typ, count, data in packed:
+            fh.write(struct.pack("<HHQ", tag, typ, count) + data)
+        fh.write(struct.pack("<Q", 0))
+        fh.seek(8)
+        fh.write(struct.pack("<Q", ifd))
+    else:
+        fh.write(struct.pack("<H", len(packed)))
+        for tag, typ, count, data in packed:
+            fh.write(struct.pack("<HHI", tag, typ, count) + data)
+        fh.write(struct.pack("<I", 0))
+        fh.seek(4)
+        fh.write(struct.pack("<I", ifd))
+
+
+def _encode_tile(tile, predictor, itemsize, zlevel):
+    if predictor == 2:
+        u = tile.view(np.dtype("<u%d" % itemsize))
+        d = u.copy()
+        d[:, 1:] = u[:, 1:] - u[:, :-1]
+        tile = d
+    return zlib.compress(tile.tobytes(), zlevel)
+
+
+class BandRasterWriter(object):
+    """ONE GeoTIFF written by all ranks of a row-banded raster at the same time (reference: every tool writes the raster it holds,
+    io.py:141-159, bluespots.py:175-214 -- here the raster is spread over the ranks, and none of them may become the funnel).
+
+    Same format as ``RasterWriter`` (256 x 256 tiles, deflate, predictor 2 except for float64, always BigTIFF).  A rank writes
+    the tile rows that START in its band; the rows of its last tile row that belong to the next band (< 256) come from that
+    neighbour -- the only raster data that crosses ranks.  Compressed sizes are not known in advance, so every tile owns a SLOT
+    of the worst-case deflate size at a position that follows from its index alone (``os.pwrite``: no rank waits for another); the
+    unused tail of a slot is a hole of the (sparse) file, the tile-offset / byte-count tags say where the data is, like in any
+    TIFF.  Rank 0 writes the header at the start and the directory behind the last slot once the byte counts are gathered (8
+    bytes per tile).  Host memory per rank: one tile row of the raster + the neighbour's rows, whatever the raster's height.
+
+    ``comm``: ``rank`` / ``size`` / ``exchange_rows`` / ``allgather`` / ``allreduce_max`` (a ``malstroem_amd.distributed.Comm``);
+    ``rows(r0, n)``: rows [r0, r0 + n) of THIS rank's band (band-local) as an (n, W) array; ``extents``: (row0, nrows) of every
+    rank, the same list on all of them.  Every rank calls ``write``; bands must hold at least one tile row (256 rows)."""
+
+    TILE = 256
+
+    def __init__(self, filepath, transform, crs, nodata=None, zlevel=6):
+        if isinstance(crs, str) and crs:
+            raise NotImplementedError("a WKT coordinate system needs GDAL; pass the `crs` of a malstroem_amd.io.RasterReader (or None)")
+        self.filepath, self.transform, self.crs, self.nodata, self.zlevel = filepath, transform, crs, nodata, int(zlevel)
+
+    @classmethod
+    def tile_rows(cls, extents, rank, H):
+        """[k0, k1): the tile rows that start inside the band of ``rank``"""
+        T = cls.TILE
+        row0, nrows = extents[rank]
+        k0 = -(-row0 // T)
+        k1 = -(-(row0 + nrows) // T) if rank + 1 < len(extents) else -(-H // T)
+        return k0, max(k0, k1)
+
+    def write(self, comm, shape, extents, rows, dtype):
+        T = self.TILE
+        H, W = int(shape[0]), int(shape[1])
+        dtype = np.dtype(dtype).newbyteorder("<")
+        me, size = comm.rank, comm.size
+        row0, nrows = extents[me]
+        if size > 1 and min(n for _, n in extents) < T:
+            raise ValueError("BandRasterWriter needs bands of at least %d rows" % T)
+        predictor = 1 if dtype == np.dtype(np.float64) else 2
+        across = -(-W // T)
+        ntiles = across * -(-H // T)
+        raw = T * T * dtype.itemsize
+        slot = (raw + raw // 1000 + 64 + 15) & ~15                # (zlib's worst case is raw + 5 bytes per 16 KB block + 6)
+        k0, k1 = self.tile_rows(extents, me, H)
+        # rows of my band's head that complete the previous rank's last tile row / rows I need from the next rank
+        give = min(nrows, k0 * T - row0) if me > 0 else 0
+        need = max(0, min(H, k1 * T) - (row0 + nrows)) if me + 1 < size else 0
+        to_up = np.ascontiguousarray(rows(0, give), dtype=dtype) if give else (np.zeros((1, W), dtype) if me > 0 else None)
+        to_down = (np.zeros((max(need, 1), W), dtype) if me + 1 < size else None)   # (nothing travels down: the transports want equal shapes per seam)
+        _, from_down = comm.exchange_rows(to_up, to_down) if size > 1 else (None, None)
+        err = None
+        try:
+            if me == 0:
+                with open(self.filepath, "wb") as fh:
+                    fh.write(b"II" + struct.pack("<HHHQ", 43, 8, 0, 0))
+        except OSError as e:
+            err = e
+        if comm.allreduce_max(1.0 if err else 0.0) > 0.0:          # (also: the file exists before anybody else opens it)
+            raise err or IOError("rank 0 could not create %s" % self.filepath)
+        counts = np.zeros((k1 - k0) * across, dtype=np.int64)
+        try:
+            fd = os.open(self.filepath, os.O_WRONLY)
+            try:
+                pending = np.zeros((T, across * T), dtype=dtype)
+                for k in range(k0, k1):
+                    g0, g1 = k * T, min(H, (k + 1) * T)               # global rows of this tile row
+                    own1 = min(g1, row0 + nrows)
+                    pending[:] = 0
+                    if own1 > g0:
+                        pending[:own1 - g0, :W] = rows(g0 - row0, own1 - g0)
+                    if g1 > own1:                                     # the tail of my last tile row lives in the next band
+                        pending[own1 - g0:g1 - g0, :W] = from_down[:g1 - own1]
+                    for bx in range(across):
+                        data = _encode_tile(np.ascontiguousarray(pending[:, bx * T:(bx + 1) * T]), predictor, dtype.itemsize, self.zlevel)
+                        assert len(data) <= slot
+                        os.pwrite(fd, data, 16 + (k * across + bx) * slot)
+                        counts[(k - k0) * across + bx] = len(data)
+            finally:
+                os.close(fd)
+        except Exception as e:      # (voted on below: every rank raises or none does)
+            err = e
+        parts = comm.allgather((k0, counts))
+        if comm.allreduce_max(1.0 if err else 0.0) > 0.0:
+            raise err or IOError("another rank failed writing %s" % self.filepath)
+        if me == 0:
+            allc = np.zeros(ntiles, dtype=np.int64)
+            for pk0, pc in parts:
+                pc = np.asarray(pc, dtype=np.int64)
+                allc[pk0 * across:pk0 * across + pc.size] = pc
+            offsets = (16 + np.arange(ntiles, dtype=np.int64) * slot).tolist()
+            with open(self.filepath, "r+b") as fh:
+                fh.seek(16 + ntiles * slot)
+                _write_ifd(fh, True, (H, W), dtype, predictor, T, offsets, allc.tolist(), self.transform, self.crs, self.nodata)
+        comm.allreduce_max(0.0)                                      # (the file is complete when anybody returns)
+        return self.filepath
+
+
 class RasterWriter(object):
     """Write a 2-D array as a tiled, deflate-compressed GeoTIFF, at once (``write``) or in top-to-bottom row windows
     (``open`` / ``write_window`` / ``close``).  Creation options of the reference (io.py:112,129-139): 256 x 256 tiles,
@@ -291,66 +462,9 @@ class RasterWriter(object):
             self._fh.close()
             self._fh = None
             raise ValueError("raster incomplete: %d of %d rows written" % (self._next_row, self._shape[0]))
-        fh, big = self._fh, self._big
-        H, W = self._shape
-        kind = self._dtype.kind
-        entries = []     # (tag, type, values)
-        offtype = 16 if big else 4
-        entries += [(_TAG_WIDTH, 4, [W]), (_TAG_HEIGHT, 4, [H]), (_TAG_BITS, 3, [self._dtype.itemsize * 8]), (_TAG_COMPRESSION, 3, [8]),
-                    (_TAG_PHOTOMETRIC, 3, [1]), (_TAG_SPP, 3, [1]), (_TAG_PLANAR, 3, [1]), (_TAG_PREDICTOR, 3, [self._predictor]),
-                    (_TAG_TILE_W, 3, [self.TILE]), (_TAG_TILE_H, 3, [self.TILE]), (_TAG_TILE_OFFSETS, offtype, self._offsets),
-                    (_TAG_TILE_COUNTS, offtype, self._counts), (_TAG_SAMPLE_FORMAT, 3, [{"u": 1, "i": 2, "f": 3}[kind]])]
-        if self.transform:
-            t = [float(v) for v in self.transform]
-            if t[2] == 0.0 and t[4] == 0.0:
-                entries += [(_TAG_PIXEL_SCALE, 12, [t[1], -t[5], 0.0]), (_TAG_TIEPOINT, 12, [0.0, 0.0, 0.0, t[0], t[3], 0.0])]
-            else:
-                entries.append((_TAG_TRANSFORMATION, 12, [t[1], t[2], 0.0, t[0], t[4], t[5], 0.0, t[3], 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]))
-        if isinstance(self.crs, GeoKeys) and self.crs:
-            entries.append((_TAG_GEOKEYS, 3, list(self.crs.directory)))
-            if self.crs.doubles:
-                entries.append((_TAG_GEODOUBLES, 12, list(self.crs.doubles)))
-            if self.crs.ascii:
-                entries.append((_TAG_GEOASCII, 2, self.crs.ascii))
-        if self.nodata is not None:
-            entries.append((_TAG_NODATA, 2, ("%.17g" % self.nodata) + "\x00"))
-        entries.sort(key=lambda e: e[0])
-        # out-of-line values first, then the IFD
-        inline = 8 if big else 4
-        packed = []
-        for tag, typ, vals in entries:
-            if typ == 2:
-                data = vals.encode("latin-1")
-                count = len(data)
-            else:
-                fmt = _TYPE_FMT[typ]
-                data = struct.pack("<%d%s" % (len(vals), fmt), *vals)
-                count = len(vals)
-            if len(data) > inline:
-                if fh.tell() & 1:
-                    fh.write(b"\x00")
-                off = fh.tell()
-                fh.write(data)
-                data = struct.pack("<Q" if big else "<I", off)
-            packed.append((tag, typ, count, data.ljust(inline, b"\x00")))
-        if fh.tell() & 1:
-            fh.write(b"\x00")
-        ifd = fh.tell()
-        if big:
-            fh.write(struct.pack("<Q", len(packed)))
-            for tag, typ, count, data in packed:
-                fh.write(struct.pack("<HHQ", tag, typ, count) + data)
-            fh.write(struct.pack("<Q", 0))
-            fh.seek(8)
-            fh.write(struct.pack("<Q", ifd))
-        else:
-            fh.write(struct.pack("<H", len(packed)))
-            for tag, typ, count, data in packed:
-                fh.write(struct.pack("<HHI", tag, typ, count) + data)
-            fh.write(struct.pack("<I", 0))
-            fh.seek(4)
-            fh.write(struct.pack("<I", ifd))
-        fh.close()
+        _write_ifd(self._fh, self._big, self._shape, self._dtype, self._predictor, self.TILE, self._offsets, self._counts, self.transform,
+                   self.crs, self.nodata)
+        self._fh.close()
         self._fh = None
 
 

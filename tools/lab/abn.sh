@@ -2,7 +2,7 @@
 # on the GPU box: a development knob over several values, alternating runs:  bash tools/lab/abn.sh KNOB "v1 v2 v3" [rounds] [bench args]
 cd $GRAFT_REPO_ROOT
 export MHIP_DEVELOPER=1
-K=$1; VALS=$2; N=${3:-2}; shift 3
+K=$1; VALS=$2; N=${3:-2}; shift $(( $# < 3 ? $# : 3 ))
 for i in $(seq $N); do for v in $VALS; do
   env $K=$v python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | tail -1 > /tmp/b.json
   python3 -c "

@@ -36,6 +36,39 @@ def transform_cell_to_world(cell, transform):
     return x, y
 
 
+POURPOINT_DTYPE = np.dtype([("bspot_id", "<i8"), ("cell_row", "<i8"), ("cell_col", "<i8"), ("bspot_dmax", "<f8"), ("bspot_area", "<f8"),
+                            ("bspot_vol", "<f8"), ("wshed_area", "<f8"), ("bspot_fumm", "<f8")])
+
+
+def pourpoint_records(transform, pp_pix, bluespot_stats, watershed_stats, first_id=0):
+    """The attributes of bluespots.py:75-82 for a run of labels as ONE structured array (``POURPOINT_DTYPE``) -- what the row-band
+    path moves between ranks (65 M labels as dicts do not travel) -- computed in the arithmetic of the reference's per-label code:
+    area = count * A, vol = sum * A, wshed_area = watershed cells * A, fumm = float64(1000 * vol) / float64(wshed_area)."""
+    cell_area = abs(transform[1]) * abs(transform[5])
+    pp_pix, bluespot_stats = np.asarray(pp_pix), np.asarray(bluespot_stats)
+    n = len(pp_pix)
+    rec = np.zeros(n, POURPOINT_DTYPE)
+    rec["bspot_id"] = np.arange(int(first_id), int(first_id) + n, dtype=np.int64)
+    rec["cell_row"], rec["cell_col"] = pp_pix["row"], pp_pix["col"]
+    rec["bspot_dmax"] = bluespot_stats["max"]
+    rec["bspot_area"] = bluespot_stats["count"] * cell_area
+    rec["bspot_vol"] = bluespot_stats["sum"] * cell_area
+    rec["wshed_area"] = np.asarray(watershed_stats) * cell_area
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rec["bspot_fumm"] = np.float64(1000) * rec["bspot_vol"] / rec["wshed_area"]
+    return rec
+
+
+def pourpoint_features(records, transform):
+    """GeoJSON-like pour point features (bluespots.py:49-88) of ``pourpoint_records``, one at a time."""
+    for r in records:
+        ix = int(r["bspot_id"])
+        p = dict(bspot_id=ix, type="Feature", cell_row=int(r["cell_row"]), cell_col=int(r["cell_col"]), bspot_dmax=float(r["bspot_dmax"]),
+                 bspot_area=float(r["bspot_area"]), bspot_vol=float(r["bspot_vol"]), wshed_area=float(r["wshed_area"]), bspot_fumm=float(r["bspot_fumm"]))
+        coord = transform_cell_to_world((p['cell_row'], p['cell_col']), transform)
+        yield dict(id=ix, geometry=dict(type='Point', coordinates=list(coord)), properties=p)
+
+
 def assemble_pourpoints(transform, pp_pix, bluespot_stats, watershed_stats, first_id=0):
     """GeoJSON-like pour point features, one per label incl. background 0 (bluespots.py:49-88).  ``first_id``: the label of the
     first record (a row band assembles the features of the labels it numbered)."""

@@ -149,7 +149,7 @@ def _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasub
     pour points (records merged across bands), the stream walk (walkers handed over at the seams) and, on rank 0, the junction
     surgery, the rain events and all writing.  Returns the same dict as ``process_all`` on rank 0, ``None`` elsewhere."""
     from .algorithms import dtypes, net
-    from .bluespots import assemble_pourpoints
+    from .bluespots import POURPOINT_DTYPE, pourpoint_features, pourpoint_records
     from .distributed import BandPipeline
     from .streams import nodes_to_features
     root = comm.rank == 0
@@ -170,6 +170,12 @@ def _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasub
         reader.close()
 
         def write(name, filename, nodata=None):
+            # every rank writes the tile rows that start in its band into the ONE file (io.BandRasterWriter): the reference's tools
+            # write the raster they hold (io.py:141-159), and here nobody holds it -- nor may a rank become the funnel for it.
+            # Bands so thin that a tile row spans three of them (tests): gathered to rank 0 in row windows, as until round 3
+            if io.BandRasterWriter.supports(extents, reader.shape[0]):
+                pipe.write_raster(name, io.BandRasterWriter(os.path.join(outdir, filename), tr, crs, nodata))
+                return
             w = io.RasterWriter(os.path.join(outdir, filename), tr, crs, nodata) if root else None
             opened = False
             for row0, rows in pipe.gather_rows(name):
@@ -181,6 +187,7 @@ def _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasub
             if root:
                 w.close()
         pipe.H_W = reader.shape
+        extents = [tuple(e) for e in comm.allgather((int(pipe.row0), int(pipe.nrows)))]
         logger.info("Calculating filled DEM and bluespot depths")
         pipe.fill()
         write("filled", "filled.tif", nodatasubst)
@@ -210,18 +217,21 @@ def _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasub
         pipe.watershed()
         write("watersheds", "watersheds.tif", 0)
         stats, counts, pour = pipe.stats(), pipe.watershed_counts(), pipe.pourpoints(use_accum=bool(accum))
-        # pour point features: every rank its own labels, rank 0 the background record (bluespots.py:49-88 emits index 0 as well)
+        # pour points: every rank the records of its own labels (rank 0 the background record in front: bluespots.py:49-88 emits
+        # index 0 as well) as ONE structured array -- the ranks trade arrays, and only rank 0 ever turns records into features
         lo = stats["first_label"]
-        feats = assemble_pourpoints(tr, pour["records"], stats["records"], counts["records"], first_id=lo)
+        recs = pourpoint_records(tr, pour["records"], stats["records"], counts["records"], first_id=lo)
         if root:
-            feats = assemble_pourpoints(tr, [pour["background"]], [stats["background"]], [counts["background"]], first_id=0) + feats
-        feats = [f for part in comm.allgather(feats) for f in part]
+            recs = np.concatenate([pourpoint_records(tr, [pour["background"]], [stats["background"]], [counts["background"]], first_id=0), recs])
+        recs = np.concatenate([np.asarray(part, dtype=POURPOINT_DTYPE) for part in comm.allgather(recs)])
         pourpoint_writer = io.VectorWriter('GeoJSON', outvector, 'pourpoints', None, None, crs)
+        feats = None
         if root:
-            logger.info("Writing {} pour points".format(len(feats)))
+            logger.info("Writing {} pour points".format(len(recs)))
+            feats = list(pourpoint_features(recs, tr))
             pourpoint_writer.write_geojson_features(dict(type="FeatureCollection", features=feats))
         # stream network: walkers start at every pour point (also the background's) and are handed over at the seams
-        pix = [(f['properties']['cell_row'], f['properties']['cell_col']) for f in feats]
+        pix = np.stack([recs["cell_row"], recs["cell_col"]], axis=1)
         labels_next, geoms = pipe.trace_downstream(pix, 0, geometry=True)
     finally:
         pipe.close()
@@ -229,8 +239,8 @@ def _process_all_bands(dem, outdir, rain, accum, filter, comm, device, nodatasub
         comm.allreduce_max(0.0)       # (rank 0 is writing: leave together)
         return None
     try:
-        ids = [f['properties']['bspot_id'] for f in feats]
-        nodes = net.network_from_walks(ids, pix, labels_next, geoms, next_label=nlabels + 1)
+        ids = recs["bspot_id"].tolist()
+        nodes = net.network_from_walks(ids, pix.tolist(), labels_next, geoms, next_label=nlabels + 1)
         nodes_writer = io.VectorWriter('GeoJSON', outvector, 'nodes', None, None, crs)
         streams_writer = io.VectorWriter('GeoJSON', outvector, 'streams', None, None, crs)
         node_feats, stream_feats = nodes_to_features(nodes, feats, tr)

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
                 mine |= (w & A_MASK) != SENT13;
             }
         }
-        more = __syncthreads_or(mine) != 0;
+        more = __syncthreads_or(mine) != 0;   // (a one-barrier vote through three LDS flags -- common.hpp: WgVote -- measured slower here: 3.61 -> 3.83 ms)
     }
     if (more) {
         // still walking after 2**12 steps: the path has entered a flow cycle, and A is a cell ON the cycle; over all

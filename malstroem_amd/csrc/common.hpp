@@ -371,4 +371,26 @@ int negative_lut_dev(int32_t *d_lab, int64_t n, const int32_t *d_lut, int64_t nl
 
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+#ifdef __HIPCC__
+// "Does any thread of the workgroup say yes?" with ONE barrier per call.  The library's __syncthreads_or is a reduction through 256
+// bytes of LDS of its own with two barriers; the loops that end on such a vote (pointer doubling, label-correcting sweeps) are
+// bound by exactly these barriers.  Three LDS words take turns: call n raises w[n % 3] in front of its barrier and reads it behind;
+// thread 0 clears the word of call n + 2 there (its last readers left before call n's barrier, its next writers come behind call
+// n + 1's).  The caller zeroes the three words in front of a barrier; every call must be reached by all threads of the workgroup.
+struct WgVote {
+    int *w;
+    int turn;
+    __device__ __forceinline__ explicit WgVote(int *lds3) : w(lds3), turn(0) {}
+    __device__ __forceinline__ bool any(bool p)
+    {
+        if (__any(p) && (threadIdx.x & 63u) == 0u) w[turn] = 1;
+        __syncthreads();
+        const bool r = w[turn] != 0;
+        if (threadIdx.x == 0) w[turn == 0 ? 2 : turn - 1] = 0;
+        turn = turn == 2 ? 0 : turn + 1;
+        return r;
+    }
+};
+#endif
+
 }  // namespace mh

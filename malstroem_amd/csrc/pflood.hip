@@ -1090,7 +1090,7 @@ __global__ void pf_queue_init_kernel(PfQueue *q, unsigned int *mark, int nbr, in
     }
 }
 
-__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_solve_queue_kernel(SolveArgs sa, PfQueue *q, const int *__restrict__ ecount)
+__device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue *q, const int *__restrict__ ecount)
 {
     __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
     __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
@@ -1254,6 +1254,16 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             atomicAdd(&q->finished, 1u);
         }
     }
+}
+
+// three workgroups per CU at up to 80 VGPRs, or four at 64 (the loads' address arithmetic then spills a dozen words once per visit)
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_solve_queue_kernel(SolveArgs sa, PfQueue *q, const int *__restrict__ ecount)
+{
+    pf_solve_queue_body(sa, q, ecount);
+}
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(8, 8))) void pf_solve_queue4_kernel(SolveArgs sa, PfQueue *q, const int *__restrict__ ecount)
+{
+    pf_solve_queue_body(sa, q, ecount);
 }
 
 // ---- K4: final level of every basin, then the raster ---------------------------------------------------------------------
@@ -1627,7 +1637,9 @@ int PfRun::solve(hipStream_t s)
         sa.nbr = m.nbr;
         sa.nbc = m.nbc;
         sa.eblk = m.eblk;
-        hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
+        static const bool four = [] { const char *e = dev_env("MHIP_PF_QWG"); return e && e[0] == '4'; }();     // (development: A/B)
+        if (four) hipLaunchKernelGGL(pf_solve_queue4_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 1024)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);
+        else hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
         MH_HIP(hipGetLastError());
         m.launches += 2;
         unsigned int h_q[4] = {0, 0, 0, 0};      // head, tail, finished, abort

@@ -515,6 +515,14 @@ class HipBand(object):
         _lib.call("mhip_ctx_download", self._ctx, which, _lib.ptr(out))
         return out
 
+    def download_rows(self, name, row0, nrows):
+        """rows [row0, row0 + nrows) of the band's OWNED rows (a window on the host, whatever the band's height)"""
+        which = RASTERS[name]
+        out = np.empty((int(nrows), self.W), dtype=RASTER_DTYPE[which])
+        if nrows:
+            _lib.call("mhip_ctx_download_rows", self._ctx, which, _lib.i64(row0), _lib.i64(nrows), _lib.ptr(out))
+        return out
+
     def get_edge_row(self, name, side):
         which = RASTERS[name]
         out = np.empty(self.W, dtype=RASTER_DTYPE[which])
@@ -1515,3 +1523,14 @@ class BandPipeline(object):
 
     def download(self, name):
         return self.band.download(name)
+
+    def download_rows(self, name, row0, nrows):
+        if hasattr(self.band, "download_rows"):
+            return self.band.download_rows(name, row0, nrows)
+        return self.band.download(name)[row0:row0 + nrows]
+
+    def write_raster(self, name, writer):
+        """Raster ``name`` of all bands into ONE file, every rank writing the tile rows that start in its band
+        (``malstroem_amd.io.BandRasterWriter``): no rank gathers the raster, a rank's host memory is one tile row.  Collective."""
+        extents = [tuple(e) for e in self._cur_comm().allgather((int(self.row0), int(self.nrows)))]
+        return writer.write(self._cur_comm(), (self.H, self.W), extents, lambda r0, n: self.download_rows(name, r0, n), RASTER_DTYPE[RASTERS[name]])

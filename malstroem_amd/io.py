@@ -289,7 +289,7 @@ class BandRasterWriter(object):
 
     ``comm``: ``rank`` / ``size`` / ``exchange_rows`` / ``allgather`` / ``allreduce_max`` (a ``malstroem_amd.distributed.Comm``);
     ``rows(r0, n)``: rows [r0, r0 + n) of THIS rank's band (band-local) as an (n, W) array; ``extents``: (row0, nrows) of every
-    rank, the same list on all of them.  Every rank calls ``write``; bands must hold at least one tile row (256 rows)."""
+    rank, the same list on all of them.  Every rank calls ``write``; see ``supports`` for the band layouts it takes."""
 
     TILE = 256
 
@@ -307,14 +307,24 @@ class BandRasterWriter(object):
         k1 = -(-(row0 + nrows) // T) if rank + 1 < len(extents) else -(-H // T)
         return k0, max(k0, k1)
 
+    @classmethod
+    def supports(cls, extents, H):
+        """every tile row ends in the band it starts in or in the next one (true whenever the bands hold 255 rows or more)"""
+        T = cls.TILE
+        for r in range(len(extents) - 1):
+            end = extents[r][0] + extents[r][1]
+            if min(H, -(-end // T) * T) - end > extents[r + 1][1] or extents[r][1] < 1:
+                return False
+        return True
+
     def write(self, comm, shape, extents, rows, dtype):
         T = self.TILE
         H, W = int(shape[0]), int(shape[1])
         dtype = np.dtype(dtype).newbyteorder("<")
         me, size = comm.rank, comm.size
         row0, nrows = extents[me]
-        if size > 1 and min(n for _, n in extents) < T:
-            raise ValueError("BandRasterWriter needs bands of at least %d rows" % T)
+        if not self.supports(extents, H):
+            raise ValueError("BandRasterWriter: a tile row (%d rows) must end in the band it starts in or in the next one" % T)
         predictor = 1 if dtype == np.dtype(np.float64) else 2
         across = -(-W // T)
         ntiles = across * -(-H // T)

@@ -93,6 +93,9 @@ class CpuBand(object):
     def download(self, name):
         return self.r[name][self.ht:self.ht + self.nrows].copy()
 
+    def download_rows(self, name, row0, nrows):
+        return self.r[name][self.ht + row0:self.ht + row0 + nrows].copy()
+
     def get_edge_row(self, name, side):
         row = {0: self.ht, 1: self.ht + self.nrows - 1, 2: 0, 3: self.H - 1}[side]
         return self._raster(name)[row].copy()

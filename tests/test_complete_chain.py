@@ -264,9 +264,16 @@ def test_complete_on_row_bands_equals_one_context_on_a_larger_terrain(tmp_path):
     bands = tmp_path / "bands"
     bands.mkdir()
     res, err = [None] * 4, []
+    # (512 rows per band: every rank writes its own tile rows of every raster -- nothing may be gathered to rank 0)
+    from malstroem_amd.distributed import BandPipeline
+    monkey_gather = BandPipeline.gather_rows
+
+    def no_gather(self, *a, **k):
+        raise AssertionError("a raster went through the rank-0 funnel")
 
     def work(comm):
         try:
+            BandPipeline.gather_rows = no_gather
             res[comm.rank] = process_all(src, str(bands), [20, 60], accum=True, filter=flt, comm=comm)
         except Exception as e:      # pragma: no cover
             import traceback
@@ -276,6 +283,7 @@ def test_complete_on_row_bands_equals_one_context_on_a_larger_terrain(tmp_path):
     threads = [threading.Thread(target=work, args=(c,), daemon=True) for c in ThreadComm.world(4)]
     [t.start() for t in threads]
     [t.join(900) for t in threads]
+    BandPipeline.gather_rows = monkey_gather
     assert not err and not any(t.is_alive() for t in threads), err
     r4 = res[0]
     assert r4["nlabels"] == r1["nlabels"] > 100

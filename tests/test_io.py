@@ -71,6 +71,56 @@ def test_bigtiff_and_crs_pass_through(tmp_path):
         w.close()                                           # incomplete
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.uint8])
+@pytest.mark.parametrize("nbands,shape", [(3, (1300, 700)), (4, (1100, 256)), (2, (517, 90))])
+def test_band_writer_all_ranks_write_one_file(tmp_path, dtype, nbands, shape):
+    """io.BandRasterWriter: every rank of a row-banded raster writes the tile rows that start in its band into ONE GeoTIFF (slots of
+    worst-case size, `os.pwrite`, the directory by rank 0); only the < 256 rows that complete a rank's last tile row come from its
+    neighbour.  The file decodes to the raster, with the same tags as the one RasterWriter writes -- seams on and off the tile grid."""
+    import threading
+    from malstroem_amd.distributed import ThreadComm, band_rows
+    from malstroem_amd.io import BandRasterWriter
+    H, W = shape
+    rng = np.random.default_rng(H + W)
+    a = (np.cumsum(rng.random((H, W)), axis=1) * 3).astype(dtype)
+    gt = (10.0, 2.0, 0.0, 50.0, 0.0, -2.0)
+    RasterWriter(str(tmp_path / "one.tif"), gt, None, 0).write(a)
+    ext = [band_rows(H, nbands, r, True) for r in range(nbands)]
+    seen, errs = [], []
+
+    def run(comm):
+        try:
+            r0, nr = ext[comm.rank]
+
+            def rows(q0, q):
+                assert 0 <= q0 and q0 + q <= nr
+                seen.append((comm.rank, q))
+                return a[r0 + q0:r0 + q0 + q]
+            BandRasterWriter(str(tmp_path / "bands.tif"), gt, None, 0).write(comm, (H, W), ext, rows, dtype)
+        except Exception as e:      # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errs.append(e)
+    threads = [threading.Thread(target=run, args=(c,), daemon=True) for c in ThreadComm.world(nbands)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert not errs and not any(t.is_alive() for t in threads)
+    assert max(q for _, q in seen) <= 256                      # a rank never asks its band for more than one tile row
+    with RasterReader(str(tmp_path / "one.tif")) as r1, RasterReader(str(tmp_path / "bands.tif")) as r2:
+        got = r2.read()
+        assert got.dtype == a.dtype and np.array_equal(got, a) and np.array_equal(r1.read(), a)
+        assert r1.transform == r2.transform and r1.nodata == r2.nodata
+        assert np.array_equal(r2.read_window(H // 2, 40), a[H // 2:H // 2 + 40])
+
+
+def test_band_writer_refuses_a_tile_row_over_three_bands(tmp_path):
+    from malstroem_amd.distributed import ThreadComm
+    from malstroem_amd.io import BandRasterWriter
+    c = ThreadComm.world(3)[0]
+    with pytest.raises(ValueError):
+        BandRasterWriter(str(tmp_path / "x.tif"), None, None).write(c, (300, 64), [(0, 100), (100, 100), (200, 100)], lambda a, b: None, np.float32)
+
+
 def test_nodata_substitution_follows_the_reference_rule(tmp_path):
     a = np.array([[1.0, -9999.0, 3.0], [0.0, 5.0, -9999.0]], dtype=np.float32)
     p1, p2 = str(tmp_path / "n1.tif"), str(tmp_path / "n0.tif")

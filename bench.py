@@ -515,6 +515,7 @@ def main():
         info = {k: pipe.get_int(k) for k in keys}
         for k in ("fill_algorithm", "fill_launches", "noflat_algorithm") + (() if config2 else ("pour_algorithm",)):
             info[k] = pipe.get_int(k)
+        info["engines_seen_in_timed_steps"] = {k: sorted(v) for k, v in engines_seen.items()}
         info["engines"] = ENGINE_NOTE
         if info["noflat_algorithm"] not in (2, 3):
             info["noflat_reject"] = {k: pipe.get_int("noflat_reject" + k) for k in ("", "_irregular", "_unreached", "_mismatch")}

@@ -934,17 +934,18 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             if (ok) lv[u] = a.Lv[(size_t)(p * a.ntc + q) * NSMAX + k];
         }
 #pragma unroll
-        for (int u = 0; u < NLV; ++u) L[t + u * ST] = lv[u];
+        for (int u = 0; u < NLV; ++u) {       // (the block's own levels also as loaded, in front of the barrier: see pf_solve_queue_body)
+            const int i = t + u * ST;
+            const int rt = i / NSMAX, k = i - rt * NSMAX, ri = rt / RT, rj = rt - ri * RT;
+            L[i] = lv[u];
+            if (ri >= 1 && ri <= BT && rj >= 1 && rj <= BT) Lold[((ri - 1) * BT + rj - 1) * NSMAX + k] = lv[u];
+        }
     }
-    // ---- the block's relaxations: registers for the whole visit (EMAX / ST = 6 per thread); in flight together with the levels
+    // ---- the block's relaxations: registers for the whole visit (EMAX / ST = 12 per thread); in flight together with the levels
     unsigned long long er[EMAX / ST];
 #pragma unroll
     for (int k = 0; k < EMAX / ST; ++k) er[k] = sa.eblk[(size_t)blk * EMAX + t + k * ST];
     __syncthreads();
-    for (int i = t; i < BT * BT * NSMAX; i += ST) {
-        const int bt = i / NSMAX, k = i - bt * NSMAX;
-        Lold[i] = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
-    }
 #ifdef PF_PROFILE
     pk1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1155,8 +1156,18 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
                 lv[u] = EMPTY;
                 if (ok) lv[u] = ld_sc1(&a.Lv[(size_t)(p * a.ntc + qq) * NSMAX + k]);
             }
+            // (the block's own levels a second time, as loaded: what a seed is compared with at the end of the visit.  Written HERE, in
+            // front of the barrier the sweeps start behind -- as a pass of its own between that barrier and the sweeps, a thread that
+            // was through with its copies lowered a level before another thread had copied it: the drop was never written back, nobody
+            // was woken, the proof failed -- seen in one step of six when the kernel was built for 64 registers, whose spills skew the
+            // waves; the rounds' kernel had the same window since round 2)
 #pragma unroll
-            for (int u = 0; u < NLV; ++u) L[t + u * ST] = lv[u];
+            for (int u = 0; u < NLV; ++u) {
+                const int i = t + u * ST;
+                const int rt = i / NSMAX, k = i - rt * NSMAX, ri = rt / RT, rj = rt - ri * RT;
+                L[i] = lv[u];
+                if (ri >= 1 && ri <= BT && rj >= 1 && rj <= BT) Lold[((ri - 1) * BT + rj - 1) * NSMAX + k] = lv[u];
+            }
         }
         // ---- the block's relaxations (read-only during the solve): only the used part of the packed array
         const int ne = ecount[blk];
@@ -1167,13 +1178,11 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
             if (t + k * ST < ne) er[k] = sa.eblk[(size_t)blk * EMAX + t + k * ST];
         }
         __syncthreads();
-        for (int i = t; i < BT * BT * NSMAX; i += ST) {
-            const int bt = i / NSMAX, k = i - bt * NSMAX;
-            Lold[i] = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
-        }
         // ---- the block's fixed point (only the levels are read from LDS)
+        int dbg_sweeps = 0;
         for (int it = 0; it < BT * BT * NSMAX; ++it) {
             bool ch = false;
+            ++dbg_sweeps;
 #pragma unroll
             for (int k = 0; k < EMAX / ST; ++k) {
                 const unsigned long long r = er[k];
@@ -1202,7 +1211,8 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every writing wave, before the barrier the wake-ups sit behind
-        if (wg_or(moved)) {
+        const bool dbg_moved = wg_or(moved);
+        if (dbg_moved) {
             unsigned wake = 0;
 #pragma unroll
             for (int k = 0; k < EMAX / ST; ++k) {
@@ -1244,6 +1254,10 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
             }
         }
         __syncthreads();
+        if (sa.first == 2 && t == 0) {      // (MHIP_PF_DEBUG: visits that lowered a seed, sweeps)
+            if (s_wake >= 0 && dbg_moved) atomicAdd(&q->pad2[0], 1u);
+            atomicAdd(&q->pad2[1], (unsigned int)dbg_sweeps);
+        }
         if (t == 0) {
             // woken while this visit ran (by a level that may have changed after it was loaded): once more, through the queue -- one
             // visit of a block at a time, none of them lost
@@ -1256,12 +1270,9 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
     }
 }
 
-// three workgroups per CU at up to 80 VGPRs, or four at 64 (the loads' address arithmetic then spills a dozen words once per visit)
+// three workgroups per CU at up to 80 VGPRs.  (Four at 64 -- the loads' address arithmetic then spills a dozen words once per visit --
+// were measured: fill 7.96 against 7.53 ms on the same box, tools/lab/qtest.sh; not kept.)
 __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void pf_solve_queue_kernel(SolveArgs sa, PfQueue *q, const int *__restrict__ ecount)
-{
-    pf_solve_queue_body(sa, q, ecount);
-}
-__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(8, 8))) void pf_solve_queue4_kernel(SolveArgs sa, PfQueue *q, const int *__restrict__ ecount)
 {
     pf_solve_queue_body(sa, q, ecount);
 }
@@ -1637,9 +1648,9 @@ int PfRun::solve(hipStream_t s)
         sa.nbr = m.nbr;
         sa.nbc = m.nbc;
         sa.eblk = m.eblk;
-        static const bool four = [] { const char *e = dev_env("MHIP_PF_QWG"); return e && e[0] == '4'; }();     // (development: A/B)
-        if (four) hipLaunchKernelGGL(pf_solve_queue4_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 1024)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);
-        else hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
+        sa.first = dev_env("MHIP_PF_DEBUG") ? 2 : 0;
+        static const int qgrid = [] { const char *e = dev_env("MHIP_PF_QGRID"); return e ? atoi(e) : 0; }();                // (development)
+        hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, qgrid ? qgrid : 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
         MH_HIP(hipGetLastError());
         m.launches += 2;
         unsigned int h_q[4] = {0, 0, 0, 0};      // head, tail, finished, abort
@@ -1653,7 +1664,12 @@ int PfRun::solve(hipStream_t s)
         m.mm_valid = true;
         m.solved_once = true;
         if (h_flag) return MHIP_ELIMIT;
-        if (dev_env("MHIP_PF_DEBUG")) fprintf(stderr, "[pf_solve queue] tickets taken %u, handed out %u, visits finished %u, abort %u\n", h_q[0], h_q[1], h_q[2], h_q[3]);
+        if (dev_env("MHIP_PF_DEBUG")) {
+            unsigned int h_d[2] = {0, 0};
+            MH_HIP(hipMemcpy(h_d, m.queue->pad2, 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pf_solve queue] tickets taken %u, handed out %u, visits finished %u (lowered a seed: %u, LDS sweeps %u), abort %u\n", h_q[0], h_q[1], h_q[2],
+                    h_d[0], h_d[1], h_q[3]);
+        }
         m.queue_visits += h_q[2];
         if (!h_q[3] && h_q[2] == h_q[1]) return MHIP_OK;
         // called off (never seen): the levels are upper bounds of the solution all the same -- the rounds finish the job

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void accum_band_exit_kernel(Nodes nd, int64_t 
     const bool present = k < W ? fixed_top != 0 : fixed_bot != 0;
     int32_t x = present ? nd.halo_first[k] : -1;
     if (x <= -2) res = -2 - x;
-    for (int64_t step = 0; x >= 0 && step < 4 * ntiles + 4; ++step) {     // x: an F_EXIT node; longer than every simple path = a flow cycle
+    for (int64_t step = 0; x >= 0 && step < ntiles * PERIM + 4; ++step) {     // x: an F_EXIT node; a simple path visits an exit node once (a meander crosses a tile's outline many times): longer = a flow cycle
         const int32_t d = nd.dst[x];
         int dr_, dc_, xr, xc;
         perim_cell(d % NODE_STRIDE, dr_, dc_);
@@ -651,8 +651,179 @@ __global__ __launch_bounds__(256) void accum_band_exit_kernel(Nodes nd, int64_t 
 }
 }  // namespace
 
+namespace {
+// ---- row bands, second pass as a DELTA over the first (round 4) -------------------------------------------------------------------
+// After the boundary pass a band holds the accumulation of its OWN cells (halo cells as sources of nothing); the neighbours' final
+// values X[h] of the halo cells then arrive, and  final[c] = own[c] + sum of X[h] over the halo cells h whose flow path runs through c.
+// The band used to accumulate a second time from scratch with the halo cells as sources (64-bit sums, both tile passes and the graph
+// walk again: 52 of 175 ms per step at 4 bands of 32768^2).  The perimeter graph of the first pass already says where every halo
+// cell's path goes: (A) one thread per halo cell follows its path from tile to tile and adds X[h] to the entry cells it passes
+// (the `inflow` words, cleared first) -- a few steps per halo cell, rivers merge but are walked separately --, marking the tiles it
+// touches; (B) a workgroup per TOUCHED tile lets every such entry (and every halo cell of the tile that flows into it) walk its
+// in-tile path and add its share, on the tile's own sums in LDS, and writes the tile back.  Tiles no halo flux reaches -- most of a
+// band -- are not read at all.  An unknown halo value (<= 0: a flow cycle upstream in the neighbouring band) or a path that does
+// not end (a cycle across tiles) raises `flag`: the caller then runs the full second pass.
+__global__ __launch_bounds__(256) void accum_delta_graph_kernel(Nodes nd, const uint8_t *__restrict__ fd, const double *__restrict__ out, int64_t H, int64_t W,
+                                                               int ntc, int64_t ntiles, int fixed_top, int fixed_bot, uint8_t *touched, unsigned int *flag)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * W) return;
+    const int side = k < W ? 0 : 1;
+    if (side == 0 ? !fixed_top : !fixed_bot) return;
+    const int64_t col = k - (int64_t)side * W, row = side == 0 ? 0 : H - 1;
+    auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
+    const unsigned code = fd[row * W + col];
+    if (code > 7u || dir_dr((int)code) == 0) return;
+    const int64_t tr = row + dir_dr((int)code), tc = col + dir_dc((int)code);
+    if (tr < 0 || tr >= H || tc < 0 || tc >= W || halo_row(tr)) return;      // the cell does not flow into the band
+    const double X = out[row * W + col];
+    if (!(X > 0.0)) {                 // not known (a flow cycle upstream, in the neighbouring band): everything below it stays unresolved
+        *flag = 1u;
+        return;
+    }
+    const unsigned long long D = (unsigned long long)X;
+    touched[(row / AT) * ntc + col / AT] = 1;
+    int32_t x = nd.halo_first[k];
+    int64_t step = 0;
+    const int64_t cap = ntiles * PERIM + 4;                     // a simple path visits an exit node once: longer = a flow cycle across tiles
+    for (; x >= 0 && step < cap; ++step) {                      // x: the exit node of the tile the path is in
+        const int32_t e = nd.dst[x];
+        int er, ec;
+        perim_cell(e % NODE_STRIDE, er, ec);
+        const int64_t egr = (int64_t)((e / NODE_STRIDE) / ntc) * AT + er;
+        if (halo_row(egr)) break;                               // the path leaves the band: its flux is the neighbour's business
+        atomicAdd(reinterpret_cast<unsigned long long *>(&nd.inflow[e]), D);
+        touched[e / NODE_STRIDE] = 1;
+        const uint16_t ex = nd.exit_of[e];
+        if (ex == NO_EXIT) break;
+        x = (e / NODE_STRIDE) * NODE_STRIDE + ex;
+    }
+    if (x >= 0 && step >= cap) *flag = 1u;
+}
+
+__global__ __launch_bounds__(ATN) void accum_delta_tile_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H, int64_t W, int ntc, Nodes nd,
+                                                              int fixed_top, int fixed_bot, const uint8_t *__restrict__ touched)
+{
+    const int tile = blockIdx.x;
+    if (!touched[tile]) return;                                  // (block-uniform)
+    __shared__ unsigned long long S[AT * AT];                    // own sum (0: unresolved -- stays 0 and ends every walk) + the shares added
+    __shared__ uint16_t P[AT * AT];
+    __shared__ uint32_t wl_cell[PERIM + AT * 2];
+    __shared__ unsigned long long wl_add[PERIM + AT * 2];
+    __shared__ uint32_t wl_n;
+    const int ti = tile / ntc, tj = tile - ti * ntc;
+    const int64_t r0 = (int64_t)ti * AT, c0 = (int64_t)tj * AT;
+    const int tid = threadIdx.x;
+    auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
+    if (tid == 0) wl_n = 0;
+    for (int i = tid; i < AT * AT; i += ATN) {
+        const int r = i / AT, c = i - r * AT;
+        const int64_t rr = r0 + r, cc = c0 + c;
+        const bool inside = rr < H && cc < W;
+        const bool owned = inside && !halo_row(rr);
+        const double own = owned ? out[rr * W + cc] : 0.0;
+        S[i] = own > 0.0 ? (unsigned long long)own : 0ull;
+        uint16_t nx = (uint16_t)SENT13;
+        const unsigned code = inside ? fd[rr * W + cc] : 8u;
+        if (owned && code <= 7u) {
+            const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
+            if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr)) nx = (uint16_t)(nr * AT + nc);
+        }
+        P[i] = nx;
+    }
+    __syncthreads();
+    // the walkers: the entry cells the graph pass left a share at, and the halo cells of this tile that flow into one of its cells
+    if (tid < PERIM) {
+        const unsigned long long d = nd.inflow[(int64_t)tile * NODE_STRIDE + tid];
+        int r, c;
+        perim_cell(tid, r, c);
+        if (d != 0ull && (r0 + r) < H && (c0 + c) < W && !halo_row(r0 + r)) {
+            const uint32_t kk = atomicAdd(&wl_n, 1u);
+            wl_cell[kk] = (uint32_t)(r * AT + c);
+            wl_add[kk] = d;
+        }
+    }
+    for (int side = 0; side < 2; ++side) {
+        const int64_t hr = side == 0 ? 0 : H - 1;
+        if ((side == 0 ? !fixed_top : !fixed_bot) || hr < r0 || hr >= r0 + AT) continue;
+        if (tid < AT && c0 + tid < W) {
+            const int r = (int)(hr - r0), c = tid;
+            const unsigned code = fd[hr * W + c0 + c];
+            const double X = out[hr * W + c0 + c];
+            if (code <= 7u && dir_dr((int)code) != 0 && X > 0.0) {
+                const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
+                if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr)) {
+                    const uint32_t kk = atomicAdd(&wl_n, 1u);
+                    wl_cell[kk] = (uint32_t)(nr * AT + nc);
+                    wl_add[kk] = (unsigned long long)X;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nw = wl_n;
+    for (uint32_t w = tid; w < nw; w += ATN) {
+        uint32_t a = wl_cell[w];
+        const unsigned long long v = wl_add[w];
+        do {
+            if (S[a] == 0ull) break;                  // unresolved in the first pass: stays 0, and so does everything below it
+            atomicAdd(&S[a], v);
+            a = P[a];
+        } while (a != SENT13);
+    }
+    __syncthreads();
+    for (int i = tid; i < AT * AT; i += ATN) {
+        const int r = i / AT, c = i - r * AT;
+        const int64_t rr = r0 + r, cc = c0 + c;
+        if (rr < H && cc < W && !halo_row(rr)) out[rr * W + cc] = (double)S[i];
+    }
+}
+}  // namespace
+
+// the second pass of a row band as a delta over the kept perimeter graph of the boundary pass; *done == false: not applicable
+// (no kept graph, an unknown halo value, a flow cycle across tiles) -- the caller runs the full pass
+int accum_band_delta_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot, AccumKeep *keep, bool *done)
+{
+    *done = false;
+    if (!keep || !keep->valid || keep->H != H || keep->W != W || keep->fixed_top != fixed_top || keep->fixed_bot != fixed_bot || !keep->nodes.p) return MHIP_OK;
+    static const bool off = [] { const char *e = dev_env("MHIP_BAND_ACC"); return e && std::string(e) == "full"; }();      // (development: A/B)
+    if (off) return MHIP_OK;
+    const int ntr = (int)cdiv(H, AT), ntc = (int)cdiv(W, AT);
+    const int64_t ntiles = (int64_t)ntr * ntc, nnodes = ntiles * NODE_STRIDE;
+    char *b = keep->nodes.as<char>();
+    Nodes nd;
+    nd.gstate = reinterpret_cast<uint64_t *>(b + keep->o[0]);
+    nd.inflow = reinterpret_cast<uint64_t *>(b + keep->o[1]);
+    nd.arrived = reinterpret_cast<uint32_t *>(b + keep->o[2]);
+    nd.next = reinterpret_cast<int32_t *>(b + keep->o[3]);
+    nd.dst = reinterpret_cast<int32_t *>(b + keep->o[4]);
+    nd.exit_of = reinterpret_cast<uint16_t *>(b + keep->o[5]);
+    nd.flags = reinterpret_cast<uint8_t *>(b + keep->o[6]);
+    nd.halo_first = reinterpret_cast<int32_t *>(b + keep->o[7]);
+    nd.bexit = reinterpret_cast<int32_t *>(b + keep->o[8]);
+    DevBuf aux;
+    MH_TRY(aux.alloc((size_t)ntiles + 64));
+    uint8_t *touched = aux.as<uint8_t>() + 64;
+    unsigned int *flag = aux.as<unsigned int>();
+    MH_HIP(hipMemsetAsync(aux.p, 0, (size_t)ntiles + 64, s));
+    MH_HIP(hipMemsetAsync(nd.inflow, 0, 8 * (size_t)nnodes, s));
+    hipLaunchKernelGGL(accum_delta_graph_kernel, dim3((unsigned)cdiv(2 * W, 256)), dim3(256), 0, s, nd, d_fd, (const double *)d_out, H, W, ntc, ntiles, fixed_top,
+                       fixed_bot, touched, flag);
+    MH_HIP(hipGetLastError());
+    unsigned int h_flag = 0;
+    MH_HIP(hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, s));
+    MH_HIP(stream_sync(s));
+    keep->valid = false;                  // (one use: the halo values it was fed are this exchange's)
+    if (h_flag) return MHIP_OK;           // nothing has been written yet: the full pass takes over
+    hipLaunchKernelGGL(accum_delta_tile_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, (const uint8_t *)touched);
+    MH_HIP(hipGetLastError());
+    MH_HIP(stream_sync(s));               // (aux goes back to the pool)
+    *done = true;
+    return MHIP_OK;
+}
+
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot, int halo_zero,
-              int32_t *d_exit_map, PourLink *pour)
+              int32_t *d_exit_map, PourLink *pour, AccumKeep *keep)
 {
     const int ntr = (int)cdiv(H, AT), ntc = (int)cdiv(W, AT);
     const int64_t ntiles = (int64_t)ntr * ntc, nnodes = ntiles * NODE_STRIDE;
@@ -707,12 +878,24 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
         }
         hipLaunchKernelGGL(accum_final_walk_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, pc);
     }
-    else if (!(fixed_top || fixed_bot) && H * W < (int64_t)0x7fffffff)
+    else if ((!(fixed_top || fixed_bot) || halo_zero) && H * W < (int64_t)0x7fffffff)      // (halo_zero: a band's OWN cells only -- no sum passes their number)
         hipLaunchKernelGGL((accum_tile_kernel<true, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else
         hipLaunchKernelGGL((accum_tile_kernel<true, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     MH_HIP(hipGetLastError());
-    MH_HIP(stream_sync(s));  // the node buffer goes back to the pool
+    MH_HIP(stream_sync(s));  // the node buffer goes back to the pool -- or, after the boundary pass of a row band, stays for the delta pass
+    if (keep) {
+        keep->valid = false;
+        if (d_exit_map) {
+            keep->nodes.release();
+            keep->nodes.p = buf.p; keep->nodes.bytes = buf.bytes;
+            buf.p = nullptr; buf.bytes = 0;
+            const size_t offs[9] = {o_gstate, o_inflow, o_arrived, o_next, o_dst, o_exit, o_flags, o_halo, o_bexit};
+            for (int k = 0; k < 9; ++k) keep->o[k] = offs[k];
+            keep->H = H; keep->W = W; keep->fixed_top = fixed_top; keep->fixed_bot = fixed_bot;
+            keep->valid = true;
+        }
+    }
 #ifdef MH_PROFILE_ACCUM
     {
         unsigned long long pr[2][8];

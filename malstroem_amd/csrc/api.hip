@@ -548,6 +548,8 @@ struct mhip_ctx {
     bool have[MHIP_R_COUNT_] = {};
     DevBuf tmp_i32;         // CCL parent scratch
     DevBuf raw_stats, stats, ws_counts, pour;
+    AccumKeep acc_keep;     // row band: the perimeter graph of mhip_ctx_band_accum_boundary, for the ACCUM run that follows the exchange
+    int accum_algorithm = 0;   // 0: full accumulation, 1: the band's second pass as a delta over the kept graph
     DevBuf pp_mask0, pp_list, pp_tiles, pp_misc, pp_key;    // pour-point candidates on their way from the watersheds to the accumulation (PourLink)
     hipEvent_t ev_cand = nullptr;
     int pour_algorithm = 0;
@@ -728,6 +730,7 @@ int mhip_ctx_upload(mhip_ctx *c, int which, const void *host)
             if (k != MHIP_R_DEM) c->have[k] = false;
     if (which == MHIP_R_LABELS) { c->nlabels = -1; c->nlabels_raw = -1; c->labels_filtered = true; c->labels_components = false; }
     if (which == MHIP_R_FLOWDIR) c->nodir_valid = false;
+    if (which == MHIP_R_FLOWDIR || which == MHIP_R_DEM || which == MHIP_R_ACCUM) c->acc_keep.valid = false;
     return MHIP_OK;
 }
 
@@ -941,7 +944,7 @@ int mhip_ctx_band_accum_boundary(mhip_ctx *c, int32_t *exit_map)
     DevBuf d_map;
     MH_TRY(d_map.alloc(8 * (size_t)c->W));
     MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, cs(c), c->ht, c->hb, 1,
-                     d_map.as<int32_t>()));
+                     d_map.as<int32_t>(), nullptr, &c->acc_keep));
     MH_HIP(hipMemcpyAsync(exit_map, d_map.p, 8 * (size_t)c->W, hipMemcpyDeviceToHost, cs(c)));
     MH_HIP(stream_sync(cs(c)));
     return MHIP_OK;
@@ -1634,6 +1637,7 @@ static int stage_flowdir(mhip_ctx *c, hipStream_t s)
     MH_TRY(ctx_raster(c, MHIP_R_FLOWDIR));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_FLOWDIR, s, &e1));
+    c->acc_keep.valid = false;
     MH_TRY(c->nodir_cnt.alloc(4));
     MH_HIP(hipMemsetAsync(c->nodir_cnt.p, 0, 4, s));
     MH_TRY(d8_dev(c->r[MHIP_R_NOFLAT].as<double>(), c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->H, c->W, 1, s, c->row0 - c->ht,
@@ -1663,7 +1667,15 @@ static int stage_accum(mhip_ctx *c, hipStream_t s, PourLink *pour = nullptr)
     MH_TRY(ctx_raster(c, MHIP_R_ACCUM));
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_ACCUM, s, &e1));
-    MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, s, c->ht, c->hb, 0, nullptr, pour));
+    bool delta_done = false;
+    // a row band right behind its boundary pass (own contributions in ACCUM, the neighbours' values in the halo rows by now): only
+    // the flux that enters at the seams is added, along the paths the kept perimeter graph says it takes (accum.hip)
+    if ((c->ht || c->hb) && c->acc_keep.valid)
+        MH_TRY(accum_band_delta_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, s, c->ht, c->hb, &c->acc_keep, &delta_done));
+    c->accum_algorithm = delta_done ? 1 : 0;
+    c->acc_keep.valid = false;
+    if (!delta_done)
+        MH_TRY(accum_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_ACCUM].as<double>(), c->H, c->W, s, c->ht, c->hb, 0, nullptr, pour));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_ACCUM] = true;
     c->have[MHIP_R_ACCUM] = true;
@@ -2054,6 +2066,7 @@ int mhip_ctx_get_i64(mhip_ctx *c, const char *key, int64_t *value)
     else if (k == "fill_launches") *value = c->fill_st.rounds;
     else if (k == "fill_hot_launches") *value = c->fill_st.hot_launches;
     else if (k == "noflat_hot_launches") *value = c->noflat_st.hot_launches;
+    else if (k == "accum_algorithm") *value = c->accum_algorithm;   // 0 full accumulation, 1 a row band's second pass as a delta over the boundary pass's graph
     else if (k == "pour_algorithm") *value = c->pour_algorithm;   // 0 a pass over values + labels (label_ops.hip), 1 keys out of the accumulation's final pass (PourLink)
     else if (k == "noflat_algorithm") *value = c->noflat_st.algorithm;   // 0 float64 relaxation (fill.hip), 2 integer geodesic transform (noflat_geo.hip)
     else if (k == "noflat_visits") *value = c->noflat_st.visits;

@@ -331,8 +331,16 @@ struct PourLink {                // host side: hand-over between the thread of t
     bool consumed = false;                         // the final pass has written the keys
 };
 // accum.hip
+struct AccumKeep {               // the perimeter graph of a row band's boundary pass, kept for the delta pass that follows it
+    DevBuf nodes;
+    size_t o[9] = {};
+    int64_t H = 0, W = 0;
+    int fixed_top = 0, fixed_bot = 0;
+    bool valid = false;
+};
 int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top = 0, int fixed_bot = 0, int halo_zero = 0,
-              int32_t *d_exit_map = nullptr, PourLink *pour = nullptr);
+              int32_t *d_exit_map = nullptr, PourLink *pour = nullptr, AccumKeep *keep = nullptr);
+int accum_band_delta_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStream_t s, int fixed_top, int fixed_bot, AccumKeep *keep, bool *done);
 // ccl.hip   (d_tmp: H*W int32 scratch)
 // stats_out: the labelling's last pass also reduces label_stats(d_data, labels) into *stats_out (allocated here: nlabels + 1 records)
 int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,

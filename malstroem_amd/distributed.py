@@ -860,10 +860,10 @@ class BandPipeline(object):
     def engines(self):
         """Which engine the last fill / no-flats fill of this band ran (``ctx_get_int``: fill 1 = tiled priority-flood, 0 = iterative
         schedule, 4 = flood + iterative repair; no-flats 2 = integer geodesic transform, 3 = + float64 relaxation of irregular flats,
-        0 = float64 relaxation): a silent fall-back is 2-3x slower and ``bench.py`` refuses to report it.  ``None``: a stand-in
-        backend that does not say."""
+        0 = float64 relaxation; accumulation 1 = the second pass as a delta over the boundary pass's perimeter graph, 0 = a full second
+        pass): a silent fall-back is 2-3x slower and ``bench.py`` refuses to report it.  ``None``: a stand-in backend that does not say."""
         out = {}
-        for name, key in (("fill", "fill_algorithm"), ("noflat", "noflat_algorithm")):
+        for name, key in (("fill", "fill_algorithm"), ("noflat", "noflat_algorithm"), ("accum", "accum_algorithm")):
             try:
                 out[name] = int(self.band.get_int(key))
             except Exception:

@@ -330,9 +330,16 @@ int mhip_ctx_trace_downstream(mhip_ctx *ctx, const int64_t *cells_rc, int64_t n,
                               int32_t *out_label, int32_t *out_found, int64_t *out_len, const int64_t *offsets, int64_t *out_cells);
 /* after mhip_ctx_sync: milliseconds (HIP events on the ctx stream) of `stage` (single bit) in the last run */
 int mhip_ctx_stage_ms(mhip_ctx *ctx, int stage, float *ms);
-/* milliseconds / launch count of one named kernel family in the last run ("d8", "fill_round", ...) */
+/* milliseconds / launch count of one named kernel family in the last run ("d8", "fill_round", "noflat_round");
+ * "d8_steady" is a measurement of its own: it LAUNCHES the D8 stencil on the resident no-flats surface 16 times back to back
+ * between one pair of events (steady-state throughput; an undivided context only) and returns their total */
 int mhip_ctx_kernel_ms(mhip_ctx *ctx, const char *kernel, float *ms_total, int32_t *launches);
-int mhip_ctx_get_i64(mhip_ctx *ctx, const char *key, int64_t *value); /* "nlabels_raw", "nlabels", "fill_rounds", ... */
+/* "nlabels_raw", "nlabels", "fill_rounds", "fill_launches", "fill_visits", "noflat_rounds", "noflat_visits", ... and which engine
+ * the last run of a stage took: "fill_algorithm" (1 tiled priority-flood, 0 iterative schedule, 4 flood + iterative repair),
+ * "noflat_algorithm" (2 integer geodesic transform, 3 + float64 relaxation of irregular flats, 0 float64 relaxation; why a
+ * transform was handed back: "noflat_reject*"), "pour_algorithm" (1 keys out of the accumulation's final pass, 0 a pass over
+ * values + labels), "accum_algorithm" (row bands: 1 the second pass as a delta over the boundary pass's graph, 0 a full pass) */
+int mhip_ctx_get_i64(mhip_ctx *ctx, const char *key, int64_t *value);
 int mhip_ctx_get_f64(mhip_ctx *ctx, const char *key, double *value);  /* "short", "diag" */
 /* label filter between MHIP_STAGE_LABEL and MHIP_STAGE_WATERSHED (reference bluespots.py:165-172):
  * download raw stats (nlabels_raw+1 records), decide on host, upload keep flags. */

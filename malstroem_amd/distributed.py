@@ -248,6 +248,11 @@ def wire_loads(buf):
     return obj
 
 
+def _is_loopback(addr):
+    a = str(addr).strip().lower()
+    return a in ("localhost", "::1", "") or a.startswith("127.")
+
+
 class SocketComm(Comm):
     """Control-plane transport over plain TCP sockets (stdlib only): rank 0 listens on (addr, port), every other rank
     connects once; a collective is "send my object to rank 0, receive the list of everybody's" in the data-only wire format above
@@ -266,6 +271,11 @@ class SocketComm(Comm):
         if secret is None:
             secret = os.environ.get("MALSTROEM_COMM_SECRET")
         self._secret = secret.encode("utf-8") if isinstance(secret, str) else secret
+        # Without a secret the HMAC key is empty, i.e. anybody who reaches the port can join as a rank (and feed halo rows or the
+        # ncclUniqueId): fine on the loopback interface, refused on any other address
+        if int(size) > 1 and not self._secret and not _is_loopback(addr):
+            raise ValueError("SocketComm on %r needs a shared secret (MALSTROEM_COMM_SECRET, or secret=...): without one any host that "
+                             "reaches the port could join as a rank" % (addr,))
         self._lock = threading.Lock()
         self._nclones = 0
         if _socks is not None:
@@ -336,9 +346,15 @@ class SocketComm(Comm):
     def _send_msg(cls, sock, payload):
         sock.sendall(struct.pack("<q", len(payload)) + payload)
 
+    # the largest message a peer may announce (the seam systems gather a few MB, `gather_rows` a window of rows): a length word
+    # beyond this is a broken or hostile peer, not something to allocate
+    MAX_MESSAGE = int(os.environ.get("MALSTROEM_COMM_MAX_MESSAGE", 8 << 30))
+
     @classmethod
     def _recv_msg(cls, sock):
         n = struct.unpack("<q", cls._recv_exact(sock, 8))[0]
+        if n < 0 or n > cls.MAX_MESSAGE:
+            raise ConnectionError("SocketComm: a peer announced a message of %d bytes (limit %d, MALSTROEM_COMM_MAX_MESSAGE)" % (n, cls.MAX_MESSAGE))
         return cls._recv_exact(sock, n)
 
     def allgather(self, obj):

@@ -513,3 +513,24 @@ def test_socketcomm_refuses_strangers_and_speaks_data_only():
         D.wire_dumps(object())
     with pytest.raises(ValueError):
         D.wire_loads(b"?")
+
+
+def test_socket_comm_wants_a_secret_off_the_loopback_interface(monkeypatch):
+    """without MALSTROEM_COMM_SECRET the HMAC key of the handshake is empty -- anybody who reaches the port could join as a
+    rank.  Fine on 127.0.0.1, refused on any other address; and a length word beyond the message limit is a broken peer, not an
+    allocation."""
+    import socket
+    import struct
+    from malstroem_amd.distributed import SocketComm
+    monkeypatch.delenv("MALSTROEM_COMM_SECRET", raising=False)
+    with pytest.raises(ValueError):
+        SocketComm(1, 2, addr="10.11.12.13", port=29999, timeout_s=0.2)
+    assert SocketComm(0, 1, addr="10.11.12.13").size == 1          # (a single rank opens nothing)
+    a, b = socket.socketpair()
+    try:
+        a.sendall(struct.pack("<q", SocketComm.MAX_MESSAGE + 1))
+        with pytest.raises(ConnectionError):
+            SocketComm._recv_msg(b)
+    finally:
+        a.close()
+        b.close()

@@ -1012,22 +1012,29 @@ __device__ __forceinline__ void visit(const GeoArgs &a, int t, const uint32_t *t
 #endif
 }
 
-template <bool FIRST>
+// WPB: wavefronts per workgroup.  Four (68 KB of LDS a workgroup) while the rounds have the chip to themselves; ONE (18.7 KB) for the
+// tail rounds when the label branch runs beside them (mhip_ctx_run, MHIP_LABEL_START=1): a 68 KB workgroup of four 242-register
+// waves only fits a CU from which half of the labelling's workgroups have gone -- and the dispatcher refills every gap with the
+// labelling's small ones first, because THEY fit (no-flats stage 6.8 -> 9.5 ms in round 3 and again in round 4) --, a single wave with
+// 18.7 KB fits as soon as one of them leaves.
+template <bool FIRST, int WPB = 4>
 __device__ __forceinline__ void round_body(const GeoArgs &a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t scr_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(lds + wave * (WN * (WN + 1)));
-    uint32_t *tab_l = lds + 4 * (WN * (WN + 1));
+    uint32_t *tab_l = lds + WPB * (WN * (WN + 1));
     // (the table's two words per thread and the round's tile count in flight together: as a loop, then the count behind the barrier, they
     // were three dependent round trips in front of every launch)
-    const int nwaves = (int)gridDim.x * 4, gw = (int)blockIdx.x * 4 + wave;
-    const uint32_t tw0 = a.tab[threadIdx.x], tw1 = a.tab[threadIdx.x + 256];
+    const int nwaves = (int)gridDim.x * WPB, gw = (int)blockIdx.x * WPB + wave;
+    uint32_t tw[512 / (64 * WPB)];
+#pragma unroll
+    for (int k = 0; k < 512 / (64 * WPB); ++k) tw[k] = a.tab[threadIdx.x + k * 64 * WPB];
     const int n = FIRST ? a.nt : (int)__builtin_amdgcn_readfirstlane((int)*a.count);
     const int t_first = FIRST ? 0 : a.list[gw < a.nt ? gw : a.nt - 1];      // (this wave's first tile, if the round has that many: no fourth trip)
-    tab_l[threadIdx.x] = tw0;
-    tab_l[threadIdx.x + 256] = tw1;
+#pragma unroll
+    for (int k = 0; k < 512 / (64 * WPB); ++k) tab_l[threadIdx.x + k * 64 * WPB] = tw[k];
     __syncthreads();
     unsigned visits = 0, cycles = 0;
     for (int i = gw; i < n; i += nwaves) {
@@ -1042,6 +1049,7 @@ __device__ __forceinline__ void round_body(const GeoArgs &a)
 }
 __global__ __launch_bounds__(256, 2) void ng_first_kernel(GeoArgs a) { round_body<true>(a); }
 __global__ __launch_bounds__(256, 2) void ng_round_kernel(GeoArgs a) { round_body<false>(a); }
+__global__ __launch_bounds__(64, 2) void ng_round_w1_kernel(GeoArgs a) { round_body<false, 1>(a); }
 
 // ---- the marks of one round -> the tile list of the next (clears the marks) --------------------------------------------------
 // The mark bytes are read as 64-bit words (the array is padded to a multiple of 8 bytes), one word per thread; the order of the
@@ -1332,7 +1340,10 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
             a.list_next = odd ? m.d_list : m.d_list2;
             a.count_next = m.d_any + m.round + 1;
         }
-        hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), m.lds, s, a);
+        if (m.light && tail_hook)      // (the label branch runs beside these rounds: one wavefront per workgroup, see round_body)
+            hipLaunchKernelGGL(ng_round_w1_kernel, dim3((unsigned)std::min<int64_t>(m.nt, 2048)), dim3(64), (WN * (WN + 1) + 512) * sizeof(uint32_t), s, a);
+        else
+            hipLaunchKernelGGL(ng_round_kernel, dim3(grid), dim3(256), m.lds, s, a);
     }
     MH_HIP(hipGetLastError());
     return MHIP_OK;

@@ -127,7 +127,7 @@ STAGE_KERNELS = {"flowdir": ("d8_kernel", "d8s_kernel"), "fill": ("fill_round_ke
 
 
 FETCH_NOTE = ("FETCH_SIZE x 2 (calibrated on the streaming kernels of the same run, tools/pmc_traffic.py): exact for coalesced "
-              "streams, an UPPER BOUND for kernels that gather scattered sectors (ccl_*, ws_*, accum_*, ng_round, pf_link)")
+              "streams, an UPPER BOUND for kernels that gather scattered sectors (ccl_*, ws_*, accum_*, ng_round, pf_ring)")
 
 
 def lib_fingerprint():

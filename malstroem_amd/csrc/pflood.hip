@@ -13,11 +13,11 @@
 //                         the raster border) and the SEED it drains to (a ring cell that is a local pit, or OCEAN = the
 //                         raster border).  Out: basin slot per owned cell (u16), per-tile basin table (V, seed), the seed
 //                         of every ring cell, and the min spill elevation between pairs of seeds.
-//   K2 pf_link_kernel     a ring cell of tile T is an owned cell of a neighbouring tile T': both seeds it drains to are
-//                         joined by an edge of weight W_T'[cell]; de-duplicated per tile.
-//   K3 pf_pack_kernel /   minimax distance of every seed to OCEAN over (spill edges + links): worklist rounds over blocks of
-//      pf_solve_kernel    4 x 4 tiles; the block's relaxations are packed once and held in registers during a visit, the levels
-//                         of its 6 x 6 region of tiles in LDS.
+//   K2 pf_ring_kernel /   a ring cell of tile T is an owned cell of a neighbouring tile T': both seeds it drains to are
+//      pf_link2_kernel    joined by an edge of weight W_T'[cell]; de-duplicated per tile.
+//   K3 pf_pack_kernel /   minimax distance of every seed to OCEAN over (spill edges + links): block visits (4 x 4 tiles) taken from
+//      pf_solve_queue_    a queue inside ONE launch; the block's relaxations are packed once and held in registers during a visit,
+//      kernel             the levels of its 6 x 6 region of tiles in LDS (pf_solve_kernel: the same visits as one launch per round).
 //   K4 pf_final_kernel /  level of a basin = max(V, L[seed]);  F[c] = max(dem[c], level[basin[c]]), depths = F - dem.
 //      pf_apply_kernel
 //
@@ -66,6 +66,7 @@ struct PfArgs {
     unsigned long long *links;  // [ntiles * LMAX]   (myLab << 48 | dir << 40 | nbrLab << 32 | w)
     int *tileNL;            // [ntiles] links of the tile = tileNL0 links between tiles + the band's halo links
     int *tileNL0;           // [ntiles]
+    unsigned long long *ringRec;   // [ntiles * 256] per ring position of a tile: its own seed << 40 | the owner tile's seed << 32 | the cell's fill level there (pf_ring_kernel)
     int fixed_top, fixed_bot;   // row band: local row 0 / H - 1 is a halo row of the neighbouring band (a ring row, not a raster border)
     uint32_t *Lv;           // [ntiles * NSMAX] minimax level of every seed (keys)
     unsigned int *flags;    // [0]: overflow
@@ -732,8 +733,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #endif
 }
 
-// ---- K2: the two seeds of a ring cell (its own tile's and its owner's) are joined at the owner's fill level of the cell
-__global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
+// ---- K2: the two seeds of a ring cell (its own tile's and its owner's) are joined at the owner's fill level of the cell.
+// In two passes since round 4.  Until then one kernel gathered, per tile, the ring cells of all NINE windows around it (a cell
+// concerns a tile as the window's tile or as its owner): 2 x 252 useful entries out of 9 x 252 candidates, nine dependent gather
+// chains per thread, the ring COLUMNS a sector per cell -- 0.60 ms, 12 B of traffic per raster cell.  Split: (A) every tile resolves
+// its OWN ring once (one entry per thread, one gather chain: slot -> owner's tables) into a record per ring position; (B) a tile's
+// links are its own 252 records + the 252 records of its eight neighbours whose cells it owns -- four contiguous runs of 62 and
+// four corners, all coalesced -- through the same LDS hash as before.  Same links, bit for bit (the tests that pin the flood pin them);
+// 0.60 -> 0.54 ms (fill 7.51 -> 7.45 ms, same box, alternating): pass A is still one chain of three dependent gathers per ring cell.
+__global__ __launch_bounds__(256) void pf_ring_kernel(PfArgs a)
+{
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
+    unsigned long long rec = ~0ull;
+    if (t < 252) {
+        int wr, wc;
+        ring_cell(t, wr, wc);
+        const int64_t r = (int64_t)ti * TI + wr, c = (int64_t)tj * TI + wc;
+        if (!(r <= 0 || r >= a.H - 1 || c <= 0 || c >= a.W - 1)) {          // inside the raster and not a raster border cell
+            const int oi = (int)((r - 1) / TI), oj = (int)((c - 1) / TI);     // the tile that owns the cell
+            const int ot = oi * a.ntc + oj;
+            const uint32_t labX = a.ringLab[(size_t)tile * 256 + t];
+            const int so = min((int)a.bslot[r * a.W + c], NBMAX - 1);          // (a tile that gave up on a capacity wrote no slots: stay inside the tables)
+            const uint32_t labO = a.tabL[(size_t)ot * NBMAX + so];
+            const uint32_t w = max(dem_key(a.dem[r * a.W + c]), a.tabV[(size_t)ot * NBMAX + so]);
+            rec = ((unsigned long long)labX << 40) | ((unsigned long long)labO << 32) | w;
+        }
+    }
+    a.ringRec[(size_t)tile * 256 + t] = rec;
+}
+
+__global__ __launch_bounds__(256) void pf_link2_kernel(PfArgs a)
 {
     __shared__ uint32_t lk[LH], lw[LH];
     __shared__ int s_cnt;
@@ -741,34 +771,40 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
     const int tile = blockIdx.x, ti = tile / a.ntc, tj = tile - ti * a.ntc;
     for (int i = t; i < LH; i += 256) { lk[i] = EMPTY; lw[i] = EMPTY; }
     if (t == 0) s_cnt = 0;
+    // this thread's two entries: one of the tile's own ring (e < 252), one of a neighbour's ring cell the tile owns
+    unsigned long long rec[2] = {~0ull, ~0ull};
+    int dirs[2] = {4, 4};
+    bool own[2] = {true, false};
+    if (t < 252) {
+        rec[0] = a.ringRec[(size_t)tile * 256 + t];
+        int wr, wc;
+        ring_cell(t, wr, wc);
+        const int di = wr == 0 ? -1 : (wr == WN - 1 ? 1 : 0), dj = wc == 0 ? -1 : (wc == WN - 1 ? 1 : 0);     // where the cell's owner lies
+        dirs[0] = (di + 1) * 3 + (dj + 1);
+        // the neighbour (di2, dj2) and the ring position of its window that is a cell of MINE
+        const int q = t;
+        int di2, dj2, p;
+        if (q < 62) { di2 = -1; dj2 = 0; p = WN + 1 + q; }                               // above: its bottom ring row, columns 1 .. 62
+        else if (q < 124) { di2 = 1; dj2 = 0; p = 1 + (q - 62); }                         // below: its top ring row
+        else if (q < 186) { di2 = 0; dj2 = -1; p = 2 * WN + (WN - 2) + (q - 124); }       // left: its right ring column, rows 1 .. 62
+        else if (q < 248) { di2 = 0; dj2 = 1; p = 2 * WN + (q - 186); }                   // right: its left ring column
+        else if (q == 248) { di2 = -1; dj2 = -1; p = WN + WN - 1; }                       // the four corners
+        else if (q == 249) { di2 = -1; dj2 = 1; p = WN; }
+        else if (q == 250) { di2 = 1; dj2 = -1; p = WN - 1; }
+        else { di2 = 1; dj2 = 1; p = 0; }
+        const int xi = ti + di2, xj = tj + dj2;
+        if (xi >= 0 && xi < a.ntr && xj >= 0 && xj < a.ntc) rec[1] = a.ringRec[(size_t)(xi * a.ntc + xj) * 256 + p];
+        dirs[1] = (di2 + 1) * 3 + (dj2 + 1);
+    }
     __syncthreads();
     bool ov = false;
-    // ring cells of the 3 x 3 tiles around (and including) this one; an entry concerns this tile when it is the cell's
-    // window tile (x == 4) or its owner
-    for (int e = t; e < 9 * 252; e += 256) {
-        const int x = e / 252, p = e - x * 252;
-        const int xi = ti + x / 3 - 1, xj = tj + x % 3 - 1;
-        if (xi < 0 || xi >= a.ntr || xj < 0 || xj >= a.ntc) continue;
-        int wr, wc;
-        ring_cell(p, wr, wc);
-        const int64_t r = (int64_t)xi * TI + wr, c = (int64_t)xj * TI + wc;
-        if (r <= 0 || r >= a.H - 1 || c <= 0 || c >= a.W - 1) continue;   // outside the raster or a raster border cell
-        const int oi = (int)((r - 1) / TI), oj = (int)((c - 1) / TI);       // the tile that owns the cell
-        const int xt = xi * a.ntc + xj, ot = oi * a.ntc + oj;
-        if (x == 4 ? false : ot != tile) continue;
-        const uint32_t labX = a.ringLab[(size_t)xt * 256 + p];
-        // (a tile that gave up on a capacity wrote no slots: whatever the word holds must stay inside the tables; the result of
-        // the run is discarded anyway -- the overflow flag is up)
-        const int so = min((int)a.bslot[r * a.W + c], NBMAX - 1);
-        const uint32_t labO = a.tabL[(size_t)ot * NBMAX + so];
-        const uint32_t w = max(dem_key(a.dem[r * a.W + c]), a.tabV[(size_t)ot * NBMAX + so]);
-        uint32_t mylab, nlab;
-        int di, dj;
-        if (x == 4) { mylab = labX; nlab = labO; di = oi - ti; dj = oj - tj; }
-        else { mylab = labO; nlab = labX; di = xi - ti; dj = xj - tj; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (rec[u] == ~0ull) continue;
+        const uint32_t labX = (uint32_t)(rec[u] >> 40) & 0xffu, labO = (uint32_t)(rec[u] >> 32) & 0xffu, w = (uint32_t)rec[u];
+        const uint32_t mylab = own[u] ? labX : labO, nlab = own[u] ? labO : labX;
         if (mylab == (uint32_t)OCEAN) continue;                            // OCEAN's level is fixed
-        const uint32_t dir = (uint32_t)((di + 1) * 3 + (dj + 1));
-        const uint32_t key = mylab << 16 | dir << 8 | nlab;
+        const uint32_t key = mylab << 16 | (uint32_t)dirs[u] << 8 | nlab;
         unsigned h = (key * 2654435761u) >> 22;
         bool done = false;
         for (int probe = 0; probe < 64; ++probe) {
@@ -798,9 +834,6 @@ __global__ __launch_bounds__(256) void pf_link_kernel(PfArgs a)
         a.tileNL[tile] = s_cnt;
         a.tileNL0[tile] = s_cnt;
     }
-#ifdef PF_PROFILE
-    if (t == 0) atomicAdd(&a.prof[12], (unsigned long long)s_cnt);
-#endif
     // start values of the solve: +inf for every seed (OCEAN is not stored: its level is below everything)
     if (t < NSMAX) a.Lv[(size_t)tile * NSMAX + t] = EMPTY;
 }
@@ -1751,6 +1784,7 @@ int PfRun::begin(hipStream_t s)
     const size_t o_ring = off; off = al(off + (size_t)ntiles * 256);
     const size_t o_spill = off; off = al(off + (size_t)ntiles * SPMAX * 8);
     const size_t o_links = off; off = al(off + (size_t)ntiles * LMAX * 8);
+    const size_t o_rrec = off; off = al(off + (size_t)ntiles * 256 * 8);
     const size_t o_lv = off; off = al(off + (size_t)ntiles * NSMAX * 4);
     // solve worklist: one active byte per block of BT x BT tiles, double buffered
     m.nbr = (int)cdiv(ntr, BT);
@@ -1792,6 +1826,7 @@ int PfRun::begin(hipStream_t s)
     a.spill = reinterpret_cast<unsigned long long *>(b + o_spill);
     a.tileNS = reinterpret_cast<int *>(b + o_ns);
     a.links = reinterpret_cast<unsigned long long *>(b + o_links);
+    a.ringRec = reinterpret_cast<unsigned long long *>(b + o_rrec);
     a.tileNL = reinterpret_cast<int *>(b + o_nl);
     a.tileNL0 = reinterpret_cast<int *>(b + o_nl0);
     a.Lv = reinterpret_cast<uint32_t *>(b + o_lv);
@@ -1863,7 +1898,10 @@ int PfRun::begin(hipStream_t s)
     hipLaunchKernelGGL(pf_tile_kernel, dim3((unsigned)ntiles), dim3(NT), 0, s, a);
     MH_HIP(hipEventRecord(m.k1_e1, s));
     hipLaunchKernelGGL(pf_minmax_kernel, dim3(64), dim3(256), 0, s, a.mm, ntiles * (NT / 64), m.mmout);
-    hipLaunchKernelGGL(pf_link_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
+    {
+        hipLaunchKernelGGL(pf_ring_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pf_link2_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, a);
+    }
     MH_TRY(pack(s, 0, m.nbr));
     MH_HIP(hipGetLastError());
     m.launches = 3;

@@ -131,11 +131,17 @@ FETCH_NOTE = ("FETCH_SIZE x 2 (calibrated on the streaming kernels of the same r
 
 
 def lib_fingerprint():
-    """sha256 (16 hex digits) of the shipped libmalstroem_hip.so: the PMC table records the library it was collected with"""
+    """sha256 (16 hex digits) over the library's SOURCES (csrc/*.hip, common.hpp, the Makefile, the C-ABI header, in name order): what
+    the PMC table records of the library it was collected with.  (The shared object's own bytes differ from build to build --
+    hipcc embeds build paths in the code object bundle --, the sources say which kernels ran.)"""
     import hashlib
-    from malstroem_amd import _lib
+    h = hashlib.sha256()
     try:
-        return hashlib.sha256(Path(_lib.LIB_PATH).read_bytes()).hexdigest()[:16]
+        src = sorted((ROOT / "malstroem_amd" / "csrc").glob("*.hip")) + [ROOT / "malstroem_amd" / "csrc" / "common.hpp",
+                                                                         ROOT / "malstroem_amd" / "csrc" / "Makefile", ROOT / "include" / "malstroem_hip.h"]
+        for f in src:
+            h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+        return h.hexdigest()[:16]
     except Exception:
         return None
 
@@ -168,7 +174,7 @@ def pmc_traffic(stage, n):
         return None
     fp = lib_fingerprint()
     out = {"source": "profiles/" + path.name, "fetch_correction": FETCH_NOTE,
-           "table_library": meta.get("library_sha256_16"), "table_matches_this_library": bool(fp and meta.get("library_sha256_16") == fp)}
+           "table_library": meta.get("library_sources_sha256_16"), "table_matches_this_library": bool(fp and meta.get("library_sources_sha256_16") == fp)}
     if stage == "flowdir":
         tot /= max(launches, 1)
         out.update({"hbm_bytes_per_launch": round(tot), "bytes_per_cell": round(tot / (float(n) * n), 2), "launches_in_table": launches})
@@ -565,7 +571,7 @@ def main():
                     "avg_launch_us": round(1e3 * kms / max(hot_launches[stage], 1), 1), "timed_by": "HIP events around the launches, on their stream"}
             rows, meta, path = pmc_table(n)
             fp = lib_fingerprint()
-            if rows is not None and fp and meta.get("library_sha256_16") == fp:
+            if rows is not None and fp and meta.get("library_sources_sha256_16") == fp:
                 # counter-based figures (HBM bytes the kernel MOVED / its time), only when the table was collected with this very
                 # library: they are traffic, not the algorithmic fraction the `frac` keys of this line carry
                 for row in rows:
@@ -578,7 +584,7 @@ def main():
                         break
             elif rows is not None:
                 out_["traffic_note"] = "profiles/%s was collected with another build of the library (%s != %s): no counter figures" % (
-                    path.name, meta.get("library_sha256_16"), fp)
+                    path.name, meta.get("library_sources_sha256_16"), fp)
             return out_
         out = {
             "metric": ("Mcells/s fill->D8 on %d^2 f32 DEM" if config2 else "Mcells/s fill->D8->accum->label on %d^2 f32 DEM") % n,

@@ -65,8 +65,12 @@ def main():
     # the number of chain steps in the profiled command (`--steps 1 --warmup 0`: one)
     import hashlib
     from pathlib import Path
-    lib = Path(__file__).resolve().parent.parent / "malstroem_amd" / "lib" / "libmalstroem_hip.so"
-    meta = {"library_sha256_16": hashlib.sha256(lib.read_bytes()).hexdigest()[:16] if lib.exists() else None,
+    root = Path(__file__).resolve().parent.parent
+    h = hashlib.sha256()       # (the same fingerprint as bench.lib_fingerprint: the library's sources, not the shared object's bytes)
+    for f in sorted((root / "malstroem_amd" / "csrc").glob("*.hip")) + [root / "malstroem_amd" / "csrc" / "common.hpp",
+                                                                        root / "malstroem_amd" / "csrc" / "Makefile", root / "include" / "malstroem_hip.h"]:
+        h.update(f.name.encode() + b"\0" + f.read_bytes() + b"\0")
+    meta = {"library_sources_sha256_16": h.hexdigest()[:16],
             "steps": int(sys.argv[4]) if len(sys.argv) > 4 else 1, "cells": n * n,
             "fetch_correction": "fetch_bytes_per_cell = 2 x FETCH_SIZE: exact for coalesced streams, an UPPER BOUND for scattered gathers"}
     print(json.dumps({"meta": meta, "kernels": rows}, indent=1))

@@ -943,6 +943,8 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     for (unsigned int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     __syncthreads();                                   // the LDS arrays of the previous visit are free
     const int blk = sa.first ? (int)wi : sa.list_cur[wi], bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
+    int tv = t;                                        // (a new name per visit: see pf_solve_queue_body -- the words' region coordinates stay out of scratch)
+    asm volatile("" : "+v"(tv));
     if (t == 0) {
         sa.mark_cur[blk] = 0u;                         // this buffer is appended to again two rounds from now
         s_wake = 0;
@@ -959,7 +961,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         uint32_t lv[NLV];
 #pragma unroll
         for (int u = 0; u < NLV; ++u) {
-            const int i = t + u * ST;
+            const int i = tv + u * ST;
             const int rt = i / NSMAX, k = i - rt * NSMAX;
             const int p = bi * BT + rt / RT - 1, q = bj * BT + rt % RT - 1;
             const bool ok = p >= 0 && p < a.ntr && q >= 0 && q < a.ntc;
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         }
 #pragma unroll
         for (int u = 0; u < NLV; ++u) {       // (the block's own levels also as loaded, in front of the barrier: see pf_solve_queue_body)
-            const int i = t + u * ST;
+            const int i = tv + u * ST;
             const int rt = i / NSMAX, k = i - rt * NSMAX, ri = rt / RT, rj = rt - ri * RT;
             L[i] = lv[u];
             if (ri >= 1 && ri <= BT && rj >= 1 && rj <= BT) Lold[((ri - 1) * BT + rj - 1) * NSMAX + k] = lv[u];
@@ -1006,7 +1008,7 @@ __global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 #endif
     // ---- write back; wake the neighbouring blocks that hold a link to a seed whose level dropped
     bool moved = false;
-    for (int i = t; i < BT * BT * NSMAX; i += ST) {
+    for (int i = tv; i < BT * BT * NSMAX; i += ST) {
         const int bt = i / NSMAX, k = i - bt * NSMAX;
         const int p = bi * BT + bt / BT, q = bj * BT + bt % BT;
         const uint32_t v = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
@@ -1126,7 +1128,8 @@ __global__ void pf_queue_init_kernel(PfQueue *q, unsigned int *mark, int nbr, in
 
 __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue *q, const int *__restrict__ ecount)
 {
-    __shared__ uint32_t L[RT * RT * NSMAX];            // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX
+    __shared__ uint32_t L[RT * RT * NSMAX + 4];        // 18 KB: levels of the region, tile (ri, rj) at (ri * RT + rj) * NSMAX; L[LSENT] = 0: OCEAN,
+    constexpr int LSENT = RT * RT * NSMAX;             // and the destination of a placeholder (nothing is ever below 0): no tests in the sweeps
     __shared__ uint32_t Lold[BT * BT * NSMAX];         //  8 KB: the block's levels as loaded
     __shared__ int s_wake, s_blk, s_or[3];
     const PfArgs &a = sa.a;
@@ -1142,7 +1145,7 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
         or_turn = or_turn == 2 ? 0 : or_turn + 1;
         return r;
     };
-    if (t == 0) { s_or[0] = 0; s_or[1] = 0; s_or[2] = 0; }      // (in front of the first barrier of the loop below)
+    if (t == 0) { s_or[0] = 0; s_or[1] = 0; s_or[2] = 0; L[LSENT] = 0u; }      // (in front of the first barrier of the loop below)
     const unsigned int cap_mask = q->cap_mask, cap_shift = (unsigned int)__builtin_popcount(cap_mask);
     for (;;) {
         __syncthreads();                               // the LDS arrays (and s_blk) of the previous visit are free
@@ -1176,13 +1179,18 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
         const int blk = s_blk;
         if (blk < 0) return;                           // (block-uniform) the solve is over, or was called off
         const int bi = blk / sa.nbc, bj = blk - bi * sa.nbc;
+        // (a new name for the thread's number per visit: or the region coordinates of its nine words -- a dozen values that only depend
+        // on it -- are computed once in front of the visit loop and live in SCRATCH through it: every one of the nine level loads then
+        // waited for a scratch reload of its address first, nine dependent round trips per visit)
+        int tv = t;
+        asm volatile("" : "+v"(tv));
         // ---- levels of the region: sc1 loads (another workgroup of this launch may have written them), all in flight together
         {
             constexpr int NLV = RT * RT * NSMAX / ST;
             uint32_t lv[NLV];
 #pragma unroll
             for (int u = 0; u < NLV; ++u) {
-                const int i = t + u * ST;
+                const int i = tv + u * ST;
                 const int rt = i / NSMAX, k = i - rt * NSMAX;
                 const int p = bi * BT + rt / RT - 1, qq = bj * BT + rt % RT - 1;
                 const bool ok = p >= 0 && p < a.ntr && qq >= 0 && qq < a.ntc;
@@ -1196,7 +1204,7 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
             // waves; the rounds' kernel had the same window since round 2)
 #pragma unroll
             for (int u = 0; u < NLV; ++u) {
-                const int i = t + u * ST;
+                const int i = tv + u * ST;
                 const int rt = i / NSMAX, k = i - rt * NSMAX, ri = rt / RT, rj = rt - ri * RT;
                 L[i] = lv[u];
                 if (ri >= 1 && ri <= BT && rj >= 1 && rj <= BT) Lold[((ri - 1) * BT + rj - 1) * NSMAX + k] = lv[u];
@@ -1210,6 +1218,14 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
             er[k] = ~0ull;
             if (t + k * ST < ne) er[k] = sa.eblk[(size_t)blk * EMAX + t + k * ST];
         }
+        // (once per visit instead of two tests per relaxation and sweep: OCEAN as a source and both ends of a placeholder -> the word that holds 0)
+#pragma unroll
+        for (int k = 0; k < EMAX / ST; ++k) {
+            const unsigned long long r = er[k];
+            const unsigned src = (unsigned)(r >> 32) & 0xffffu;
+            const unsigned long long dst = r == ~0ull ? (unsigned long long)LSENT : r >> 48;
+            er[k] = (dst << 48) | ((unsigned long long)(src == 0xFFFFu ? (unsigned)LSENT : src) << 32) | (r & 0xffffffffull);
+        }
         __syncthreads();
         // ---- the block's fixed point (only the levels are read from LDS)
         int dbg_sweeps = 0;
@@ -1219,9 +1235,8 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
 #pragma unroll
             for (int k = 0; k < EMAX / ST; ++k) {
                 const unsigned long long r = er[k];
-                if (r == ~0ull) continue;
                 const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
-                const uint32_t v = max((uint32_t)r, src == 0xFFFF ? 0u : L[src]);
+                const uint32_t v = max((uint32_t)r, L[src]);
                 if (v < L[dst]) {
                     atomicMin(&L[dst], v);
                     ch = true;
@@ -1231,7 +1246,7 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
         }
         // ---- write back (write-through), drain, then wake the neighbouring blocks that hold a link to a seed whose level dropped
         bool moved = false;
-        for (int i = t; i < BT * BT * NSMAX; i += ST) {
+        for (int i = tv; i < BT * BT * NSMAX; i += ST) {
             const int bt = i / NSMAX, k = i - bt * NSMAX;
             const int p = bi * BT + bt / BT, qq = bj * BT + bt % BT;
             const uint32_t v = L[((bt / BT + 1) * RT + bt % BT + 1) * NSMAX + k];
@@ -1251,7 +1266,7 @@ __device__ __forceinline__ void pf_solve_queue_body(const SolveArgs &sa, PfQueue
             for (int k = 0; k < EMAX / ST; ++k) {
                 const unsigned long long r = er[k];
                 const int dst = (int)(r >> 48), src = (int)((r >> 32) & 0xffffu);
-                if (src == 0xFFFF) continue;                                       // also the ~0 placeholders
+                if (src == LSENT) continue;                                        // OCEAN, and the placeholders
                 const int st = src / NSMAX, si = st / RT, sj = st % RT;             // region tile of the source
                 if (si >= 1 && si <= BT && sj >= 1 && sj <= BT) continue;          // inside the block
                 const int dt = dst / NSMAX, di_ = dt / RT - 1, dj_ = dt % RT - 1;   // block-local tile of the destination

@@ -28,7 +28,7 @@ def test_no_full_wave_value_is_spilled_under_narrowed_exec(tmp_path):
     assert len(srcs) >= 8
     with ThreadPoolExecutor(max_workers=4) as ex:
         outs = list(ex.map(lambda s: _isa(s, tmp_path / (s.stem + ".s")), srcs))
-    nkern, bad, scratch, geo = 0, [], {}, {}
+    nkern, bad, scratch, geo, flood = 0, [], {}, {}, {}
     for o in outs:
         nkern += sum(1 for _ in lint_exec_spills.kernels(str(o)))
         bad += lint_exec_spills.lint(str(o))
@@ -36,6 +36,8 @@ def test_no_full_wave_value_is_spilled_under_narrowed_exec(tmp_path):
             scratch = lint_exec_spills.private_segments(str(o))
         if o.stem == "noflat_geo":
             geo = lint_exec_spills.private_segments(str(o))
+        if o.stem == "pflood":
+            flood = lint_exec_spills.private_segments(str(o))
     assert nkern >= 40            # the lint really saw the kernels
     assert not bad, bad
     # the fill kernels hold their 64 x 64 windows in registers by design: any private segment means the window spilled
@@ -46,6 +48,9 @@ def test_no_full_wave_value_is_spilled_under_narrowed_exec(tmp_path):
     # distances + 13 mask words; the full adjacency words only for windows of three or more classes)
     hot = {k: v for k, v in geo.items() if "ng_round_kernel" in k or "ng_first_kernel" in k}
     assert len(hot) == 2 and all(v == 0 for v in hot.values()), geo
+    # the flood's kernels: the seed-graph solve kept a dozen per-thread address words in scratch until round 4 (hoisted out of the
+    # visit loop) and every level load of a visit waited for a scratch reload first: 0.2 ms of the fill stage
+    assert len(flood) >= 10 and all(v == 0 for v in flood.values()), flood
 
 
 def test_lint_catches_the_pattern(tmp_path):

@@ -573,6 +573,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         return;
     }
     PF_STAMP(4);
+    // the basins' (level, seed) come back from the tile's tables -- each thread reads what it wrote itself --: the loads go out HERE,
+    // in front of the compaction, and are used behind it (two dependent round trips to memory otherwise sit between two barriers)
+    static_assert(NBMAX <= 2 * NT, "a thread parks at most two basins");
+    uint32_t pk_hi[2] = {0xffffffffu, 0xffffffffu}, pk_lo[2] = {0xffu, 0xffu};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sI = t + u * NT;
+        if (sI < NB) {
+            pk_hi[u] = __hip_atomic_load(&a.tabV[(size_t)tile * NBMAX + sI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pk_lo[u] = __hip_atomic_load(&a.tabL[(size_t)tile * NBMAX + sI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // compact the pairs into the memory of the elevation keys (every thread holds what it still needs in registers)
     uint32_t *ek = zk, *ew = zk + HE;
     for (int h = t; h < HEU; h += NT) {
@@ -584,13 +596,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }
     __syncthreads();
     const int NE = s_ne;
-    // X is free again: the basins' (level, seed) come back from the tile's tables (each thread reads what it wrote itself), their
-    // kinds from the roots -- a basin whose root is a ring cell or a raster border cell is fixed, every other is an interior pit
-    for (int sI = t; sI < NB; sI += NT) {
-        const uint32_t hi = __hip_atomic_load(&a.tabV[(size_t)tile * NBMAX + sI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t lo = __hip_atomic_load(&a.tabL[(size_t)tile * NBMAX + sI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bkey[sI] = ((unsigned long long)hi << 32) | ((hi == 0xffffffffu && lo == 0xffu) ? 0xffffffffull : (unsigned long long)lo);
-        btype[sI] = 1;
+    // X is free again: bkey / btype move back in; the basins' kinds from the roots -- a basin whose root is a ring cell or a raster
+    // border cell is fixed, every other is an interior pit
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int sI = t + u * NT;
+        if (sI < NB) {
+            const uint32_t hi = pk_hi[u], lo = pk_lo[u];
+            bkey[sI] = ((unsigned long long)hi << 32) | ((hi == 0xffffffffu && lo == 0xffu) ? 0xffffffffull : (unsigned long long)lo);
+            btype[sI] = 1;
+        }
     }
     __syncthreads();
 #pragma unroll

@@ -1260,6 +1260,7 @@ struct GeoRun::Impl {
     int ntr = 0, ntc = 0, round = 0, used = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span;   // around every batch of ng_round_kernel launches
     int span_rounds = 0;
+    uint32_t last_count = 0xffffffffu;   // tiles of the last round the host has seen
     bool light = false;          // the rounds from light_from on append to the next round's list themselves
     int light_from = 0;
     int64_t nt = 0;
@@ -1414,6 +1415,7 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
         }
     }
     m.round = 0;
+    m.last_count = 0xffffffffu;
     m.used = 0;
     MH_TRY(launch_rounds(s, 1));
     unsigned long long h_c[4] = {0, 0, 0, 0};
@@ -1439,7 +1441,10 @@ int GeoRun::batch(hipStream_t s, bool *active)
     const char *eb = dev_env("MHIP_NG_BATCH");
     const int nb_env = eb && atoi(eb) >= 1 && atoi(eb) <= BATCH ? atoi(eb) : 0;
     for (;;) {
-        const int nb = nb_env ? nb_env : (m.light ? BATCH : BATCH_HEAD);
+        // rounds per host read-back.  A batch is launched blind: the rounds behind the one that finds no tile are no-ops of ~2 us with
+        // ~10 us of dispatch gap each -- 28 of them at the end of the 16384^2 benchmark with batches of 32 (round 84 of 112), 0.3 ms.
+        // The tile counts fall slowly towards the end (... 531 363 186 100 49 24 9 2): a short batch once the last count is small
+        const int nb = nb_env ? nb_env : (!m.light ? BATCH_HEAD : (m.last_count <= 64 ? 8 : (m.last_count <= 512 ? 16 : BATCH)));
         if (m.round + BATCH > MAXR) {
             set_error("no-flats fill (geodesic) did not converge within %d rounds", MAXR);
             return MHIP_ENOTCONV;
@@ -1457,6 +1462,7 @@ int GeoRun::batch(hipStream_t s, bool *active)
             }
             ++m.used;
         }
+        m.last_count = h_any[nb - 1];
         if (!m.light && h_any[nb - 1] <= LIGHT_TILES && !no_light) {   // the tail: from here on the rounds build their lists themselves
             m.light = true;
             m.light_from = m.round;

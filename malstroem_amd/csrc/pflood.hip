@@ -1098,9 +1098,12 @@ struct PfQueue {                   // (every counter on a line of its own: same-
     unsigned int pad2[63];
     unsigned int abort;            // a spin ran out, or the generations did
     unsigned int cap_mask;         // slots - 1 (a power of two >= 2 * blocks + grid)
-    unsigned int pad3[62];
+    unsigned int flags[2];         // the flood's flags (PfArgs::flags: [0] a capacity overflowed, [1] the proof failed) ...
+    unsigned int mm[2];            // ... and the DEM's smallest | largest elevation key (pf_minmax_kernel): they live HERE so that ONE copy
+    unsigned int pad3[58];         // of the header brings everything the host wants to know after the solve (six 4-byte copies cost 25 us each)
     unsigned int slots[1];         // [cap]: (ticket / cap + 1) << 20 | block
 };
+static_assert(offsetof(PfQueue, slots) == 1024, "header = four lines of 256 bytes");
 constexpr unsigned int PFQ_SPIN_LIMIT = 1u << 21;    // polls of ~0.3-1 us each
 constexpr int PFQ_BLK_BITS = 20;
 
@@ -1137,6 +1140,7 @@ __global__ void pf_queue_init_kernel(PfQueue *q, unsigned int *mark, int nbr, in
         q->head = 0u;
         q->tail = (unsigned int)n;
         q->finished = 0u;
+        q->abort = 0u;
         q->cap_mask = cap_mask;
     }
 }
@@ -1653,6 +1657,7 @@ struct PfRun::Impl {
     size_t queue_bytes = 0;
     unsigned int queue_cap = 0;
     unsigned long long queue_visits = 0;
+    bool rounds_ran = false;              // pf_solve_kernel (the fall-back / A-B partner) counted visits on the device
     bool solved_once = false;             // the first solve starts from the outline of the block grid, later ones from the band's first / last block rows
     int64_t ntiles = 0;
     size_t nslots = 0;
@@ -1701,7 +1706,8 @@ int PfRun::solve(hipStream_t s)
     static const bool use_rounds = [] { const char *e = dev_env("MHIP_PF_SOLVE"); return e && std::string(e) == "rounds"; }();
     if (!use_rounds) {
         const int mode = m.solved_once ? 1 : 0;
-        MH_HIP(hipMemsetAsync(m.queue, 0, m.queue_bytes, s));
+        MH_HIP(hipMemsetAsync(m.queue, 0, offsetof(PfQueue, abort), s));                     // head | tail | finished (+ the debug counters)
+        MH_HIP(hipMemsetAsync(m.queue->slots, 0, (size_t)m.queue_cap * 4, s));
         const int n_init = mode == 0 ? ((m.nbr == 1 || m.nbc == 1) ? m.nbr * m.nbc : 2 * (m.nbc - 1) + 2 * (m.nbr - 1)) : 2 * m.nbc;
         hipLaunchKernelGGL(pf_queue_init_kernel, dim3((unsigned)cdiv(n_init, 256)), dim3(256), 0, s, m.queue, m.mark, m.nbr, m.nbc, mode, 0, m.nbr - 1, m.queue_cap - 1u);
         SolveArgs sa = {};
@@ -1716,14 +1722,13 @@ int PfRun::solve(hipStream_t s)
         hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, qgrid ? qgrid : 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
         MH_HIP(hipGetLastError());
         m.launches += 2;
-        unsigned int h_q[4] = {0, 0, 0, 0};      // head, tail, finished, abort
-        MH_HIP(hipMemcpyAsync(&h_q[0], &m.queue->head, 4, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipMemcpyAsync(&h_q[1], &m.queue->tail, 4, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipMemcpyAsync(&h_q[2], &m.queue->finished, 4, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipMemcpyAsync(&h_q[3], &m.queue->abort, 4, hipMemcpyDeviceToHost, s));
-        MH_HIP(hipMemcpyAsync(&h_flag, m.a.flags, 4, hipMemcpyDeviceToHost, s));
-        if (!m.mm_valid) MH_HIP(hipMemcpyAsync(m.h_mm, m.mmout, 8, hipMemcpyDeviceToHost, s));
+        unsigned int h_hdr[256 * 4 / 4];          // the queue's header: ONE copy
+        MH_HIP(hipMemcpyAsync(h_hdr, m.queue, sizeof(h_hdr), hipMemcpyDeviceToHost, s));
         MH_HIP(stream_sync(s));
+        const PfQueue *hq = reinterpret_cast<const PfQueue *>(h_hdr);
+        const unsigned int h_q[4] = {hq->head, hq->tail, hq->finished, hq->abort};
+        h_flag = hq->flags[0];
+        if (!m.mm_valid) { m.h_mm[0] = hq->mm[0]; m.h_mm[1] = hq->mm[1]; }
         m.mm_valid = true;
         m.solved_once = true;
         if (h_flag) return MHIP_ELIMIT;
@@ -1740,6 +1745,7 @@ int PfRun::solve(hipStream_t s)
         m.round = 0;
         MH_HIP(hipMemsetAsync(m.any, 0, (size_t)(PF_MAXR + 2) * 4, s));
     }
+    m.rounds_ran = true;
     for (;;) {
         if (m.round + PF_BATCH + 1 >= PF_MAXR) {
             set_error("priority-flood seed graph did not converge within %d rounds", PF_MAXR);
@@ -1861,18 +1867,20 @@ int PfRun::begin(hipStream_t s)
     a.tileNL0 = reinterpret_cast<int *>(b + o_nl0);
     a.Lv = reinterpret_cast<uint32_t *>(b + o_lv);
     m.any = reinterpret_cast<unsigned int *>(b + o_cnt);      // [PF_MAXR + 2] "round r was handed work"
-    a.flags = m.any + (PF_MAXR + 2);
-    m.visits = reinterpret_cast<unsigned long long *>(a.flags + 2);
+    m.visits = reinterpret_cast<unsigned long long *>(m.any + (PF_MAXR + 2) + 2);
     a.prof = m.visits + 1;   // 24 words (inside the zeroed tail of the workspace)
     m.mark = reinterpret_cast<unsigned int *>(b + o_act);
     m.list = reinterpret_cast<int *>(b + o_list);
     m.eblk = reinterpret_cast<unsigned long long *>(b + o_eblk);
     a.mm = reinterpret_cast<uint32_t *>(b + o_mm);
-    m.mmout = a.mm + (size_t)ntiles * (NT / 64) * 2;
     m.ecount = reinterpret_cast<int *>(b + o_ecnt);
     m.queue = reinterpret_cast<PfQueue *>(b + o_queue);
+    a.flags = m.queue->flags;             // (in the queue's header: see PfQueue)
+    m.mmout = m.queue->mm;
+    MH_HIP(hipMemsetAsync(&m.queue->abort, 0, 256, s));
     m.solved_once = false;
     m.queue_visits = 0;
+    m.rounds_ran = false;
     m.mm_valid = false;
     {
         const uint32_t init[2] = {0xffffffffu, 0u};
@@ -1934,7 +1942,7 @@ int PfRun::begin(hipStream_t s)
     }
     MH_TRY(pack(s, 0, m.nbr));
     MH_HIP(hipGetLastError());
-    m.launches = 3;
+    m.launches = 5;         // pf_tile, pf_minmax, pf_ring, pf_link2, pf_pack
     MH_TRY(solve(s));
     return publish_edges(s);
 }
@@ -2020,7 +2028,7 @@ int PfRun::finish(hipStream_t s, float *d_depths, FillStats *st, bool *violated)
 #endif
     if (st) {
         unsigned long long h_vis = 0;
-        MH_HIP(hipMemcpyAsync(&h_vis, m.visits, 8, hipMemcpyDeviceToHost, s));
+        if (m.rounds_ran) MH_HIP(hipMemcpyAsync(&h_vis, m.visits, 8, hipMemcpyDeviceToHost, s));      // (the queue solve's visits came with its header)
         MH_HIP(stream_sync(s));
         *st = FillStats();
         st->rounds = m.launches;

@@ -18,7 +18,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o k -- python3 be
 python3 tools/kernel_stats.py $O/prof/k_results.db > $O/${TAG}_kernel_stats.csv
 echo "kernel stats done"
 timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/${TAG}_bench16384.json
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench16384_20steps.json
 echo "bench done"
+# one step as a timeline (every dispatch with its start, duration and the idle gap before it)
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/tl -o k -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/tl.log 2>&1
+python3 tools/kernel_timeline.py $O/tl/k_results.db -2 > $O/${TAG}_step_timeline.csv
+rm -rf $O/tl
 timeout -k 10 300 python3 bench.py --beta 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench16384_beta3.json
 timeout -k 10 300 python3 bench.py --config 2 2>/dev/null | tail -1 > $O/${TAG}_bench4096_config2.json
 if [ -z "$QUICK" ]; then timeout -k 10 600 python3 bench.py --size 32768 --bands 4 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench32768_4bands_1gpu.json; fi

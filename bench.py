@@ -366,7 +366,9 @@ def main():
             print("bench.py: band setup failed on at least one rank (no replica fall-back); see the tracebacks above", file=sys.stderr)
         shutdown(3)
 
-    def step(record):
+    nsampled = [0]
+
+    def step(record, sample=True):
         if band_mode:
             gate.wait()     # go
             gate.wait()     # all bands of this process are through
@@ -376,13 +378,17 @@ def main():
             pipe.run(*stage_names)
             pipe.sync()
             if record:
+                for k in engines_seen:            # EVERY timed step, not just the last one: an intermittent fall-back must not hide
+                    engines_seen[k].add(pipe.get_int(k))
+            if record and sample:
+                # (the stage times of about eight of the timed steps, evenly spaced: fourteen ctypes calls cost ~80 us of a 22 ms step
+                # when every step pays them -- the timeline showed the device idle that long between two steps)
+                nsampled[0] += 1
                 for s in stage_names:
                     stage_ms[s] += pipe.stage_ms(s)
                 for s in ("fill", "noflat"):      # the stage's dominant kernel, HIP events around its launches inside the library
                     hot_ms[s] += pipe.get_float(s + "_hot_ms")
                     hot_launches[s] = pipe.get_int(s + "_hot_launches")
-                for k in engines_seen:            # EVERY timed step, not just the last one: an intermittent fall-back must not hide
-                    engines_seen[k].add(pipe.get_int(k))
 
     engines_seen = {"fill_algorithm": set(), "noflat_algorithm": set()}
     if not config2:
@@ -400,8 +406,9 @@ def main():
         w.timings, w.host_ms = {}, {}
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    stride = max(1, args.steps // 8)
+    for i in range(args.steps):
+        step(True, i % stride == 0)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -516,7 +523,7 @@ def main():
                 "host_serial_ms_total": round(sum(host_serial.values()), 2)}
     else:
         for s in stage_names:
-            stage_ms[s] /= args.steps
+            stage_ms[s] /= max(nsampled[0], 1)
         keys = ("fill_rounds", "noflat_rounds", "fill_tiles", "fill_visits", "fill_cycles", "noflat_visits", "noflat_cycles") + (() if config2 else ("nlabels",))
         info = {k: pipe.get_int(k) for k in keys}
         for k in ("fill_algorithm", "fill_launches", "noflat_algorithm") + (() if config2 else ("pour_algorithm",)):
@@ -566,7 +573,7 @@ def main():
             its own HBM bytes (the committed PMC table of the same command), next to the stage figure"""
             if band_mode or stage not in hot_ms or hot_ms[stage] <= 0.0:
                 return None
-            kms = hot_ms[stage] / args.steps
+            kms = hot_ms[stage] / max(nsampled[0], 1)
             out_ = {"name": KERNEL_OF_STAGE[stage], "launches_per_step": hot_launches[stage], "ms_per_step": round(kms, 3),
                     "avg_launch_us": round(1e3 * kms / max(hot_launches[stage], 1), 1), "timed_by": "HIP events around the launches, on their stream"}
             rows, meta, path = pmc_table(n)
@@ -609,7 +616,7 @@ def main():
                             "unit": "GB/s", "frac": d8["frac_of_hbm_peak"], "frac_of_measured_copy_peak": round(d8["achieved_GBs"] / copy_gbs, 4) if copy_gbs else None,
                             "frac_of_measured_read_peak": round(d8["achieved_GBs"] / read_gbs, 4) if read_gbs else None,
                             "traffic": pmc_traffic("flowdir", n) if not band_mode else None},
-            "stages": stages,
+            "stages": stages, "stage_times_sampled_steps": nsampled[0] if not band_mode else None,
         }
         if world == 1 and not band_mode and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src.full, min(args.cpu_sample, n))

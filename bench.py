@@ -391,6 +391,9 @@ def main():
                     hot_launches[s] = pipe.get_int(s + "_hot_launches")
 
     engines_seen = {"fill_algorithm": set(), "noflat_algorithm": set()}
+    # development knob of the library (MHIP_DEVELOPER=1 MHIP_SERIAL=1): every stage on the context's stream, nothing overlapped --
+    # the per-stage times then mean "alone on the GPU"; the line carries "streams": "serial"
+    serial_streams = os.environ.get("MHIP_DEVELOPER", "") == "1" and os.environ.get("MHIP_SERIAL", "")[:1] == "1"
     if not config2:
         engines_seen["pour_algorithm"] = set()
 
@@ -423,7 +426,7 @@ def main():
     fell_back = []
     if pipe is not None:
         want = {"fill_algorithm": (1,), "noflat_algorithm": (2,)}
-        if not config2:
+        if not config2 and not serial_streams:      # (one stream: the pour points are a pass of their own by design, not a fall-back)
             want["pour_algorithm"] = (1,)
         fell_back = ["%s=%s" % (k, sorted(engines_seen[k])) for k, ok in want.items() if not engines_seen[k] <= set(ok)]
     for w in workers:
@@ -542,7 +545,7 @@ def main():
         # pour points: the event times of those tail stages include the time they waited for CUs the other branch held (alone:
         # accumulation 5.6, labelling 5.5, watersheds 3.6 ms at 16384^2).  The dominant stage is taken among the stages
         # that had the GPU to themselves, whose time means the same thing in the chain and alone.
-        overlapped = () if (band_mode or config2) else ("accum", "label", "watershed", "pourpoints")
+        overlapped = () if (band_mode or config2 or serial_streams) else ("accum", "label", "watershed", "pourpoints")
         for s in overlapped:
             stages[s]["overlapped"] = True
         dominant = max((s for s in stage_names if s not in overlapped), key=lambda s: stage_ms[s])
@@ -600,7 +603,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32 fill / f64 no-flats+D8+accum / u8 flowdir / i32 labels", "data": "synthetic",
             "config": {"workload": "%dx%d float32 DEM (%s): %s" % (n, n, src.recipe, chain),
-                       "parallelism": parallelism, "dem_generation_s": round(t_gen, 1), **info},
+                       "parallelism": parallelism, "dem_generation_s": round(t_gen, 1),
+                       **({"streams": "serial (MHIP_SERIAL=1: every stage alone on the GPU, the pour points as a pass of their own)"} if serial_streams else {}),
+                       **info},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_STAGE.get(dominant, dominant), "stage": dominant,
                          "kernel_detail": kernel_detail(dominant),
                          "launches_per_step": info.get(launches_key, 1),

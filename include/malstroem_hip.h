@@ -284,6 +284,16 @@ int mhip_ctx_band_relabel(mhip_ctx *ctx, const int32_t *lut, int64_t nlocal, int
  * numbered by another band, or without an owned cell) -> target[k] */
 int mhip_ctx_band_relabel_sparse(mhip_ctx *ctx, int64_t nlocal, int64_t offset, const int32_t *dropped, const int32_t *target,
                                  int64_t ndropped, int64_t nlabels_global);
+/* mhip_ctx_band_ccl_local + mhip_ctx_band_relabel_sparse as two HALVES of one labelling, without the two passes over the label raster
+ * between them (reference: label.py:8-23 numbers one raster in one go; a band has to wait for its neighbours).  begin: everything
+ * up to the emit pass -- *nlocal band-local labels, and of the LABELS raster only the two top and the two bottom local rows are
+ * written (band-local labels: what mhip_ctx_get_edge_row / mhip_ctx_exchange_edge_rows hand to the seam merge).  finish: the
+ * GLOBAL label of every cell in one pass (the map of mhip_ctx_band_relabel_sparse); with_stats != 0: label_stats of the depths over
+ * the owned rows by global label ride on it -- the records of mhip_ctx_band_records(ctx, 0), which need not run then.  Between the
+ * two calls LABELS is not a raster of labels (mhip_ctx_download etc. refuse it). */
+int mhip_ctx_band_ccl_begin(mhip_ctx *ctx, int64_t *nlocal);
+int mhip_ctx_band_ccl_finish(mhip_ctx *ctx, int64_t offset, const int32_t *dropped, const int32_t *target, int64_t ndropped,
+                             int64_t nlabels_global, int with_stats);
 /* watersheds on a band: local pointer jumping with pseudo labels on the halo rows, then a boundary LUT */
 /* the bluespot filter on a band (bluespots.py:165-172 as a rank relabel): labels in [lo, hi] (numbered by this band) -> lut[l - lo]
  * (0 = dropped); a label another band numbered -> fnew[k] where fid[k] == l (fid sorted, unique); nlabels_new = the global count */

@@ -41,7 +41,7 @@ SYMBOLS = [
     "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_certify", "mhip_ctx_fill_end",
     "mhip_ctx_geo_begin", "mhip_ctx_geo_batch", "mhip_ctx_geo_halo_changed", "mhip_ctx_geo_end", "mhip_ctx_fill_attach", "mhip_ctx_noflat_verify",
-    "mhip_ctx_zero_raster", "mhip_ctx_band_accum_boundary", "mhip_ctx_band_ccl_local", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_relabel_range", "mhip_ctx_band_trace", "mhip_ctx_band_watershed_local",
+    "mhip_ctx_zero_raster", "mhip_ctx_band_accum_boundary", "mhip_ctx_band_ccl_local", "mhip_ctx_band_ccl_begin", "mhip_ctx_band_ccl_finish", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_relabel_range", "mhip_ctx_band_trace", "mhip_ctx_band_watershed_local",
     "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_records", "mhip_ctx_band_fetch", "mhip_ctx_band_gather",
     "mhip_ctx_band_foreign_counts", "mhip_ctx_side_begin", "mhip_ctx_side_end",
     "mhip_ctx_has_comm", "mhip_ctx_exchange_halo", "mhip_ctx_exchange_edge_rows", "mhip_ctx_comm_add_side", "mhip_band_union_find", "mhip_band_accum_pairs", "mhip_band_accum_solve", "mhip_band_label_pairs",

@@ -547,6 +547,8 @@ struct mhip_ctx {
     DevBuf r[MHIP_R_COUNT_];
     bool have[MHIP_R_COUNT_] = {};
     DevBuf tmp_i32;         // CCL parent scratch
+    CclKeep ccl_keep;       // a row band's labelling between its two halves (mhip_ctx_band_ccl_begin / _finish)
+    bool ccl_pending = false;
     DevBuf raw_stats, stats, ws_counts, pour;
     AccumKeep acc_keep;     // row band: the perimeter graph of mhip_ctx_band_accum_boundary, for the ACCUM run that follows the exchange
     int accum_algorithm = 0;   // 0: full accumulation, 1: the band's second pass as a delta over the kept graph
@@ -999,6 +1001,72 @@ int mhip_ctx_band_relabel_sparse(mhip_ctx *c, int64_t nlocal, int64_t offset, co
     MH_TRY(relabel_sparse_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, nlocal, (int32_t)offset, d_d.as<int32_t>(), d_t.as<int32_t>(),
                               (int32_t)ndropped, cs(c)));
     c->nlabels = c->nlabels_raw = nlabels_global;
+    c->labels_filtered = true;
+    return MHIP_OK;
+}
+
+/* The two calls above as two HALVES of one labelling, without the two passes over the label raster that lie between them (the
+ * emit pass that writes band-local labels everywhere, and the relabelling pass that reads them back): `begin` stops before the emit
+ * pass -- *nlocal band-local labels, and of the labels raster only the two top and the two bottom rows (band-local labels: what
+ * mhip_ctx_get_edge_row / mhip_ctx_exchange_edge_rows hand to the seam merge) are written; `finish` writes the GLOBAL label of every
+ * cell in one pass (local l -> offset + l - #(dropped labels < l), dropped[k] -> target[k], as mhip_ctx_band_relabel_sparse).
+ * with_stats != 0: label_stats of the depths over the OWNED rows by global label ride on that pass -- what mhip_ctx_band_records(ctx, 0)
+ * computes; mhip_ctx_band_fetch / _gather(which = 0) read them.  Between the two calls the labels raster is not a raster of labels. */
+int mhip_ctx_band_ccl_begin(mhip_ctx *c, int64_t *nlocal)
+{
+    MH_ARG(c && nlocal && c->have[MHIP_R_DEPTHS], "ctx_band_ccl_begin needs bluespot depths");
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, MHIP_R_LABELS));
+    c->have[MHIP_R_LABELS] = false;
+    if (!c->tmp_i32.p) MH_TRY(c->tmp_i32.alloc(4 * (size_t)(c->H * c->W)));
+    MH_TRY(ccl8_f32_begin_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), c->H, c->W,
+                              nlocal, cs(c), &c->ccl_keep));
+    c->ccl_keep.nlocal = *nlocal;
+    c->ccl_pending = true;
+    return MHIP_OK;
+}
+
+int mhip_ctx_band_ccl_finish(mhip_ctx *c, int64_t offset, const int32_t *dropped, const int32_t *target, int64_t ndropped, int64_t nlabels_global,
+                             int with_stats)
+{
+    MH_ARG(c && c->ccl_pending && ndropped >= 0 && (ndropped == 0 || (dropped && target)) && nlabels_global >= 0 &&
+               offset >= 0 && offset + c->ccl_keep.nlocal < (int64_t)INT32_MAX && nlabels_global < (int64_t)INT32_MAX,
+           "ctx_band_ccl_finish(ctx, offset, dropped, target, ndropped, nlabels_global, with_stats) follows ctx_band_ccl_begin");
+    for (int64_t k = 1; k < ndropped; ++k) MH_ARG(dropped[k - 1] < dropped[k], "ctx_band_ccl_finish: dropped labels must be sorted and unique");
+    MH_ARG(!with_stats || c->have[MHIP_R_DEPTHS], "ctx_band_ccl_finish: the statistics need the depths");
+    MH_HIP(hipSetDevice(c->device));
+    const int64_t nlocal = c->ccl_keep.nlocal;
+    DevBuf d_d, d_t;
+    MH_TRY(d_d.alloc(4 * (size_t)(ndropped + 1)));
+    MH_TRY(d_t.alloc(4 * (size_t)(ndropped + 1)));
+    if (ndropped) {
+        MH_HIP(hipMemcpyAsync(d_d.p, dropped, 4 * (size_t)ndropped, hipMemcpyHostToDevice, cs(c)));
+        MH_HIP(hipMemcpyAsync(d_t.p, target, 4 * (size_t)ndropped, hipMemcpyHostToDevice, cs(c)));
+    }
+    c->ccl_pending = false;
+    if (with_stats) MH_TRY(c->stats.alloc(sizeof(mhip_stat_record) * (size_t)(nlabels_global + 1)));
+    if (c->ccl_keep.valid) {
+        MH_TRY(label_emit_sparse_dev(c->tmp_i32.as<int32_t>(), c->ccl_keep.bits.as<unsigned long long>(), c->ccl_keep.wprefix.as<uint32_t>(),
+                                     c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->H, c->W, c->ht, c->H_owned, nlocal,
+                                     (int32_t)offset, d_d.as<int32_t>(), d_t.as<int32_t>(), (int32_t)ndropped, nlabels_global,
+                                     with_stats ? c->stats.as<mhip_stat_record>() : nullptr, cs(c)));
+        c->ccl_keep.bits.release();
+        c->ccl_keep.wprefix.release();
+        c->ccl_keep.valid = false;
+    } else {
+        // (a labelling schedule that keeps no tables -- MHIP_CCL=global -- has written band-local labels everywhere)
+        MH_TRY(relabel_sparse_dev(c->r[MHIP_R_LABELS].as<int32_t>(), c->H * c->W, nlocal, (int32_t)offset, d_d.as<int32_t>(), d_t.as<int32_t>(),
+                                  (int32_t)ndropped, cs(c)));
+        if (with_stats) {
+            const int64_t off = c->W * c->ht;
+            MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>() + off, c->r[MHIP_R_LABELS].as<int32_t>() + off, c->H_owned * c->W, nlabels_global,
+                                   c->stats.as<mhip_stat_record>(), cs(c), c->W, true));
+        }
+        MH_HIP(stream_sync(cs(c)));
+    }
+    c->nlabels = c->nlabels_raw = nlabels_global;
+    c->have[MHIP_R_LABELS] = true;
+    c->labels_components = true;
     c->labels_filtered = true;
     return MHIP_OK;
 }

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <string>
 #include <type_traits>
+#include <utility>
 
 #include "common.hpp"
 
@@ -439,8 +440,10 @@ __global__ __launch_bounds__(256) void ccl_emit_kernel(const int32_t *__restrict
 }
 
 template <typename T>
-int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s, DevBuf *stats_out = nullptr)
+int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s, DevBuf *stats_out = nullptr,
+             CclKeep *keep = nullptr)
 {
+    if (keep) keep->valid = false;
     const int64_t n = H * W;
     if (n >= (int64_t)INT32_MAX - 1) {
         set_error("connected components: %lld cells exceed the int32 index domain", (long long)n);
@@ -498,11 +501,31 @@ int ccl8_dev(const T *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int6
                                             stats_out->as<mhip_stat_record>(), s);     // (synchronises: the scratch buffers may go)
             }
         }
-        hipLaunchKernelGGL(ccl_emit_ranked_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, n);
+        if (keep) {
+            // a row band: the emit pass waits for the seam merge (label_ops.hip: label_emit_sparse_dev); the merge wants the two top and
+            // the two bottom rows of band-local labels now
+            const int64_t top = (H < 4 ? H : 2) * W;
+            MH_TRY(ccl_emit_rows_dev(parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, 0, top, s));
+            if (H >= 4) MH_TRY(ccl_emit_rows_dev(parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, (H - 2) * W, 2 * W, s));
+        } else {
+            hipLaunchKernelGGL(ccl_emit_ranked_kernel, dim3((unsigned)cdiv(cdiv(n, 4), 256)), dim3(256), 0, s, parent, bits.as<unsigned long long>(), wprefix.as<uint32_t>(), d_labels, n);
+        }
         MH_HIP(hipGetLastError());
         MH_HIP(hipMemcpyAsync(&h_total, total.p, sizeof(h_total), hipMemcpyDeviceToHost, s));
         MH_HIP(stream_sync(s));     // (the scratch buffers of this branch go back to the pool after the sync)
         *nlabels = (int64_t)h_total;
+        if (keep) {
+            keep->bits.release();
+            keep->wprefix.release();
+            std::swap(keep->bits.p, bits.p);
+            std::swap(keep->bits.bytes, bits.bytes);
+            std::swap(keep->wprefix.p, wprefix.p);
+            std::swap(keep->wprefix.bytes, wprefix.bytes);
+            keep->H = H;
+            keep->W = W;
+            keep->nlocal = (int64_t)h_total;
+            keep->valid = true;
+        }
         return MHIP_OK;
     }
     MH_HIP(hipGetLastError());
@@ -525,6 +548,10 @@ int ccl8_f32_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t
                  hipStream_t s, DevBuf *stats_out)
 {
     return ccl8_dev<float>(d_data, d_labels, d_tmp, H, W, nlabels, s, stats_out);
+}
+int ccl8_f32_begin_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s, CclKeep *keep)
+{
+    return ccl8_dev<float>(d_data, d_labels, d_tmp, H, W, nlabels, s, nullptr, keep);
 }
 int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
                 hipStream_t s)

@@ -349,6 +349,21 @@ int label_emit_stats_dev(const int32_t *d_parent, const unsigned long long *d_ro
                          int32_t *d_labels, int64_t H, int64_t W, int64_t nlab, mhip_stat_record *d_rec, hipStream_t s);
 int ccl8_u8_dev(const uint8_t *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels,
                 hipStream_t s);
+// a row band labels in two halves: ccl8_f32_begin_dev stops before the emit pass -- the labels raster gets its two top and two bottom
+// rows only (band-local ranks: what the seam merge on the host compares), parent (d_tmp) / root bits / word prefixes stay in `keep`
+// -- and label_emit_sparse_dev writes the GLOBAL labels once the merge has numbered them (label_ops.hip)
+struct CclKeep {
+    DevBuf bits, wprefix;
+    int64_t H = 0, W = 0, nlocal = 0;
+    bool valid = false;       // false: the labels raster holds band-local labels everywhere (a schedule without the kept tables)
+};
+int ccl8_f32_begin_dev(const float *d_data, int32_t *d_labels, int32_t *d_tmp, int64_t H, int64_t W, int64_t *nlabels, hipStream_t s, CclKeep *keep);
+int ccl_emit_rows_dev(const int32_t *d_parent, const unsigned long long *d_rootbits, const uint32_t *d_wordprefix, int32_t *d_labels, int64_t base,
+                      int64_t count, hipStream_t s);
+int label_emit_sparse_dev(const int32_t *d_parent, const unsigned long long *d_rootbits, const uint32_t *d_wordprefix, const float *d_data,
+                          int32_t *d_labels, int64_t H, int64_t W, int ht, int64_t H_owned, int64_t nlocal, int32_t offset,
+                          const int32_t *d_dropped, const int32_t *d_target, int32_t ndropped, int64_t nlab_global, mhip_stat_record *d_rec,
+                          hipStream_t s);
 // label_ops.hip
 int relabel_lut_dev(int32_t *d_labels, const int32_t *d_lut, int64_t nlab, int64_t n, hipStream_t s);
 int relabel_range_dev(int32_t *d_labels, int64_t n, int32_t lo, int32_t hi, const int32_t *d_lut, const int32_t *d_fid, const int32_t *d_fnew, int32_t nf,

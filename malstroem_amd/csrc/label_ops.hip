@@ -132,8 +132,33 @@ struct EmitArgs {
     const unsigned long long *rootbits;     // one bit per cell: component roots
     const uint32_t *wordprefix;             // root bits before each 64-bit word
     int32_t *labels;                        // out
+    // a ROW BAND (EMIT == 2): `data` starts at cell `cell0` of the labelled raster (the band's first owned row; parent / rootbits /
+    // wordprefix / labels cover the whole local raster, halo rows included), and the rank -- the band-local label -- goes through the
+    // sparse map of the band protocol on the way out (see sparse_map): what leaves is the GLOBAL label, and the records are the
+    // global label's
+    int64_t cell0;
+    const uint32_t *cnt256;                 // number of dropped labels below k * 256
+    const int32_t *dropped, *target;
+    int32_t offset;
 };
-template <bool COMPONENTS, bool EMIT>
+// band-local label l (>= 1) -> global label: offset + l - (number of dropped labels below l), a dropped label (sorted list: the
+// labels another band numbers, or that own no cell here) -> its explicit target.  The list is short and a table of its counts per
+// 256 labels takes most of the search away: two loads give the dropped labels that share l's 256-range [a, b) -- none for nearly every
+// label; the labels of the band's first rows (components that touch the top seam: all dropped, and some of them lakes of 100 000
+// cells) find 256 of them there and search those in 8 steps.
+__device__ __forceinline__ int32_t sparse_map(int32_t l, uint32_t a, uint32_t b, const int32_t *__restrict__ dropped, const int32_t *__restrict__ target,
+                                              int32_t offset)
+{
+    const uint32_t end = b;
+    while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (dropped[mid] < l) a = mid + 1;
+        else b = mid;
+    }
+    if (a < end && dropped[a] == l) return target[a];
+    return offset + l - (int32_t)a;
+}
+template <bool COMPONENTS, int EMIT>
 __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
                                                    TileGeom g, int64_t nlab, StatAcc a, unsigned int *bad, EmitArgs em)
 {
@@ -192,7 +217,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
             for (int u = 0; u < 4; ++u) {
                 const int64_t i = (tr * TR + r4 + u) * g.W + col;
                 const bool valid = col < g.W && i < g.n;
-                lq[u] = valid ? (EMIT ? em.parent[i] : lab[i]) : -1;
+                lq[u] = valid ? (EMIT ? em.parent[(EMIT == 2 ? em.cell0 : 0) + i] : lab[i]) : -1;
                 dq[u] = valid ? data[i] : 0.0f;
                 if (!EMIT && valid && (lq[u] < 0 || lq[u] > nlab)) {
                     atomicOr(bad, 1u);
@@ -214,14 +239,29 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
                     wp[u] = em.wordprefix[gg >> 6];
                     rb[u] = em.rootbits[gg >> 6];
                 }
+                int32_t lr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t gg = gq[u];
+                    lr[u] = gg >= 0 ? (int32_t)(wp[u] + (uint32_t)__popcll(rb[u] & ((1ull << (gg & 63)) - 1ull))) + 1 : 0;
+                }
+                if (EMIT == 2) {
+                    uint32_t ca[4], cb[4];      // (the four rows' table entries in flight together)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        ca[u] = em.cnt256[(uint32_t)lr[u] >> 8];
+                        cb[u] = em.cnt256[((uint32_t)lr[u] >> 8) + 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (lr[u] > 0) lr[u] = sparse_map(lr[u], ca[u], cb[u], em.dropped, em.target, em.offset);
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int64_t i = (tr * TR + r4 + u) * g.W + col;
                     const bool valid = col < g.W && i < g.n;
-                    const int32_t gg = gq[u];
-                    const int32_t l = gg >= 0 ? (int32_t)(wp[u] + (uint32_t)__popcll(rb[u] & ((1ull << (gg & 63)) - 1ull))) + 1 : 0;
-                    if (valid) em.labels[i] = l;
-                    lq[u] = valid ? l : -1;
+                    if (valid) em.labels[(EMIT == 2 ? em.cell0 : 0) + i] = lr[u];
+                    lq[u] = valid ? lr[u] : -1;
                 }
             }
 #pragma unroll
@@ -751,9 +791,9 @@ int label_stats_dev(const float *d_data, const int32_t *d_labels, int64_t n, int
     // (the shortcut for components needs the raster's real geometry: tile_geom treats a flat array as 256 columns wide)
     // (the shortcut for components needs the raster's real geometry: tile_geom treats a flat array as 256 columns wide)
     if (components && W > 0 && n % W == 0)
-        hipLaunchKernelGGL((stats_kernel<true, false>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>(), EmitArgs{});
+        hipLaunchKernelGGL((stats_kernel<true, 0>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>(), EmitArgs{});
     else
-        hipLaunchKernelGGL((stats_kernel<false, false>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>(), EmitArgs{});
+        hipLaunchKernelGGL((stats_kernel<false, 0>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, d_labels, g, nlab, a, bad.as<unsigned int>(), EmitArgs{});
     hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
     MH_HIP(hipGetLastError());
     return check_bad(bad, s, "label_stats");
@@ -773,11 +813,93 @@ int label_emit_stats_dev(const int32_t *d_parent, const unsigned long long *d_ro
     hipLaunchKernelGGL(stats_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
     TileGeom g;
     g.n = n; g.W = W; g.ntr = cdiv(H, TR); g.ntc = cdiv(W, 256);
-    hipLaunchKernelGGL((stats_kernel<true, true>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, (const int32_t *)nullptr, g, nlab, a, (unsigned int *)nullptr,
-                       EmitArgs{d_parent, d_rootbits, d_wordprefix, d_labels});
+    hipLaunchKernelGGL((stats_kernel<true, 1>), dim3(tile_grid(g)), dim3(256), 0, s, d_data, (const int32_t *)nullptr, g, nlab, a, (unsigned int *)nullptr,
+                       EmitArgs{d_parent, d_rootbits, d_wordprefix, d_labels, 0, nullptr, nullptr, nullptr, 0});
     hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
     MH_HIP(hipGetLastError());
     MH_HIP(stream_sync(s));      // the accumulators go back to the pool
+    return MHIP_OK;
+}
+
+// ---- a row band's labelling in two halves (ccl.hip: ccl8_f32_begin_dev keeps parent / rootbits / wordprefix) ----------------------
+// cells [base, base + count) of the labelled raster: rank of the cell's component (the band-local label), SPARSE: through the
+// band protocol's map (sparse_map) to the global label
+template <bool SPARSE>
+__global__ __launch_bounds__(256) void emit_range_kernel(EmitArgs em, int64_t base, int64_t count)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const int64_t i = base + k;
+    const int32_t p = em.parent[i];
+    int32_t l = 0;
+    if (p >= 0) {
+        const int32_t g = em.parent[p];
+        l = (int32_t)(em.wordprefix[g >> 6] + (uint32_t)__popcll(em.rootbits[g >> 6] & ((1ull << (g & 63)) - 1ull))) + 1;
+        if (SPARSE) l = sparse_map(l, em.cnt256[(uint32_t)l >> 8], em.cnt256[((uint32_t)l >> 8) + 1], em.dropped, em.target, em.offset);
+    }
+    em.labels[i] = l;
+}
+// cnt256[k] = number of dropped labels below k * 256 (lower bound in the sorted list)
+__global__ __launch_bounds__(256) void sparse_index_kernel(const int32_t *__restrict__ dropped, int32_t ndropped, int64_t nk, uint32_t *__restrict__ cnt256)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nk) return;
+    const int64_t key = k << 8;
+    int32_t lo = 0, hi = ndropped;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if ((int64_t)dropped[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    cnt256[k] = (uint32_t)lo;
+}
+
+int ccl_emit_rows_dev(const int32_t *d_parent, const unsigned long long *d_rootbits, const uint32_t *d_wordprefix, int32_t *d_labels, int64_t base,
+                      int64_t count, hipStream_t s)
+{
+    if (count <= 0) return MHIP_OK;
+    hipLaunchKernelGGL((emit_range_kernel<false>), dim3((unsigned)cdiv(count, 256)), dim3(256), 0, s,
+                       EmitArgs{d_parent, d_rootbits, d_wordprefix, d_labels, 0, nullptr, nullptr, nullptr, 0}, base, count);
+    MH_HIP(hipGetLastError());
+    return MHIP_OK;
+}
+
+// The second half: every cell of the local raster (H rows, the owned ones are [ht, ht + H_owned)) gets its GLOBAL label in ONE pass
+// from parent[] -- rank (= band-local label) -> sparse map -- instead of an emit pass and a relabelling pass over the labels; with
+// d_rec the owned rows' label_stats ride on that pass as in the single context (records by GLOBAL label, nlab_global + 1 of them).
+int label_emit_sparse_dev(const int32_t *d_parent, const unsigned long long *d_rootbits, const uint32_t *d_wordprefix, const float *d_data,
+                          int32_t *d_labels, int64_t H, int64_t W, int ht, int64_t H_owned, int64_t nlocal, int32_t offset,
+                          const int32_t *d_dropped, const int32_t *d_target, int32_t ndropped, int64_t nlab_global, mhip_stat_record *d_rec,
+                          hipStream_t s)
+{
+    const int64_t nk = (nlocal >> 8) + 2;
+    DevBuf cnt;
+    MH_TRY(cnt.alloc(4 * (size_t)nk));
+    hipLaunchKernelGGL(sparse_index_kernel, dim3((unsigned)cdiv(nk, 256)), dim3(256), 0, s, d_dropped, ndropped, nk, cnt.as<uint32_t>());
+    EmitArgs em{d_parent, d_rootbits, d_wordprefix, d_labels, (int64_t)ht * W, cnt.as<uint32_t>(), d_dropped, d_target, offset};
+    const int64_t n_owned = H_owned * W;
+    DevBuf mn, mx, sm, ct;
+    if (d_rec) {
+        const int64_t nrec = nlab_global + 1;
+        MH_TRY(mn.alloc(4 * (size_t)nrec));
+        MH_TRY(mx.alloc(4 * (size_t)nrec));
+        MH_TRY(sm.alloc(8 * (size_t)nrec));
+        MH_TRY(ct.alloc(8 * (size_t)nrec));
+        StatAcc a{mn.as<uint32_t>(), mx.as<uint32_t>(), sm.as<double>(), ct.as<unsigned long long>()};
+        hipLaunchKernelGGL(stats_init_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec);
+        TileGeom g;
+        g.n = n_owned; g.W = W; g.ntr = cdiv(H_owned, TR); g.ntc = cdiv(W, 256);
+        hipLaunchKernelGGL((stats_kernel<true, 2>), dim3(tile_grid(g)), dim3(256), 0, s, d_data + em.cell0, (const int32_t *)nullptr, g, nlab_global, a,
+                           (unsigned int *)nullptr, em);
+        hipLaunchKernelGGL(stats_finish_kernel, dim3((unsigned)cdiv(nrec, 256)), dim3(256), 0, s, a, nrec, d_rec);
+    } else if (n_owned > 0) {
+        hipLaunchKernelGGL((emit_range_kernel<true>), dim3((unsigned)cdiv(n_owned, 256)), dim3(256), 0, s, em, em.cell0, n_owned);
+    }
+    if (ht > 0) hipLaunchKernelGGL((emit_range_kernel<true>), dim3((unsigned)cdiv(ht * W, 256)), dim3(256), 0, s, em, (int64_t)0, (int64_t)ht * W);
+    const int64_t below = (H - ht - H_owned) * W;
+    if (below > 0) hipLaunchKernelGGL((emit_range_kernel<true>), dim3((unsigned)cdiv(below, 256)), dim3(256), 0, s, em, (ht + H_owned) * W, below);
+    MH_HIP(hipGetLastError());
+    MH_HIP(stream_sync(s));      // the table and the accumulators go back to the pool
     return MHIP_OK;
 }
 

@@ -647,6 +647,21 @@ class HipBand(object):
         _lib.call("mhip_ctx_band_ccl_local", self._ctx, ctypes.byref(n))
         return int(n.value)
 
+    def ccl_begin(self):
+        """ccl_local without its emit pass: the number of band-local labels; of the labels raster only the edge rows exist until
+        ``ccl_finish`` (csrc/api.hip: mhip_ctx_band_ccl_begin)"""
+        n = ctypes.c_int64(0)
+        _lib.call("mhip_ctx_band_ccl_begin", self._ctx, ctypes.byref(n))
+        return int(n.value)
+
+    def ccl_finish(self, offset, dropped, target, nlabels_global, with_stats):
+        """the global label of every cell in one pass (the map of ``relabel_sparse``); with_stats: the label statistics of the owned
+        rows on the same pass -- ``records_compute(0)`` need not run then"""
+        d = np.ascontiguousarray(dropped, dtype=np.int32)
+        t = np.ascontiguousarray(target, dtype=np.int32)
+        _lib.call("mhip_ctx_band_ccl_finish", self._ctx, _lib.i64(offset), _lib.ptr(d), _lib.ptr(t), _lib.i64(d.size), _lib.i64(nlabels_global),
+                  1 if with_stats else 0)
+
     def relabel(self, lut, nlabels_global):
         lut = np.ascontiguousarray(lut, dtype=np.int32)
         _lib.call("mhip_ctx_band_relabel", self._ctx, _lib.ptr(lut), _lib.i64(lut.size - 1), _lib.i64(nlabels_global))
@@ -769,6 +784,7 @@ def solve_band_accum(info, W):
 
 
 _DEV = os.environ.get("MHIP_DEVELOPER") == "1"      # development knobs are only read under MHIP_DEVELOPER=1 (like the library's dev_env)
+_LABEL_THREE_PASSES = _DEV and os.environ.get("MALSTROEM_BAND_LABEL") == "passes"    # A/B: ccl_local + relabel_sparse + records_compute(0)
 _PROF = _DEV and os.environ.get("MALSTROEM_BAND_PROFILE") is not None    # wall clock of the steps inside label() / _merged()
 
 
@@ -1136,7 +1152,7 @@ class BandPipeline(object):
             b.run_accum()
         self._local(second_pass)
 
-    def label(self):
+    def label(self, with_stats=False):
         """label.connected_components over all bands with scipy's numbering (order of first raster pixel).
 
         Every band labels its local raster (owned + halo rows).  Neighbours trade their edge rows of LOCAL labels (RCCL); a band
@@ -1144,12 +1160,18 @@ class BandPipeline(object):
         (mine, theirs) pair per run -- a few thousand pairs where the rows hold 65536 cells -- together with its phantoms (local
         components made of halo cells only).  The pairs of all bands are gathered once; every rank finds the classes (union-find,
         ``mhip_band_union_find``) and derives the numbering of EVERY band from them, so no further exchange is needed; each band
-        rewrites its labels on the device.  Returns the global number of labels."""
+        writes its labels on the device.  Returns the global number of labels.
+
+        A band that can label in two halves (``ccl_begin`` / ``ccl_finish``: the HIP band) writes only its edge rows in band-local
+        labels before the merge and every cell's GLOBAL label after it, in one pass over the raster instead of three (emit, read
+        back + rewrite); ``with_stats``: the label statistics of ``stats()`` ride on that pass."""
         b, comm, W, R, me = self.band, self._cur_comm(), self.W, self.comm.size, self.comm.rank
         lap = _Lap("label", comm.rank)
+        halves = hasattr(b, "ccl_begin") and not _LABEL_THREE_PASSES
+        self._stats_on_device = False
 
         def local_part():
-            n = b.ccl_local()
+            n = b.ccl_begin() if halves else b.ccl_local()
             return n, dict(first=b.get_edge_row("labels", 0), last=b.get_edge_row("labels", 1),
                            top=b.get_edge_row("labels", 2) if self.has_up else None,
                            bot=b.get_edge_row("labels", 3) if self.has_down else None)
@@ -1195,8 +1217,12 @@ class BandPipeline(object):
             self.label_range = (int(offsets[me]) + 1, int(offsets[me + 1]))
             self.label_offsets = offsets
         lap.lap("merge (host)")
-        self._local(b.relabel_sparse, nloc, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels)
-        lap.lap("relabel_sparse")
+        if halves:
+            self._local(b.ccl_finish, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels, with_stats)
+            self._stats_on_device = bool(with_stats)
+        else:
+            self._local(b.relabel_sparse, nloc, off, dropped.astype(np.int32), target.astype(np.int32), self.nlabels)
+        lap.lap("global labels")
         lap.report()
         return self.nlabels
 
@@ -1255,7 +1281,8 @@ class BandPipeline(object):
         b, (lo, hi) = self.band, self.label_range
         lap = _Lap("records %d" % which, self.comm.rank)
         ids = np.concatenate([[0], self.shared_labels]).astype(np.int64)
-        g = self._local(lambda: (b.records_compute(which), b.records_gather(which, ids))[1])
+        fresh = which == 0 and getattr(self, "_stats_on_device", False)      # (label(with_stats=True) left them on the device)
+        g = self._local(lambda: (None if fresh else b.records_compute(which), b.records_gather(which, ids))[1])
         lap.lap("compute + gather %d" % ids.size)
         parts = self._cur_comm().allgather(g)
         lap.lap("allgather")
@@ -1339,6 +1366,7 @@ class BandPipeline(object):
             self.label_range = (off + 1, off + nkept)
             self.shared_labels = np.unique(new[new > 0]).astype(np.int64)
         self._local(b.relabel_range, lo, hi, lut.astype(np.int32), ids[foreign].astype(np.int32), new[foreign].astype(np.int32), self.nlabels)
+        self._stats_on_device = False
         return self.nlabels
 
     # ---- the stream walk across bands (reference net.py:142-169; one leg per band: csrc/trace.hip band_trace_kernel)
@@ -1435,7 +1463,7 @@ class BandPipeline(object):
                 if hasattr(self.band, "side_begin"):
                     self.band.side_begin()
                 self._tls.comm = self._comm_b
-                timed("label", self.label)
+                timed("label", lambda: self.label(with_stats=records))
                 if records:
                     out["stats"] = timed("label", lambda: self.stats(fetch_own))
             except Exception as e:      # re-raised on the main thread
@@ -1470,7 +1498,7 @@ class BandPipeline(object):
             timed("noflat", self.noflat)
             timed("flowdir", self.flowdir)
             timed("accum", self.accum)
-            timed("label", self.label)
+            timed("label", lambda: self.label(with_stats=records))
             if records:
                 out["stats"] = timed("label", lambda: self.stats(fetch_own))
             timed("watershed", self.watershed)

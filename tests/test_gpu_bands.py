@@ -353,3 +353,55 @@ def test_bands_with_a_nan_cell_follow_the_one_context_path():
     assert all(o is not None for o in out)
     assert all(np.isnan(o[1][0]) and np.isnan(o[1][1]) for o in out)
     assert np.array_equal(np.concatenate([o[0] for o in out]), want, equal_nan=True)
+
+
+@pytest.mark.parametrize("nbands,h,w,with_stats", [(3, 700, 450, True), (4, 1030, 300, False), (2, 5, 300, True), (5, 640, 70, True)])
+def test_labelling_in_two_halves_equals_the_three_passes(monkeypatch, nbands, h, w, with_stats):
+    """ccl_begin / ccl_finish (edge rows before the seam merge, every cell's GLOBAL label -- and the label statistics -- in one pass
+    after it) against ccl_local + relabel_sparse + records_compute(0): the same labels on owned AND halo rows, the same records"""
+    import malstroem_amd.distributed as D
+    dem = fbm(h, w, beta=2.0, seed=31)
+    dem[h // 2 - 2:h // 2 + 2, 10:w - 10] = dem.min() - 1.0          # a bluespot along (and across) the middle seams
+    filled = oracle.fill_terrain(dem)
+    dep = oracle.depths(filled, dem)
+
+    def run(three_passes):
+        monkeypatch.setattr(D, "_LABEL_THREE_PASSES", three_passes)
+        out, err = [None] * nbands, []
+
+        def work(comm):
+            try:
+                p = D.BandPipeline(comm, dem.shape, device=0)
+                p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+                p.fill()
+                n = p.label(with_stats=with_stats)
+                assert p._stats_on_device == (with_stats and not three_passes)
+                st = p.stats(fetch_own=True)
+                rows = [p.band.get_edge_row("labels", side) for side in (0, 1)]
+                rows += [p.band.get_edge_row("labels", 2) if p.has_up else None, p.band.get_edge_row("labels", 3) if p.has_down else None]
+                out[comm.rank] = (n, p.download("labels"), st, rows)
+                p.close()
+            except Exception as e:  # pragma: no cover
+                err.append(e)
+                raise
+        threads = [threading.Thread(target=work, args=(c,)) for c in D.ThreadComm.world(nbands)]
+        [t.start() for t in threads]
+        [t.join(600) for t in threads]
+        assert not err, err
+        return out
+
+    a, b = run(False), run(True)
+    lab, n = oracle.connected_components(dep)
+    assert np.array_equal(np.concatenate([o[1] for o in a]), lab) and all(o[0] == n for o in a)
+    want = oracle.label_stats(dep, lab, n)
+    got = np.concatenate([o[2]["records"] for o in a])
+    for f in ("min", "max", "count"):
+        assert np.array_equal(got[f], want[1:][f]), f
+    for x, y in zip(a, b):
+        assert x[0] == y[0] and np.array_equal(x[1], y[1])
+        assert np.array_equal(x[2]["records"], y[2]["records"]) and x[2]["background"] == y[2]["background"]
+        for r, q in zip(x[3], y[3]):
+            assert (r is None and q is None) or np.array_equal(r, q)
+    # the halo rows carry the neighbour's global labels
+    for k in range(1, nbands):
+        assert np.array_equal(a[k][3][2], a[k - 1][3][1]) and np.array_equal(a[k - 1][3][3], a[k][3][0])

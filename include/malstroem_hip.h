@@ -235,7 +235,9 @@ int mhip_ctx_set_halo_row(mhip_ctx *ctx, int which, int side, const void *host, 
  * its own device-to-device transport */
 int mhip_ctx_get_edge_row_dev(mhip_ctx *ctx, int which, int side, void *dev_dst);
 int mhip_ctx_set_halo_row_dev(mhip_ctx *ctx, int which, int side, const void *dev_src, int32_t *changed);
-int mhip_ctx_dem_minmax(mhip_ctx *ctx, float *mn, float *mx, int32_t *has_nan);   /* owned rows only */
+/* extremes of the band's DEM rows, for the GLOBAL extremes of fill.py:235-250: over the owned rows -- or, when the band's flood has
+ * just folded them (over its local rows, halo rows included: cells of the same raster), those */
+int mhip_ctx_dem_minmax(mhip_ctx *ctx, float *mn, float *mx, int32_t *has_nan);
 /* kind 0: fill.fill_terrain, kind 1: fill.fill_terrain_no_flats (short/diag from the GLOBAL dem extremes) */
 int mhip_ctx_fill_begin(mhip_ctx *ctx, int kind, double short_, double diag, int32_t *active);
 int mhip_ctx_fill_batch(mhip_ctx *ctx, int kind, int32_t *active);

@@ -549,6 +549,7 @@ struct mhip_ctx {
     DevBuf tmp_i32;         // CCL parent scratch
     CclKeep ccl_keep;       // a row band's labelling between its two halves (mhip_ctx_band_ccl_begin / _finish)
     bool ccl_pending = false;
+    bool pf_depths = false;  // the band flood's last pass (mhip_ctx_fill_certify) wrote the depths of the owned rows
     DevBuf raw_stats, stats, ws_counts, pour;
     AccumKeep acc_keep;     // row band: the perimeter graph of mhip_ctx_band_accum_boundary, for the ACCUM run that follows the exchange
     int accum_algorithm = 0;   // 0: full accumulation, 1: the band's second pass as a delta over the kept graph
@@ -1295,6 +1296,14 @@ int mhip_ctx_dem_minmax(mhip_ctx *c, float *mn, float *mx, int32_t *has_nan)
 {
     MH_ARG(c && mn && mx && has_nan && c->have[MHIP_R_DEM], "ctx_dem_minmax needs the DEM");
     MH_HIP(hipSetDevice(c->device));
+    if (c->have[MHIP_R_FILLED] && c->fill_st.have_minmax) {
+        // the flood that has just run over this DEM folded the extremes of its tiles (pf_minmax_kernel) -- over the band's LOCAL rows,
+        // halo rows included: cells of the same global raster, and the global extremes are what the callers fold these into
+        *mn = c->fill_st.dem_min;
+        *mx = c->fill_st.dem_max;
+        *has_nan = c->fill_st.dem_nan ? 1 : 0;
+        return MHIP_OK;
+    }
     int hn = 0;
     MH_TRY(minmax_dev(c->r[MHIP_R_DEM].as<float>() + c->W * c->ht, c->H_owned * c->W, mn, mx, &hn, cs(c)));
     *has_nan = hn;
@@ -1315,6 +1324,7 @@ int mhip_ctx_fill_begin(mhip_ctx *c, int kind, double short_, double diag, int32
         delete c->pf;
         c->pf = nullptr;
         c->pf_done = false;
+        c->pf_depths = false;
         if (!force_iter) {
             PfRun *p = new PfRun();
             p->dem = c->r[MHIP_R_DEM].as<float>();
@@ -1449,12 +1459,14 @@ int mhip_ctx_fill_certify(mhip_ctx *c, int kind, int32_t *changed)
         // bound of the result); its neighbours follow when their halo rows move (mhip_ctx_fill_halo_changed below).
         bool violated = false;
         FillStats st;
-        MH_TRY(c->pf->finish(c->stream, nullptr, &st, &violated));
+        MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));      // the bluespot depths of the owned rows ride on the pass that writes the raster, as in one context
+        MH_TRY(c->pf->finish(c->stream, c->r[MHIP_R_DEPTHS].as<float>(), &st, &violated));
         delete c->pf;
         c->pf = nullptr;
         c->fill_st = st;
         c->fill_rounds = st.rounds;
         c->pf_done = true;
+        c->pf_depths = true;
         *changed = 0;
         if (violated) {
             MH_TRY(ctx_attach_iterative_fill(c));
@@ -1487,12 +1499,16 @@ int mhip_ctx_fill_end(mhip_ctx *c, int kind)
     MH_ARG(c && (kind == 0 || kind == 1) && (c->run[kind] || (kind == 0 && (c->pf || c->pf_done))), "ctx_fill_end needs ctx_fill_begin");
     MH_HIP(hipSetDevice(c->device));
     FillStats st;
+    bool depths_written = false;       // (of the owned rows: the flood's last pass leaves the halo rows to the neighbour)
     if (kind == 0 && c->pf) {          // (a caller that skipped the certification: no proof either)
-        MH_TRY(c->pf->finish(c->stream, nullptr, &st));
+        MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
+        MH_TRY(c->pf->finish(c->stream, c->r[MHIP_R_DEPTHS].as<float>(), &st));
         delete c->pf;
         c->pf = nullptr;
+        depths_written = true;
     } else if (kind == 0 && !c->run[0]) {
         st = c->fill_st;               // finished and proven by mhip_ctx_fill_certify
+        depths_written = c->pf_depths;
     } else {
         MH_TRY(c->run[kind]->finish(c->stream, &st));
         delete c->run[kind];
@@ -1507,9 +1523,17 @@ int mhip_ctx_fill_end(mhip_ctx *c, int kind)
     if (kind) { c->noflat_rounds = st.rounds; c->noflat_st = st; c->have[MHIP_R_NOFLAT] = true; }
     else {
         c->fill_rounds = st.rounds; c->fill_st = st; c->have[MHIP_R_FILLED] = true;
+        c->pf_depths = false;
         MH_TRY(ctx_raster(c, MHIP_R_DEPTHS));
-        MH_TRY(depths_dev(c->r[MHIP_R_FILLED].as<float>(), c->r[MHIP_R_DEM].as<float>(), c->r[MHIP_R_DEPTHS].as<float>(),
-                          c->H * c->W, c->stream));
+        const float *f = c->r[MHIP_R_FILLED].as<float>(), *d = c->r[MHIP_R_DEM].as<float>();
+        float *o = c->r[MHIP_R_DEPTHS].as<float>();
+        if (!depths_written) {
+            MH_TRY(depths_dev(f, d, o, c->H * c->W, c->stream));
+        } else {                       // the halo rows: the neighbour's surface over the neighbour's terrain
+            if (c->ht) MH_TRY(depths_dev(f, d, o, c->ht * c->W, c->stream));
+            const int64_t below = (c->ht + c->H_owned) * c->W;
+            if (c->hb) MH_TRY(depths_dev(f + below, d + below, o + below, c->hb * c->W, c->stream));
+        }
         c->have[MHIP_R_DEPTHS] = true;
     }
     return MHIP_OK;

@@ -1549,8 +1549,11 @@ class BandPipeline(object):
                 finally:
                     flow_ready.set()
 
+            labels_ready = threading.Event()
+
             def side():
                 label_branch()
+                labels_ready.set()
                 flow_ready.wait()
                 # whether the watershed branch runs is a COLLECTIVE decision on the side communicator: the facts it rests on
                 # (label failed, flowdir failed) are the same on every rank, the vote makes sure of it
@@ -1558,11 +1561,16 @@ class BandPipeline(object):
                 if self._comm_b.allreduce_max(bad) == 0.0:
                     ws_branch()
 
-            together([("flowdir", flowdir_then_signal), ("accum", self.accum)], side)
+            def pour_next_to_the_watersheds():
+                # the pour points want the accumulated flow (this thread) and the labels (the other one): they run here, on the main
+                # stream and the main communicator, while the side thread is at the watersheds
+                labels_ready.wait()
+                if self.comm.allreduce_max(1.0 if err_side else 0.0) == 0.0:      # (label() failed: the same on every rank; the join below raises)
+                    out["pour"] = self.pourpoints(fetch_own)
+
+            together([("flowdir", flowdir_then_signal), ("accum", self.accum)] + ([("pourpoints", pour_next_to_the_watersheds)] if records else []), side)
         finally:
             sys.setswitchinterval(old_switch)
-        if records:
-            out["pour"] = timed("pourpoints", lambda: self.pourpoints(fetch_own))
         return out
 
     def download(self, name):

@@ -159,6 +159,7 @@ __device__ __forceinline__ int32_t sparse_map(int32_t l, uint32_t a, uint32_t b,
     return offset + l - (int32_t)a;
 }
 template <bool COMPONENTS, int EMIT>
+__attribute__((amdgpu_waves_per_eu(8, 8)))      // eight workgroups per CU (tests/test_build_lint.py); the band variant asked for 68 registers without it
 __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ data, const int32_t *__restrict__ lab,
                                                    TileGeom g, int64_t nlab, StatAcc a, unsigned int *bad, EmitArgs em)
 {
@@ -246,15 +247,14 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
                     lr[u] = gg >= 0 ? (int32_t)(wp[u] + (uint32_t)__popcll(rb[u] & ((1ull << (gg & 63)) - 1ull))) + 1 : 0;
                 }
                 if (EMIT == 2) {
-                    uint32_t ca[4], cb[4];      // (the four rows' table entries in flight together)
+                    // (two rows' table entries in flight together: all four cost the kernel its eighth workgroup per CU in registers)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        ca[u] = em.cnt256[(uint32_t)lr[u] >> 8];
-                        cb[u] = em.cnt256[((uint32_t)lr[u] >> 8) + 1];
+                    for (int h = 0; h < 4; h += 2) {
+                        const uint32_t a0 = em.cnt256[(uint32_t)lr[h] >> 8], b0 = em.cnt256[((uint32_t)lr[h] >> 8) + 1];
+                        const uint32_t a1 = em.cnt256[(uint32_t)lr[h + 1] >> 8], b1 = em.cnt256[((uint32_t)lr[h + 1] >> 8) + 1];
+                        if (lr[h] > 0) lr[h] = sparse_map(lr[h], a0, b0, em.dropped, em.target, em.offset);
+                        if (lr[h + 1] > 0) lr[h + 1] = sparse_map(lr[h + 1], a1, b1, em.dropped, em.target, em.offset);
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (lr[u] > 0) lr[u] = sparse_map(lr[u], ca[u], cb[u], em.dropped, em.target, em.offset);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {

@@ -133,7 +133,7 @@ def test_tile_kernels_keep_their_resident_workgroups(tmp_path):
     """The tile kernels of the tail wait on LDS round trips and barriers: workgroups per CU is what their speed hangs on, and a few
     registers or kilobytes too many cost a quarter of it without a test failing (end of round 3: the labelling's tile union-find ran
     5 of 8 workgroups, the statistics 6, the watersheds' tile pass 4 after the pour-point candidates were added)."""
-    want = {"ccl.hip": {"ccl_tile_kernelIf": 8}, "label_ops.hip": {"stats_kernelILb1ELb1E": 8}, "watershed.hip": {"ws_tile_kernel": 8},
+    want = {"ccl.hip": {"ccl_tile_kernelIf": 8}, "label_ops.hip": {"stats_kernelILb1ELi1E": 8, "stats_kernelILb1ELi2E": 8}, "watershed.hip": {"ws_tile_kernel": 8},
             "accum.hip": {"accum_tile_kernelILb0ELb0ELb1E": 4, "accum_final_walk_kernel": 6}}
     for fn, kernels in want.items():
         res = _residency(_isa(CSRC / fn, tmp_path / (fn + ".s")).read_text())

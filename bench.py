@@ -367,11 +367,15 @@ def main():
         shutdown(3)
 
     nsampled = [0]
+    band_step_ms = []
 
     def step(record, sample=True):
         if band_mode:
+            t_s = time.perf_counter()
             gate.wait()     # go
             gate.wait()     # all bands of this process are through
+            if record:
+                band_step_ms.append(round((time.perf_counter() - t_s) * 1e3, 1))      # (this process's bands; the line's time is the span of all steps, max over ranks)
         else:
             # one request for the whole chain: the library runs the bluespot branch (label, watershed) on a second
             # stream next to no-flats fill -> D8 -> accumulation ("stage DAG"); all labels are kept
@@ -519,7 +523,7 @@ def main():
                 host_serial[k2] = max(host_serial.get(k2, 0.0), v / args.steps)
         info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands,
                 "band_engines": [w.pipe.engines() for w in workers], "engines": ENGINE_NOTE,
-                "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side), "check": check_note,
+                "step_ms_rank0": band_step_ms, "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side), "check": check_note,
                 # thread CPU time per step of the host-only sections of the boundary systems (label / accumulation / watershed
                 # seams), maximum over the bands of rank 0: what does not shrink with the number of GPUs
                 "host_serial_ms": {k2: round(v, 2) for k2, v in sorted(host_serial.items())},

@@ -392,9 +392,13 @@ __global__ __launch_bounds__(ATN, WIDE ? 1 : 4) void accum_tile_kernel(const uin
 // tainted as well); an entry whose inflow never arrived taints its path.
 // `pc.key` (optional): the pour points on the way (common.hpp: PourCandDev) -- the final sums of the tile's candidate cells go
 // into the keys of their labels.
+// Row bands (fixed_top / fixed_bot: local row 0 / H - 1 is a halo row): the BOUNDARY pass only, where the halo cells are sources of no
+// flux -- phase 1 has given them the local sum 0 and cut every path that flows into a halo row; here they start no walk, end every
+// walk that would step onto them and are not written (their words in `out` are scratch until the exchange fills the halo rows).
 __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__restrict__ fd, double *__restrict__ out, int64_t H, int64_t W, int ntc, Nodes nd,
-                                                              PourCandDev pc)
+                                                              PourCandDev pc, int fixed_top, int fixed_bot)
 {
+    auto halo_row = [&](int64_t rr) { return (fixed_top && rr == 0) || (fixed_bot && rr == H - 1); };
     __shared__ __attribute__((aligned(16))) uint32_t S[AT * AT];
     __shared__ __attribute__((aligned(16))) uint16_t P[AT * AT];
     __shared__ uint32_t wl_cell[NODE_STRIDE], wl_add[NODE_STRIDE];
@@ -463,18 +467,23 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
             nx[t] = (uint16_t)SENT13;
             if (code <= 7u && !(l[t] & TAINT32)) {
                 const int nr = r + dir_dr((int)code), nc = c + dir_dc((int)code);
-                if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (FULL || ((r0 + nr) < H && (c0 + nc) < W))) nx[t] = (uint16_t)(nr * AT + nc);
+                if (nr >= 0 && nr < AT && nc >= 0 && nc < AT && (FULL || ((r0 + nr) < H && (c0 + nc) < W && !halo_row(r0 + nr)))) nx[t] = (uint16_t)(nr * AT + nc);
             }
         }
         *reinterpret_cast<uint4 *>(&S[r * AT + c4]) = make_uint4(l[0], l[1], l[2], l[3]);
         *reinterpret_cast<uint2 *>(&P[r * AT + c4]) = make_uint2((uint32_t)nx[0] | ((uint32_t)nx[1] << 16), (uint32_t)nx[2] | ((uint32_t)nx[3] << 16));
     }
     };
-    if (wide && r0 + AT <= H) build(std::true_type{});
+    if (wide && r0 + AT <= H && !(fixed_top && ti == 0) && !(fixed_bot && r0 + AT >= H)) build(std::true_type{});
     else build(std::false_type{});
     __syncthreads();
     // the walkers: every entry with its inflow (bit 31: the inflow never arrived -- the path is tainted)
-    const unsigned dext = arrived >> 16;
+    unsigned dext = arrived >> 16;
+    if (tid < PERIM && dext && (fixed_top || fixed_bot)) {      // (a band's halo cell is no entry, whatever flowed at it)
+        int r, c;
+        perim_cell(tid, r, c);
+        if (halo_row(r0 + r)) dext = 0;
+    }
     if (tid < PERIM && dext) {
         int r, c;
         perim_cell(tid, r, c);
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(ATN) void accum_final_walk_kernel(const uint8_t *__
     for (int q = tid; q < AT * 16; q += ATN) {
         const int r = q >> 4, c4 = (q & 15) * 4;
         const int64_t rr = r0 + r;
-        if (rr >= H) continue;
+        if (rr >= H || halo_row(rr)) continue;
         typedef double __attribute__((ext_vector_type(2))) v2d;
         const uint4 sv = *reinterpret_cast<const uint4 *>(&S[r * AT + c4]);
         const uint32_t sq[4] = {sv.x, sv.y, sv.z, sv.w};
@@ -856,7 +865,8 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     // the local sums of phase 1 fit 32 bits unless halo cells bring the neighbouring band's flux in (the final pass of a row band)
     // the final pass as walks from the entry cells (accum_final_walk_kernel) wherever the sums fit 32 bits and no halo row is a source
     static const bool doubling_final = dev_env("MHIP_ACC_DOUBLING") != nullptr;      // development knob: the second doubling pass (A/B)
-    const bool walk_final = !(fixed_top || fixed_bot) && !d_exit_map && H * W < (int64_t)0x7fffffff && !doubling_final;
+    // (a row band: its boundary pass -- halo cells are sources of no flux, the sums are the band's own cells)
+    const bool walk_final = (!(fixed_top || fixed_bot) || halo_zero) && (!d_exit_map || halo_zero) && H * W < (int64_t)0x7fffffff && !doubling_final;
     if (walk_final)
         hipLaunchKernelGGL((accum_tile_kernel<false, false, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else if ((fixed_top || fixed_bot) && !halo_zero)
@@ -876,7 +886,7 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
             pc = pour->dev;
             pour->consumed = true;
         }
-        hipLaunchKernelGGL(accum_final_walk_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, pc);
+        hipLaunchKernelGGL(accum_final_walk_kernel, dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, pc, fixed_top, fixed_bot);
     }
     else if ((!(fixed_top || fixed_bot) || halo_zero) && H * W < (int64_t)0x7fffffff)      // (halo_zero: a band's OWN cells only -- no sum passes their number)
         hipLaunchKernelGGL((accum_tile_kernel<true, false>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);

@@ -802,7 +802,12 @@ class _Lap:
 
     def report(self):
         if _PROF and self.rank == 0:
-            print("[band profile] %s: %s" % (self.what, ", ".join("%s %.1f" % kv for kv in self.acc)), file=sys.stderr, flush=True)
+            tot, cnt = {}, {}
+            for k, v in self.acc:       # (a name that recurs -- the laps of a loop -- is reported as its sum and count)
+                tot[k] = tot.get(k, 0.0) + v
+                cnt[k] = cnt.get(k, 0) + 1
+            print("[band profile] %s: %s" % (self.what, ", ".join("%s %.1f%s" % (k, tot[k], " (%d x)" % cnt[k] if cnt[k] > 1 else "") for k in tot)),
+                  file=sys.stderr, flush=True)
 
 
 # one pass-through pair of the band accumulation (csrc/bandsolve.hip: BandAccumPair)
@@ -980,24 +985,30 @@ class BandPipeline(object):
     def _fill(self, kind, name, short=0.0, diag=0.0, attach=False):
         b = self.band
         err, active = None, False
+        lap = _Lap("fill loop %d" % kind, self.comm.rank)
         try:
             active = b.fill_attach(kind, short, diag) if attach else b.fill_begin(kind, short, diag)
         except Exception as e:
             err = e
+        lap.lap("begin")
         while True:
             busy = False
             if err is None:
                 try:
                     ch_top, ch_bot = self._swap_edges(name)
+                    lap.lap("swap")
                     if ch_top:
                         b.fill_halo_changed(kind, 0)
                     if ch_bot:
                         b.fill_halo_changed(kind, 1)
                     self.exchanges["noflat" if kind else "fill"] += 1
                     busy = active or ch_top or ch_bot
+                    lap.lap("halo_changed")
                 except Exception as e:
                     err = e
-            if not self._vote(busy, err):
+            v = self._vote(busy, err)
+            lap.lap("vote")
+            if not v:
                 # every band is quiescent: certify -- one sweep over EVERY tile of every band.  The worklist schedule only
                 # revisits a tile when a neighbour's probe saw its halo drop; a sweep that moves nothing anywhere proves the
                 # state is the global fixed point (and repairs a lost wake-up if there ever was one: the loop resumes)
@@ -1006,6 +1017,7 @@ class BandPipeline(object):
                     moved = b.fill_certify(kind)
                 except Exception as e:
                     err = e
+                lap.lap("certify")
                 if not self._vote(moved, err):
                     break
                 active = False
@@ -1014,7 +1026,10 @@ class BandPipeline(object):
                 active = b.fill_batch(kind) if busy else False
             except Exception as e:
                 err = e
+            lap.lap("batch")
         b.fill_end(kind)
+        lap.lap("end")
+        lap.report()
 
     def fill(self):
         """fill.fill_terrain over all bands (+ bluespot depths of the owned rows)."""

@@ -784,6 +784,7 @@ def solve_band_accum(info, W):
 
 
 _DEV = os.environ.get("MHIP_DEVELOPER") == "1"      # development knobs are only read under MHIP_DEVELOPER=1 (like the library's dev_env)
+_ACCUM_AT_ONCE = _DEV and os.environ.get("MALSTROEM_BAND_ACCUM") == "at_once"      # A/B: the accumulation does not wait for the labelling's tile pass
 _LABEL_THREE_PASSES = _DEV and os.environ.get("MALSTROEM_BAND_LABEL") == "passes"    # A/B: ccl_local + relabel_sparse + records_compute(0)
 _PROF = _DEV and os.environ.get("MALSTROEM_BAND_PROFILE") is not None    # wall clock of the steps inside label() / _merged()
 
@@ -1192,6 +1193,9 @@ class BandPipeline(object):
                            bot=b.get_edge_row("labels", 3) if self.has_down else None)
         nloc, rows = self._local(local_part)
         lap.lap("ccl_local + edge rows")
+        started = getattr(self._tls, "ccl_done", None)      # run_chain: the main thread holds the accumulation back until here
+        if started is not None:
+            started.set()
         nbr_up, nbr_dn = self._neighbour_rows("labels")      # the neighbour's LAST row above / FIRST row below, in ITS labels
         lap.lap("neighbour rows")
         with self._host("label"):
@@ -1472,18 +1476,22 @@ class BandPipeline(object):
         if overlap and not hasattr(self, "_comm_b"):
             self._comm_b = self.comm.clone()
         err, err_side = [], []      # failures of the main thread / of the labelling thread
+        ccl_done = threading.Event()     # the labelling's tile pass is through (or the labelling has failed)
 
         def label_branch():
             try:
                 if hasattr(self.band, "side_begin"):
                     self.band.side_begin()
                 self._tls.comm = self._comm_b
+                self._tls.ccl_done = ccl_done
                 timed("label", lambda: self.label(with_stats=records))
                 if records:
                     out["stats"] = timed("label", lambda: self.stats(fetch_own))
             except Exception as e:      # re-raised on the main thread
                 err_side.append(e)
             finally:
+                ccl_done.set()
+                self._tls.ccl_done = None
                 self._tls.comm = None
                 if hasattr(self.band, "side_end"):
                     try:
@@ -1549,7 +1557,9 @@ class BandPipeline(object):
         try:
             # like the single-GPU DAG (csrc/api.hip, measured there): the no-flats fill has the GPU to itself -- its many small
             # launches queue behind the labelling's long workgroups otherwise -- then labelling + watersheds (the latter
-            # need labels and flow directions) run next to D8 + accumulation
+            # need labels and flow directions) run next to D8 + accumulation.  (Round 4: the labelling beside the no-flats fill, as in
+            # one context: the no-flats stage 29 -> 43 ms at 4 bands of 32768^2 on one GPU and the step 115.7 / 119.2 -> 114.7 / 118.5
+            # -- the band step is bound by the device's throughput, not by the order of its work.)
             timed("noflat", self.noflat)
             if self.comm.allreduce_max(0.0) > 0.0:      # (keeps the bands in step before the two-thread phase)
                 raise RuntimeError("another band failed in the no-flats fill")
@@ -1583,7 +1593,16 @@ class BandPipeline(object):
                 if self.comm.allreduce_max(1.0 if err_side else 0.0) == 0.0:      # (label() failed: the same on every rank; the join below raises)
                     out["pour"] = self.pourpoints(fetch_own)
 
-            together([("flowdir", flowdir_then_signal), ("accum", self.accum)] + ([("pourpoints", pour_next_to_the_watersheds)] if records else []), side)
+            def accum_behind_the_tile_labelling():
+                # labelling -> statistics -> watersheds -> counts is the longer of the two branches, and its first kernel (the tile
+                # union-find) took 19 ms instead of 6 next to the accumulation's tile pass (4 bands of 32768^2 on one GPU: the
+                # device divides itself evenly, not by who is on the critical path); the accumulation has the slack to wait
+                if not _ACCUM_AT_ONCE:
+                    ccl_done.wait()
+                self.accum()
+
+            together([("flowdir", flowdir_then_signal), ("accum", accum_behind_the_tile_labelling)]
+                     + ([("pourpoints", pour_next_to_the_watersheds)] if records else []), side)
         finally:
             sys.setswitchinterval(old_switch)
         return out

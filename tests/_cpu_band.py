@@ -361,6 +361,30 @@ class CpuBand(object):
         self._raster("labels")[...] = lab
         return n
 
+    # the labelling in two halves, as the HIP band does it (mhip_ctx_band_ccl_begin / _finish): between the halves only the two top
+    # and the two bottom rows of the labels raster hold (band-local) labels -- everything else is poisoned here, so a caller that
+    # read more than the edge rows before the merge would be found out
+    def ccl_begin(self):
+        lab, n = oracle.connected_components(self.r["depths"])
+        self._pending_labels = lab
+        vis = self._raster("labels")
+        vis[...] = -12345
+        H = vis.shape[0]
+        top = min(H, 2 if H >= 4 else H)
+        vis[:top] = lab[:top]
+        if H >= 4:
+            vis[H - 2:] = lab[H - 2:]
+        self._nlocal = n
+        return n
+
+    def ccl_finish(self, offset, dropped, target, nlabels_global, with_stats):
+        self._raster("labels")[...] = self._pending_labels
+        del self._pending_labels
+        self.relabel_sparse(self._nlocal, offset, dropped, target, nlabels_global)
+        if with_stats:
+            self.records_compute(0)
+            self._stats_with_labels = True
+
     def relabel(self, lut, nlabels_global):
         self.r["labels"][...] = np.asarray(lut)[self.r["labels"]]
         self.nlabels_global = int(nlabels_global)

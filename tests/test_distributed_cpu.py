@@ -408,6 +408,9 @@ def test_a_rank_local_failure_raises_on_every_rank_instead_of_hanging(where):
         def ccl_local(self):
             return self._boom("ccl_local") if where == "ccl_local" else CpuBand.ccl_local(self)
 
+        def ccl_begin(self):       # (the labelling in two halves: what run_chain calls on a band that has them)
+            return self._boom("ccl_begin") if where == "ccl_local" else CpuBand.ccl_begin(self)
+
         def watershed_local(self):
             return self._boom("watershed_local") if where == "watershed_local" else CpuBand.watershed_local(self)
 

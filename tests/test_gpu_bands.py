@@ -405,3 +405,18 @@ def test_labelling_in_two_halves_equals_the_three_passes(monkeypatch, nbands, h,
     # the halo rows carry the neighbour's global labels
     for k in range(1, nbands):
         assert np.array_equal(a[k][3][2], a[k - 1][3][1]) and np.array_equal(a[k - 1][3][3], a[k][3][0])
+
+
+@pytest.mark.parametrize("nbands", [2, 3])
+def test_bands_of_a_terrain_without_bluespots(nbands):
+    """no depression anywhere (a tilted plane with one pit in the LAST band only / none at all): bands without a single label go through
+    the labelling's two halves, the statistics pass and the record merges with empty label ranges"""
+    h, w = 400, 300
+    plane = (np.add.outer(np.arange(h), np.arange(w)) * 0.25).astype(np.float32)
+    for pit in (False, True):
+        dem = plane.copy()
+        if pit:
+            dem[h - 20:h - 10, 50:60] -= 30.0
+        out = run_bands(dem, nbands)
+        check_bands_against_oracle(dem, out)
+        assert out[0]["nlabels"] == (1 if pit else 0)

@@ -864,9 +864,8 @@ int accum_dev(const uint8_t *d_fd, double *d_out, int64_t H, int64_t W, hipStrea
     const unsigned gn = (unsigned)cdiv(nnodes, 256);
     // the local sums of phase 1 fit 32 bits unless halo cells bring the neighbouring band's flux in (the final pass of a row band)
     // the final pass as walks from the entry cells (accum_final_walk_kernel) wherever the sums fit 32 bits and no halo row is a source
-    static const bool doubling_final = dev_env("MHIP_ACC_DOUBLING") != nullptr;      // development knob: the second doubling pass (A/B)
     // (a row band: its boundary pass -- halo cells are sources of no flux, the sums are the band's own cells)
-    const bool walk_final = (!(fixed_top || fixed_bot) || halo_zero) && (!d_exit_map || halo_zero) && H * W < (int64_t)0x7fffffff && !doubling_final;
+    const bool walk_final = (!(fixed_top || fixed_bot) || halo_zero) && (!d_exit_map || halo_zero) && H * W < (int64_t)0x7fffffff;
     if (walk_final)
         hipLaunchKernelGGL((accum_tile_kernel<false, false, true>), dim3((unsigned)ntiles), dim3(ATN), 0, s, d_fd, d_out, H, W, ntc, nd, fixed_top, fixed_bot, halo_zero);
     else if ((fixed_top || fixed_bot) && !halo_zero)

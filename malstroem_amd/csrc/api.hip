@@ -632,7 +632,6 @@ int mhip_ctx_create_band(mhip_ctx **out, int64_t H_global, int64_t W, int64_t ro
     // branch of mhip_ctx_run fills the gaps on streams of the lowest
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (const char *e = dev_env("MHIP_MAIN_PRIO")) prio_greatest = atoi(e) ? prio_greatest : prio_least;   // development knob
     if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest) != hipSuccess) {
         comm_destroy(c->comm);
         delete c;
@@ -1783,15 +1782,10 @@ static int stage_label(mhip_ctx *c, hipStream_t s)
     hipEvent_t *e1;
     MH_TRY(stage_begin(c, MHIP_STAGE_LABEL, s, &e1));
     if (!c->have[MHIP_R_DEPTHS]) MH_TRY(stage_depths(c, s));   // stage DAG: the fill left them to this branch
-    // (label_stats of the raw labels rides on the labelling's last pass; MHIP_LABEL_FUSE=0, development: two passes)
-    static const bool fuse = [] { const char *e = dev_env("MHIP_LABEL_FUSE"); return !(e && e[0] == '0'); }();
+    // (label_stats of the raw labels rides on the labelling's last pass: as two passes 21.8 -> 22.2 ms a step, and with the statistics
+    // behind the stage's event -- beside the watersheds, off the critical path -- 22.3: round 4)
     MH_TRY(ccl8_f32_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), c->tmp_i32.as<int32_t>(), H, W,
-                        &c->nlabels_raw, s, fuse ? &c->raw_stats : nullptr));
-    if (!fuse) {
-        MH_TRY(c->raw_stats.alloc(sizeof(mhip_stat_record) * (size_t)(c->nlabels_raw + 1)));
-        MH_TRY(label_stats_dev(c->r[MHIP_R_DEPTHS].as<float>(), c->r[MHIP_R_LABELS].as<int32_t>(), n, c->nlabels_raw,
-                               c->raw_stats.as<mhip_stat_record>(), s, W, true));
-    }
+                        &c->nlabels_raw, s, &c->raw_stats));
     MH_HIP(hipEventRecord(*e1, s));
     c->ev_valid[MHIP_STAGE_LABEL] = true;
     c->have[MHIP_R_LABELS] = true;
@@ -1925,20 +1919,12 @@ int mhip_ctx_run(mhip_ctx *c, int mask)
             c->ev_valid[st];   // creates the key
         }
     }
-    // development knob MHIP_SIDE_CUMASK=<hex word>: the side streams may only use the CUs whose bit is set in the word (repeated
-    // over all 256 CUs) -- an experiment in letting the label branch run next to the latency-bound rounds of the no-flats fill
-    // without its long workgroups holding every CU
+    // (measured and settled in rounds 3 / 4, the knobs are gone: the priorities the other way round, and a CU mask that keeps the side
+    // streams off part of the chip so that the label branch could run next to the no-flats fill's latency-bound rounds -- neither
+    // moved the step)
     auto side_stream = [&](hipStream_t *st) -> int {
-        const char *m = dev_env("MHIP_SIDE_CUMASK");
-        if (m) {
-            uint32_t w[8];
-            for (uint32_t &x : w) x = (uint32_t)strtoul(m, nullptr, 16);
-            MH_HIP(hipExtStreamCreateWithCUMask(st, 8, w));
-            return MHIP_OK;
-        }
         int least = 0, greatest = 0;
         MH_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        if (const char *e = dev_env("MHIP_SIDE_PRIO")) least = atoi(e) ? greatest : least;   // development knob
         MH_HIP(hipStreamCreateWithPriority(st, hipStreamNonBlocking, least));
         return MHIP_OK;
     };

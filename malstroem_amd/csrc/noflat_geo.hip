@@ -1312,13 +1312,6 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
     const unsigned grid = (unsigned)std::min<int64_t>((m.nt + 3) / 4, 512);
     for (int k = 0; k < nb; ++k, ++m.round) {
         a.maxcyc = m.maxcyc;
-        {   // development knob: MHIP_NG_HEAD="rounds,cycles": the first `rounds` rounds run up to `cycles` local cycles per visit
-            static const char *eh = dev_env("MHIP_NG_HEAD");
-            if (eh) {
-                int hr = 0, hc = 1;
-                if (sscanf(eh, "%d,%d", &hr, &hc) == 2 && m.round <= hr) a.maxcyc = hc;
-            }
-        }
         a.count = m.d_any + m.round;     // tiles of this round (round 0: every tile)
         if (!m.round) {
             hipLaunchKernelGGL(ng_first_kernel, dim3(grid), dim3(256), m.lds, s, a);
@@ -1331,10 +1324,6 @@ int GeoRun::launch_rounds(hipStream_t s, int nb)
                                (int)((m.nt + 7) / 8), m.d_list, m.d_any + m.round);
         if (m.light) {
             const bool odd = ((m.round - m.light_from) & 1) != 0;
-            {
-                static const char *et = dev_env("MHIP_NG_TAILCYC");
-                if (et && atoi(et) >= 1) a.maxcyc = atoi(et);
-            }
             a.append = 1;
             a.round_next = m.round + 1;
             a.list = odd ? m.d_list2 : m.d_list;
@@ -1357,7 +1346,6 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
     Impl &m = *impl;
     static const bool off = [] { const char *e = dev_env("MHIP_NOFLAT"); return e && std::string(e) == "iterative"; }();
     m.debug = dev_env("MHIP_NG_DEBUG") != nullptr;
-    if (dev_env("MHIP_NG_MAXCYC")) m.maxcyc = atoi(dev_env("MHIP_NG_MAXCYC"));        // tuning knob (development)
     *applicable = false;
     *active = false;
     if (off || !filled || H < 3 || W < 3) return MHIP_OK;
@@ -1436,7 +1424,6 @@ int GeoRun::begin(hipStream_t s, bool *applicable, bool *active)
 int GeoRun::batch(hipStream_t s, bool *active)
 {
     Impl &m = *impl;
-    static const bool no_light = dev_env("MHIP_NG_NOLIGHT") != nullptr;   // development knob
     // rounds per host read-back; MHIP_NG_BATCH (tests): a small batch makes small rasters reach the self-listing tail rounds too
     const char *eb = dev_env("MHIP_NG_BATCH");
     const int nb_env = eb && atoi(eb) >= 1 && atoi(eb) <= BATCH ? atoi(eb) : 0;
@@ -1463,7 +1450,7 @@ int GeoRun::batch(hipStream_t s, bool *active)
             ++m.used;
         }
         m.last_count = h_any[nb - 1];
-        if (!m.light && h_any[nb - 1] <= LIGHT_TILES && !no_light) {   // the tail: from here on the rounds build their lists themselves
+        if (!m.light && h_any[nb - 1] <= LIGHT_TILES) {   // the tail: from here on the rounds build their lists themselves
             m.light = true;
             m.light_from = m.round;
         }

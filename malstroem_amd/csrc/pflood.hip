@@ -1718,8 +1718,7 @@ int PfRun::solve(hipStream_t s)
         sa.nbc = m.nbc;
         sa.eblk = m.eblk;
         sa.first = dev_env("MHIP_PF_DEBUG") ? 2 : 0;
-        static const int qgrid = [] { const char *e = dev_env("MHIP_PF_QGRID"); return e ? atoi(e) : 0; }();                // (development)
-        hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, qgrid ? qgrid : 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU
+        hipLaunchKernelGGL(pf_solve_queue_kernel, dim3((unsigned)std::min<size_t>(m.nslots, 768)), dim3(ST), 0, s, sa, m.queue, (const int *)m.ecount);   // three resident per CU (512 / 640 workgroups: slower, round 4)
         MH_HIP(hipGetLastError());
         m.launches += 2;
         unsigned int h_hdr[256 * 4 / 4];          // the queue's header: ONE copy

@@ -231,6 +231,11 @@ int mhip_ctx_band_info(mhip_ctx *ctx, int64_t *row_off, int64_t *rows_local, int
 int mhip_ctx_get_edge_row(mhip_ctx *ctx, int which, int side, void *host);   /* side 0: first owned row, 1: last owned row,
                                                                                 2: top halo row, 3: bottom halo row */
 int mhip_ctx_set_halo_row(mhip_ctx *ctx, int which, int side, const void *host, int32_t *changed); /* 0: top halo, 1: bottom */
+/* both rows of a halo exchange over the host transport with ONE synchronisation per call (the reference trades nothing: one raster,
+ * fill.py:112-232; the bands' fill loops exchange 7-24 times per step).  get: first / last OWNED row (a NULL buffer: not wanted);
+ * set: the neighbours' rows into the halo rows (NULL: no neighbour there), changed[0 / 1] = the top / bottom halo row changed */
+int mhip_ctx_get_edge_rows(mhip_ctx *ctx, int which, void *host_first, void *host_last);
+int mhip_ctx_set_halo_rows(mhip_ctx *ctx, int which, const void *host_top, const void *host_bottom, int32_t *changed /* [2] */);
 /* the same with DEVICE buffers of the caller (W * element size bytes on the context's GPU), for a launcher that brings
  * its own device-to-device transport */
 int mhip_ctx_get_edge_row_dev(mhip_ctx *ctx, int which, int side, void *dev_dst);

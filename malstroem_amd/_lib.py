@@ -38,7 +38,7 @@ SYMBOLS = [
     "mhip_ctx_kernel_ms", "mhip_ctx_get_i64", "mhip_ctx_get_f64", "mhip_ctx_raw_stats", "mhip_ctx_apply_keep",
     "mhip_ctx_stats", "mhip_ctx_watershed_counts", "mhip_ctx_pourpoints",
     "mhip_ctx_band_info", "mhip_ctx_get_edge_row", "mhip_ctx_set_halo_row", "mhip_ctx_get_edge_row_dev",
-    "mhip_ctx_set_halo_row_dev", "mhip_ctx_dem_minmax",
+    "mhip_ctx_set_halo_row_dev", "mhip_ctx_get_edge_rows", "mhip_ctx_set_halo_rows", "mhip_ctx_dem_minmax",
     "mhip_ctx_fill_begin", "mhip_ctx_fill_batch", "mhip_ctx_fill_halo_changed", "mhip_ctx_fill_certify", "mhip_ctx_fill_end",
     "mhip_ctx_geo_begin", "mhip_ctx_geo_batch", "mhip_ctx_geo_halo_changed", "mhip_ctx_geo_end", "mhip_ctx_fill_attach", "mhip_ctx_noflat_verify",
     "mhip_ctx_zero_raster", "mhip_ctx_band_accum_boundary", "mhip_ctx_band_ccl_local", "mhip_ctx_band_ccl_begin", "mhip_ctx_band_ccl_finish", "mhip_ctx_band_relabel", "mhip_ctx_band_relabel_sparse", "mhip_ctx_band_relabel_range", "mhip_ctx_band_trace", "mhip_ctx_band_watershed_local",

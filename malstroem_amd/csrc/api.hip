@@ -853,6 +853,57 @@ int mhip_ctx_set_halo_row_dev(mhip_ctx *c, int which, int side, const void *dev_
     return MHIP_OK;
 }
 
+/* The host transport's two halves of a halo exchange with ONE synchronisation each (mhip_ctx_get_edge_row / _set_halo_row: one per
+ * row -- four host round trips per exchange, and the flood's and the no-flats fill's loops exchange 7 to 24 times per step).
+ * get: the first / last owned row into host buffers (NULL: not wanted).  set: the neighbours' rows (NULL where there is none) are
+ * compared with / stored into the halo rows; changed[0 / 1] = the top / bottom halo row changed. */
+int mhip_ctx_get_edge_rows(mhip_ctx *c, int which, void *host_first, void *host_last)
+{
+    MH_ARG(c && which >= 0 && which < MHIP_R_COUNT_, "ctx_get_edge_rows(ctx, which, first, last)");
+    MH_ARG(c->r[which].p, "raster has not been computed or uploaded");
+    if (!host_first && !host_last) return MHIP_OK;
+    MH_HIP(hipSetDevice(c->device));
+    hipStream_t s = cs(c);
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    const char *base = c->r[which].as<char>();
+    if (host_first) MH_HIP(hipMemcpyAsync(host_first, base + rowb * c->ht, rowb, hipMemcpyDeviceToHost, s));
+    if (host_last) MH_HIP(hipMemcpyAsync(host_last, base + rowb * (c->ht + c->H_owned - 1), rowb, hipMemcpyDeviceToHost, s));
+    MH_HIP(stream_sync(s));
+    return MHIP_OK;
+}
+
+int mhip_ctx_set_halo_rows(mhip_ctx *c, int which, const void *host_top, const void *host_bottom, int32_t *changed)
+{
+    MH_ARG(c && changed && which >= 0 && which < MHIP_R_COUNT_, "ctx_set_halo_rows(ctx, which, top, bottom, changed[2])");
+    MH_ARG((!host_top || c->ht) && (!host_bottom || c->hb), "this band has no halo row on that side");
+    changed[0] = changed[1] = 0;
+    if (!host_top && !host_bottom) return MHIP_OK;
+    MH_HIP(hipSetDevice(c->device));
+    MH_TRY(ctx_raster(c, which));
+    hipStream_t s = cs(c);
+    const size_t rowb = raster_elem(which) * (size_t)c->W;
+    DevBuf &stage = on_side(c) ? c->comm_stage_b : c->comm_stage;
+    DevBuf flags;
+    MH_TRY(stage.alloc(2 * rowb));
+    MH_TRY(flags.alloc(8));
+    MH_HIP(hipMemsetAsync(flags.p, 0, 8, s));
+    char *base = c->r[which].as<char>();
+    if (host_top) {
+        MH_HIP(hipMemcpyAsync(stage.p, host_top, rowb, hipMemcpyHostToDevice, s));
+        MH_TRY(row_update_async(base, stage.p, (int64_t)rowb, flags.as<int>(), s));
+    }
+    if (host_bottom) {
+        MH_HIP(hipMemcpyAsync(stage.as<char>() + rowb, host_bottom, rowb, hipMemcpyHostToDevice, s));
+        MH_TRY(row_update_async(base + rowb * (c->H - 1), stage.as<char>() + rowb, (int64_t)rowb, flags.as<int>() + 1, s));
+    }
+    int h[2] = {0, 0};
+    MH_HIP(hipMemcpyAsync(h, flags.p, 8, hipMemcpyDeviceToHost, s));
+    MH_HIP(stream_sync(s));
+    changed[0] = h[0];
+    changed[1] = h[1];
+    return MHIP_OK;
+}
+
 /* RCCL transport (band contexts created with an ncclUniqueId): neighbours trade the edge rows of raster `which` GPU -> GPU
  * on the context's stream; the received rows are compared with / stored into the halo rows; changed[0 / 1] = top / bottom
  * halo row changed.  One host synchronisation (the two flags). */

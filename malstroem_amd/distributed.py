@@ -552,6 +552,23 @@ class HipBand(object):
         _lib.call("mhip_ctx_set_halo_row", self._ctx, which, int(side), _lib.ptr(a), ctypes.byref(changed))
         return bool(changed.value)
 
+    def get_edge_rows(self, name, first=True, last=True):
+        """(first owned row or None, last owned row or None): one library call, one synchronisation"""
+        which = RASTERS[name]
+        a = np.empty(self.W, dtype=RASTER_DTYPE[which]) if first else None
+        b = np.empty(self.W, dtype=RASTER_DTYPE[which]) if last else None
+        _lib.call("mhip_ctx_get_edge_rows", self._ctx, which, _lib.ptr(a) if first else None, _lib.ptr(b) if last else None)
+        return a, b
+
+    def set_halo_rows(self, name, top, bottom):
+        """the neighbours' rows into the halo rows (None: no neighbour); (top changed, bottom changed): one call, one synchronisation"""
+        which = RASTERS[name]
+        t = None if top is None else np.ascontiguousarray(top, dtype=RASTER_DTYPE[which])
+        b = None if bottom is None else np.ascontiguousarray(bottom, dtype=RASTER_DTYPE[which])
+        ch = (ctypes.c_int32 * 2)(0, 0)
+        _lib.call("mhip_ctx_set_halo_rows", self._ctx, which, _lib.ptr(t) if t is not None else None, _lib.ptr(b) if b is not None else None, ch)
+        return bool(ch[0]), bool(ch[1])
+
     def row_bytes(self, name):
         return self.W * np.dtype(RASTER_DTYPE[RASTERS[name]]).itemsize
 
@@ -942,6 +959,10 @@ class BandPipeline(object):
         b = self.band
         if self.rccl:
             return b.exchange_halo(name)
+        if hasattr(b, "get_edge_rows"):      # (the HIP band: both rows per library call, two host synchronisations instead of four)
+            to_up, to_down = b.get_edge_rows(name, self.has_up, self.has_down)
+            from_up, from_down = self.comm.exchange_rows(to_up, to_down)
+            return b.set_halo_rows(name, from_up if self.has_up else None, from_down if self.has_down else None)
         to_up = b.get_edge_row(name, 0) if self.has_up else None
         to_down = b.get_edge_row(name, 1) if self.has_down else None
         from_up, from_down = self.comm.exchange_rows(to_up, to_down)

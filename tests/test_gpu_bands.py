@@ -420,3 +420,32 @@ def test_bands_of_a_terrain_without_bluespots(nbands):
         out = run_bands(dem, nbands)
         check_bands_against_oracle(dem, out)
         assert out[0]["nlabels"] == (1 if pit else 0)
+
+
+def test_both_rows_of_an_exchange_in_one_call():
+    """mhip_ctx_get_edge_rows / mhip_ctx_set_halo_rows (one synchronisation per call: what the host transport's halo exchange uses)
+    against the one-row calls, on a middle band (two halo rows), a top band and a bottom band"""
+    from malstroem_amd.distributed import HipBand
+    dem = fbm(150, 70, beta=2.0, seed=6)
+    bands = [HipBand(150, 70, r0, 50, device=0, rank=k, size=3) for k, r0 in enumerate((0, 50, 100))]
+    try:
+        for b, r0 in zip(bands, (0, 50, 100)):
+            b.upload("dem", dem[r0:r0 + 50])
+        top, mid, bot = bands
+        first, last = mid.get_edge_rows("dem")
+        assert np.array_equal(first, dem[50]) and np.array_equal(last, dem[99])
+        assert mid.get_edge_rows("dem", first=False)[0] is None and np.array_equal(top.get_edge_rows("dem", first=False)[1], dem[49])
+        assert mid.set_halo_rows("dem", dem[49], dem[100]) == (True, True)
+        assert np.array_equal(mid.get_edge_row("dem", 2), dem[49]) and np.array_equal(mid.get_edge_row("dem", 3), dem[100])
+        assert mid.set_halo_rows("dem", dem[49], dem[100]) == (False, False)          # the same bytes again
+        other = dem[100].copy()
+        other[3] += 1.0
+        assert mid.set_halo_rows("dem", dem[49], other) == (False, True)
+        assert mid.set_halo_rows("dem", None, None) == (False, False)
+        assert top.set_halo_rows("dem", None, dem[50]) == (False, True) and np.array_equal(top.get_edge_row("dem", 3), dem[50])
+        assert bot.set_halo_rows("dem", dem[99], None) == (True, False) and np.array_equal(bot.get_edge_row("dem", 2), dem[99])
+        with pytest.raises(ValueError):
+            top.set_halo_rows("dem", dem[0], None)                                     # no halo row above the first band
+    finally:
+        for b in bands:
+            b.close()

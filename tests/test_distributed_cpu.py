@@ -113,6 +113,55 @@ def test_protocol_threadcomm_cpu_backend(nbands):
     check_records(out, ref)
 
 
+@pytest.mark.parametrize("procs,k", [(2, 2), (3, 2), (1, 3), (2, 3)])
+def test_protocol_hybridcomm_bands_per_process_times_processes(procs, k):
+    """HybridComm: k band threads per "process" times `procs` processes (the 1- and 2-GPU shapes of the 65536^2 scaling run; the
+    processes are stood in for by the endpoints of a ThreadComm here).  Rows travel between neighbours only -- in memory inside a
+    process, through the process-level neighbour exchange at its two ends --, the votes as one number per process."""
+    from malstroem_amd.distributed import HybridComm
+    dem = fbm(120, 70, beta=2.0, seed=9)
+    ref = reference(dem)
+    n = procs * k
+    out = [None] * n
+    calls = {"rows": 0, "objects": 0}
+
+    class CountingComm(ThreadComm):
+        def exchange_rows(self, a, b):
+            calls["rows"] += 1
+            return ThreadComm.exchange_rows(self, a, b)
+
+        def allgather(self, obj):
+            calls["objects"] += 1
+            return ThreadComm.allgather(self, obj)
+
+    def work(comm):
+        p = BandPipeline(comm, dem.shape, backend_factory=CpuBand)
+        assert (p.has_up, p.has_down) == (comm.rank > 0, comm.rank < n - 1)
+        p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+        rec = p.run_chain()
+        o = {kk: p.download(kk) for kk in KEYS}
+        o["short_diag"] = (p.short, p.diag)
+        o["nlabels"] = p.nlabels
+        o.update(rec)
+        out[comm.rank] = o
+
+    world = CountingComm._World(procs)
+    endpoints = [e for r in range(procs) for e in HybridComm.world(CountingComm(world, r), k)]
+    assert [e.rank for e in endpoints] == list(range(n)) and all(e.size == n for e in endpoints)
+    threads = [threading.Thread(target=work, args=(c,)) for c in endpoints]
+    [t.start() for t in threads]
+    [t.join(300) for t in threads]
+    assert all(o is not None for o in out)
+    for kk in KEYS:
+        assert np.array_equal(np.concatenate([o[kk] for o in out]), ref[kk]), kk
+    assert out[0]["short_diag"] == ref["short_diag"] and all(o["nlabels"] == ref["nlabels"] for o in out)
+    check_records(out, ref)
+    if procs > 1:
+        assert calls["rows"] > 0            # the halo rows went through the process-level NEIGHBOUR exchange ...
+    else:
+        assert calls["rows"] == 0           # ... and never left the process where there is only one
+
+
 def band_accum(fd, nbands, **kw):
     """BandPipeline.accum() on given flow directions -> (accumulation of the undivided raster, exchanges per band)"""
     out = [None] * nbands

@@ -521,7 +521,18 @@ def main():
         for w in workers:
             for k2, v in w.host_ms.items():
                 host_serial[k2] = max(host_serial.get(k2, 0.0), v / args.steps)
+        # which transport carries the rows of each seam (seam s lies between band s and band s + 1; band b runs on rank b // k)
+        seam_transports = []
+        kb = nbands // world      # bands per process
+        for sm in range(nbands - 1):
+            if sm // kb == (sm + 1) // kb:
+                seam_transports.append("memory of process %d (two bands of one process)" % (sm // kb))
+            elif used_rccl:
+                seam_transports.append("RCCL, rank %d <-> %d (ncclSend / ncclRecv on the bands' streams)" % (sm // kb, (sm + 1) // kb))
+            else:
+                seam_transports.append("host communicator (gloo point-to-point), process %d <-> %d" % (sm // kb, (sm + 1) // kb))
         info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands,
+                "seam_transports": seam_transports,
                 "band_engines": [w.pipe.engines() for w in workers], "engines": ENGINE_NOTE,
                 "step_ms_rank0": band_step_ms, "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side), "check": check_note,
                 # thread CPU time per step of the host-only sections of the boundary systems (label / accumulation / watershed

@@ -37,5 +37,10 @@ def test_bench_launch_shape_equals_one_context(nproc, bands, tmp_path):
     cfg = line["config"]
     assert line["n_gpus"] == nproc and cfg["bands"] == bands and line["scaling"] == "strong"
     assert cfg["rccl_ranks"] == 0                                  # one device: the rows went through the host communicator, and the line says so
+    seams = cfg["seam_transports"]                                 # ... seam by seam: in memory between two bands of one process, gloo between processes
+    k = bands // nproc
+    assert len(seams) == bands - 1
+    for sm, text in enumerate(seams):
+        assert text.startswith("memory of process") if sm // k == (sm + 1) // k else text.startswith("host communicator"), seams
     assert cfg["check"].endswith("== one undivided context"), cfg["check"]
     assert all(e["fill"] == 1 and e["noflat"] in (2, 3) for e in cfg["band_engines"]), cfg["band_engines"]

@@ -167,6 +167,20 @@ int mhip_band_ws_publish(int64_t W, int32_t me, const int32_t *mine, const int32
                          int64_t *n);
 int mhip_band_ws_lut(int64_t W, int32_t me, int64_t n, const int64_t *N, const int64_t *V, const int32_t *up, const int32_t *dn,
                      int32_t *lut);
+/* Rendezvous of the band threads of ONE process (distributed.ThreadComm / HybridComm: k bands per process where a raster is beyond
+ * 2**31 cells; the reference has no counterpart -- one process, one raster).  A thread blocks inside the call (ctypes: no GIL),
+ * spins a few microseconds and then sleeps; a wait longer than timeout_ms returns MHIP_ECOMM and breaks the group for good.
+ * allreduce_max: the maximum of every thread's value.  offer + take: the neighbour exchange in two calls -- rank r offers to_up (to
+ * r - 1) / to_down (to r + 1) with eight words of description each (meta[0] = bytes; NULL = nothing) and learns what its neighbours
+ * offer (meta_from_*[0] = -1: nothing); take copies those bytes into buffers the caller sized from that. */
+int mhip_tg_create(int32_t n, void **group);
+int mhip_tg_destroy(void *group);
+int mhip_tg_barrier(void *group, int32_t timeout_ms);
+int mhip_tg_allreduce_max(void *group, int32_t rank, double value, double *out, int32_t timeout_ms);
+int mhip_tg_offer(void *group, int32_t rank, const void *to_up, const int64_t *meta_up /* [8] */, const void *to_down, const int64_t *meta_down,
+                  int64_t *meta_from_up /* [8] */, int64_t *meta_from_down, int32_t timeout_ms);
+int mhip_tg_take(void *group, int32_t rank, void *from_up, void *from_down, int32_t timeout_ms);
+
 /* per-label records of labels that live in several bands: parts[r] = band r's n partial records, merged in band order into out.
  * kind 0: {min, max, sum, count} (label_stats, _label.pyx:22-24); kind 2 / 3: {value, row, col} of label_max_index / label_min_index
  * (_label.pyx:26-28; row < 0: the band holds no cell of the label; the earlier band wins ties = first raster position) */

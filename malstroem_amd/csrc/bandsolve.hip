@@ -464,3 +464,145 @@ extern "C" int mhip_band_merge_records(int32_t kind, int32_t R, int64_t n, const
     }
     return MHIP_OK;
 }
+
+// ---- several bands of ONE process (host threads): their rendezvous in the library ---------------------------------------------
+// The 1- and 2-GPU shapes of a raster beyond 2**31 cells run k bands per process, a host thread each (distributed.ThreadComm /
+// HybridComm).  Their halo exchanges and votes are rendezvous of those threads -- 40 to 60 per step -- and as Python objects
+// (queue.Queue, threading.Barrier: a handful of GIL hand-overs per thread and wait) each cost ~0.1 ms with the device idle.  Here a
+// thread blocks inside a ctypes call (no GIL), spins for a few microseconds first and sleeps on a condition variable after that.
+// A wait that lasts longer than `timeout_ms` returns MHIP_ECOMM: a band that died must not leave the others waiting for ever.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace {
+struct ThreadGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    std::atomic<unsigned long long> generation{0};
+    bool broken = false;
+    std::vector<double> value;
+    std::vector<const void *> up, down;     // the rows rank r offers to r - 1 / r + 1 in the current exchange
+    std::vector<int64_t> meta_up, meta_down;      // eight words each: [0] bytes (-1: nothing), the rest is the callers' (dtype, shape)
+    explicit ThreadGroup(int n_) : n(n_), value(n_), up(n_), down(n_), meta_up((size_t)n_ * 8), meta_down((size_t)n_ * 8) {}
+
+    int barrier(int timeout_ms)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return MHIP_ECOMM;
+        const unsigned long long gen = generation.load(std::memory_order_relaxed);
+        if (++arrived == n) {
+            arrived = 0;
+            generation.store(gen + 1, std::memory_order_release);
+            lk.unlock();
+            cv.notify_all();
+            return MHIP_OK;
+        }
+        lk.unlock();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {      // the others are usually microseconds away
+            if (generation.load(std::memory_order_acquire) != gen) return MHIP_OK;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
+        }
+        lk.lock();
+        const bool ok = cv.wait_for(lk, std::chrono::milliseconds(timeout_ms),
+                                    [&] { return generation.load(std::memory_order_acquire) != gen || broken; });
+        if (!ok || (broken && generation.load(std::memory_order_acquire) == gen)) {
+            broken = true;      // nobody gets past a barrier of this group any more
+            lk.unlock();
+            cv.notify_all();
+            return MHIP_ECOMM;
+        }
+        return MHIP_OK;
+    }
+};
+#define MH_TG(expr)                                                                                                         \
+    do {                                                                                                                    \
+        if ((expr) != MHIP_OK) {                                                                                            \
+            mh::set_error("a band thread of this process did not arrive within the timeout (or the group is broken)");     \
+            return MHIP_ECOMM;                                                                                              \
+        }                                                                                                                   \
+    } while (0)
+}  // namespace
+
+extern "C" int mhip_tg_create(int32_t n, void **group)
+{
+    MH_ARG(n >= 1 && group, "tg_create(n, &group)");
+    *group = new ThreadGroup(n);
+    return MHIP_OK;
+}
+
+extern "C" int mhip_tg_destroy(void *group)
+{
+    delete static_cast<ThreadGroup *>(group);
+    return MHIP_OK;
+}
+
+extern "C" int mhip_tg_barrier(void *group, int32_t timeout_ms)
+{
+    MH_ARG(group && timeout_ms > 0, "tg_barrier(group, timeout_ms)");
+    MH_TG(static_cast<ThreadGroup *>(group)->barrier(timeout_ms));
+    return MHIP_OK;
+}
+
+/* the maximum of every thread's value (all threads call it; rank in [0, n)) */
+extern "C" int mhip_tg_allreduce_max(void *group, int32_t rank, double value, double *out, int32_t timeout_ms)
+{
+    ThreadGroup *g = static_cast<ThreadGroup *>(group);
+    MH_ARG(g && out && rank >= 0 && rank < g->n && timeout_ms > 0, "tg_allreduce_max(group, rank, value, &out, timeout_ms)");
+    g->value[rank] = value;
+    MH_TG(g->barrier(timeout_ms));
+    double m = g->value[0];
+    for (int r = 1; r < g->n; ++r) m = g->value[r] > m ? g->value[r] : m;      // (a NaN vote loses: the callers vote 0 / 1 / 2)
+    *out = m;
+    MH_TG(g->barrier(timeout_ms));      // everybody has read: the slots may be written again
+    return MHIP_OK;
+}
+
+/* Neighbour exchange between the threads in two calls, because a thread does not know what its neighbours will hand it (halo rows
+ * have its own rows' shape; the raster writer passes blocks of rows of any height).  offer: rank r leaves `to_up` (for r - 1) and
+ * `to_down` (for r + 1) with eight words of description each (meta[0] = bytes, the rest is the caller's: item size, kind, shape);
+ * NULL = nothing.  It learns what r - 1 offers downwards (meta_from_up) and r + 1 upwards (meta_from_down); [0] = -1: nothing.
+ * take: the bytes into buffers of at least those sizes (NULL where nothing comes); the offered rows must stay valid until it returns. */
+extern "C" int mhip_tg_offer(void *group, int32_t rank, const void *to_up, const int64_t *meta_up, const void *to_down, const int64_t *meta_down,
+                             int64_t *meta_from_up, int64_t *meta_from_down, int32_t timeout_ms)
+{
+    ThreadGroup *g = static_cast<ThreadGroup *>(group);
+    MH_ARG(g && rank >= 0 && rank < g->n && meta_from_up && meta_from_down && timeout_ms > 0 && (!to_up || meta_up) && (!to_down || meta_down),
+           "tg_offer(group, rank, to_up, meta_up[8], to_down, meta_down[8], meta_from_up[8], meta_from_down[8], timeout_ms)");
+    g->up[rank] = to_up;
+    g->down[rank] = to_down;
+    for (int k = 0; k < 8; ++k) {
+        g->meta_up[(size_t)rank * 8 + k] = to_up ? meta_up[k] : -1;
+        g->meta_down[(size_t)rank * 8 + k] = to_down ? meta_down[k] : -1;
+    }
+    MH_TG(g->barrier(timeout_ms));
+    for (int k = 0; k < 8; ++k) {
+        meta_from_up[k] = rank > 0 ? g->meta_down[(size_t)(rank - 1) * 8 + k] : -1;
+        meta_from_down[k] = rank < g->n - 1 ? g->meta_up[(size_t)(rank + 1) * 8 + k] : -1;
+    }
+    return MHIP_OK;
+}
+
+extern "C" int mhip_tg_take(void *group, int32_t rank, void *from_up, void *from_down, int32_t timeout_ms)
+{
+    ThreadGroup *g = static_cast<ThreadGroup *>(group);
+    MH_ARG(g && rank >= 0 && rank < g->n && timeout_ms > 0, "tg_take(group, rank, from_up, from_down, timeout_ms)");
+    int rc = MHIP_OK;
+    if (rank > 0 && g->meta_down[(size_t)(rank - 1) * 8] >= 0) {
+        if (!from_up) rc = MHIP_EINVAL;
+        else memcpy(from_up, g->down[rank - 1], (size_t)g->meta_down[(size_t)(rank - 1) * 8]);
+    }
+    if (rank < g->n - 1 && g->meta_up[(size_t)(rank + 1) * 8] >= 0) {
+        if (!from_down) rc = MHIP_EINVAL;
+        else memcpy(from_down, g->up[rank + 1], (size_t)g->meta_up[(size_t)(rank + 1) * 8]);
+    }
+    MH_TG(g->barrier(timeout_ms));      // everybody has copied: the offered rows may go
+    if (rc != MHIP_OK) mh::set_error("tg_take: no buffer for a row a neighbour offers");
+    return rc;
+}

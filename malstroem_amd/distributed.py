@@ -104,16 +104,87 @@ class SingleComm(Comm):
         return [obj]
 
 
+class _Rendezvous(object):
+    """The meeting point of the n band threads of one process.  In the library where it can be loaded (``mhip_tg_*``: a thread blocks
+    inside a ctypes call -- no GIL --, spins a few microseconds and then sleeps; 40-60 rendezvous per step of a band chain cost
+    ~0.1 ms each as ``threading.Barrier`` / ``queue.Queue`` hand-overs with the device idle), as ``threading.Barrier`` elsewhere.
+    A wait that outlasts ``timeout_s`` raises on every thread (a band that died must not leave the others waiting)."""
+
+    def __init__(self, n, timeout_s=600.0):
+        self.n, self.timeout_ms = int(n), int(timeout_s * 1000)
+        self._tg = None
+        if os.environ.get("MALSTROEM_THREAD_RENDEZVOUS", "") != "python":
+            try:
+                h = ctypes.c_void_p()
+                _lib.call("mhip_tg_create", self.n, ctypes.byref(h))
+                self._tg = h
+            except Exception:
+                self._tg = None
+        self._barrier = threading.Barrier(self.n) if self._tg is None else None
+        self._slots = [None] * self.n
+
+    def __del__(self):
+        try:
+            if self._tg is not None:
+                _lib.call("mhip_tg_destroy", self._tg)
+        except Exception:
+            pass
+
+    def wait(self):
+        if self._tg is not None:
+            _lib.call("mhip_tg_barrier", self._tg, self.timeout_ms)
+        else:
+            self._barrier.wait(timeout=self.timeout_ms / 1e3)
+
+    def gather(self, rank, obj):
+        """every thread's object, in rank order"""
+        self._slots[rank] = obj
+        self.wait()
+        out = list(self._slots)
+        self.wait()
+        return out
+
+    def max(self, rank, value):
+        if self._tg is None:
+            return max(self.gather(rank, float(value)))
+        out = ctypes.c_double(0.0)
+        _lib.call("mhip_tg_allreduce_max", self._tg, int(rank), ctypes.c_double(float(value)), ctypes.byref(out), self.timeout_ms)
+        return out.value
+
+    def rows(self, rank, to_up, to_down):
+        """neighbour exchange between the threads: (row of rank - 1 offered downwards or None, row of rank + 1 offered upwards or None)"""
+        if self._tg is None:
+            offers = self.gather(rank, (None if to_up is None else np.array(to_up, copy=True), None if to_down is None else np.array(to_down, copy=True)))
+            return (offers[rank - 1][1] if rank > 0 else None), (offers[rank + 1][0] if rank < self.n - 1 else None)
+        a = None if to_up is None else np.ascontiguousarray(to_up)
+        b = None if to_down is None else np.ascontiguousarray(to_down)
+
+        def describe(x):      # bytes, item size, dtype kind, dimensions, shape (up to four)
+            if x.ndim > 4 or x.dtype.kind not in "fiub":
+                raise ValueError("rows travel as plain numeric arrays of at most four dimensions")
+            return (ctypes.c_int64 * 8)(x.nbytes, x.dtype.itemsize, ord(x.dtype.kind), x.ndim, *(list(x.shape) + [0] * (4 - x.ndim)))
+
+        def buffer_for(meta):
+            if meta[0] < 0:
+                return None
+            return np.empty(tuple(int(meta[4 + k]) for k in range(int(meta[3]))), dtype=np.dtype("%s%d" % (chr(int(meta[2])), int(meta[1]))))
+
+        m_up, m_down = (ctypes.c_int64 * 8)(), (ctypes.c_int64 * 8)()
+        _lib.call("mhip_tg_offer", self._tg, int(rank), _lib.ptr(a) if a is not None else None, describe(a) if a is not None else None,
+                  _lib.ptr(b) if b is not None else None, describe(b) if b is not None else None, m_up, m_down, self.timeout_ms)
+        from_up, from_down = buffer_for(m_up), buffer_for(m_down)
+        _lib.call("mhip_tg_take", self._tg, int(rank), _lib.ptr(from_up) if from_up is not None else None,
+                  _lib.ptr(from_down) if from_down is not None else None, self.timeout_ms)
+        return from_up, from_down
+
+
 class ThreadComm(Comm):
     """In-process transport: ``ThreadComm.world(n)`` returns n endpoints to be driven by n threads."""
 
     class _World(object):
         def __init__(self, n):
             self.n = n
-            self.down = [queue.Queue() for _ in range(n)]   # down[i]: messages travelling from rank i to rank i+1
-            self.up = [queue.Queue() for _ in range(n)]     # up[i]: messages travelling from rank i to rank i-1
-            self.barrier = threading.Barrier(n)
-            self.slots = [None] * n
+            self.meet = _Rendezvous(n)
 
     @classmethod
     def world(cls, n):
@@ -126,25 +197,13 @@ class ThreadComm(Comm):
         self.size = world.n
 
     def exchange_rows(self, to_up, to_down):
-        w = self._w
-        if self.rank > 0:
-            w.up[self.rank].put(None if to_up is None else np.array(to_up, copy=True))
-        if self.rank < self.size - 1:
-            w.down[self.rank].put(None if to_down is None else np.array(to_down, copy=True))
-        from_up = w.down[self.rank - 1].get(timeout=600) if self.rank > 0 else None
-        from_down = w.up[self.rank + 1].get(timeout=600) if self.rank < self.size - 1 else None
-        return from_up, from_down
+        return self._w.meet.rows(self.rank, to_up if self.rank > 0 else None, to_down if self.rank < self.size - 1 else None)
 
     def allgather(self, obj):
-        w = self._w
-        w.slots[self.rank] = obj
-        w.barrier.wait(timeout=600)
-        out = list(w.slots)
-        w.barrier.wait(timeout=600)
-        return out
+        return self._w.meet.gather(self.rank, obj)
 
     def allreduce_max(self, value):
-        return max(self.allgather(value))
+        return self._w.meet.max(self.rank, value)
 
     def clone(self):
         w = self.allgather(ThreadComm._World(self.size) if self.rank == 0 else None)[0]   # rank 0's object, shared in-process
@@ -411,7 +470,7 @@ class HybridComm(Comm):
     class _World(object):
         def __init__(self, proc, k):
             self.proc, self.k = proc, k
-            self.barrier = threading.Barrier(k)
+            self.meet = _Rendezvous(k, timeout_s=1800.0)
             self.slots = [None] * k
             self.result = None
 
@@ -428,24 +487,24 @@ class HybridComm(Comm):
     def allgather(self, obj):
         w = self._w
         w.slots[self._t] = obj
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         if self._t == 0:
             w.result = [o for part in w.proc.allgather(list(w.slots)) for o in part]
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         out = w.result
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         return out
 
     def allreduce_max(self, value):
         """the threads' maximum, then ONE number through the process-level communicator (not an all-gather of objects)"""
         w = self._w
         w.slots[self._t] = float(value)
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         if self._t == 0:
             w.result = w.proc.allreduce_max(max(w.slots)) if w.proc.size > 1 else max(w.slots)
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         out = w.result
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         return out
 
     def exchange_rows(self, to_up, to_down):
@@ -454,27 +513,27 @@ class HybridComm(Comm):
         exchange all-gathered every band's rows as objects: 2 processes x 2 bands of 32768 columns, 132 instead of 116 ms a step.)"""
         w, t, k = self._w, self._t, self._w.k
         w.slots[t] = (None if to_up is None else np.array(to_up, copy=True), None if to_down is None else np.array(to_down, copy=True))
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         if t == 0:
             if w.proc.size > 1:
                 w.result = w.proc.exchange_rows(w.slots[0][0] if w.proc.rank > 0 else None,
                                                 w.slots[k - 1][1] if w.proc.rank < w.proc.size - 1 else None)
             else:
                 w.result = (None, None)
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         from_up = w.slots[t - 1][1] if t > 0 else w.result[0]
         from_down = w.slots[t + 1][0] if t < k - 1 else w.result[1]
-        w.barrier.wait(timeout=1800)        # (everybody has read: the slots may be written again)
+        w.meet.wait()        # (everybody has read: the slots may be written again)
         return from_up, from_down
 
     def clone(self):
         w = self._w
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         if self._t == 0:
             w.result = HybridComm._World(w.proc.clone(), w.k)
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         nw = w.result
-        w.barrier.wait(timeout=1800)
+        w.meet.wait()
         return HybridComm(nw, self._t)
 
 

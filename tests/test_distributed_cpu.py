@@ -586,3 +586,56 @@ def test_socket_comm_wants_a_secret_off_the_loopback_interface(monkeypatch):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("impl", ["library", "python"])
+def test_the_band_threads_rendezvous(impl, monkeypatch):
+    """distributed._Rendezvous (the meeting point of the band threads of one process): in the library (mhip_tg_*) and as Python
+    barriers -- maxima, object gathers, neighbour exchanges of rows of ANY shape (halo rows have the receiver's own shape, the raster
+    writer hands over blocks of rows of any height, or nothing), and a thread that never arrives breaks the wait for the others."""
+    import time
+    from malstroem_amd import distributed as D
+    if impl == "python":
+        monkeypatch.setenv("MALSTROEM_THREAD_RENDEZVOUS", "python")
+    n = 4
+    meet = D._Rendezvous(n, timeout_s=30.0)
+    assert (meet._tg is not None) == (impl == "library")
+    out = [None] * n
+
+    def work(r):
+        rng = np.random.default_rng(r)
+        log = []
+        for it in range(50):
+            log.append(meet.max(r, float((r * 7 + it) % 5)) == float(max((q * 7 + it) % 5 for q in range(n))))
+            log.append(meet.gather(r, (r, it)) == [(q, it) for q in range(n)])
+            # rank r offers (r + it % 3) rows of (it % 4 + 1) float32 upwards and an int32 vector downwards -- or nothing, now and then
+            up = None if (r == 0 or (r + it) % 5 == 0) else np.full((r + it % 3, it % 4 + 1), 100 * r + it, np.float32)
+            down = None if (r == n - 1 or (r + it) % 7 == 0) else np.arange(r + it + 1, dtype=np.int32)
+            fu, fd = meet.rows(r, up, down)
+            q = r - 1      # what the neighbour above offered downwards
+            want_u = None if (r == 0 or (q + it) % 7 == 0) else np.arange(q + it + 1, dtype=np.int32)
+            q = r + 1      # what the neighbour below offered upwards
+            want_d = None if (r == n - 1 or (q + it) % 5 == 0) else np.full((q + it % 3, it % 4 + 1), 100 * q + it, np.float32)
+            for got, want in ((fu, want_u), (fd, want_d)):
+                log.append((got is None and want is None) or (got is not None and want is not None and got.dtype == want.dtype and
+                                                               got.shape == want.shape and np.array_equal(got, want)))
+        out[r] = all(log)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    [t.start() for t in threads]
+    [t.join(120) for t in threads]
+    assert out == [True] * n
+    # one thread stays away: the others give up together after the timeout instead of waiting for ever
+    meet2 = D._Rendezvous(3, timeout_s=0.5)
+    raised = [None, None]
+
+    def waits(r):
+        try:
+            meet2.max(r, 1.0)
+        except Exception as e:
+            raised[r] = e
+    t0 = time.time()
+    threads = [threading.Thread(target=waits, args=(r,)) for r in range(2)]
+    [t.start() for t in threads]
+    [t.join(30) for t in threads]
+    assert all(r is not None for r in raised) and time.time() - t0 < 10

@@ -5,9 +5,39 @@ with four methods (exchange_rows / allreduce_max / allgather / clone).  A launch
 ``python -m torch.distributed.run`` (bench.py, the gloo process tests) already has a rendezvous, so it wraps it here
 instead of opening the package's own SocketComm.  Nothing in here touches a GPU.
 """
+import atexit
 import datetime
+import os
+import time
 
 import numpy as np
+
+# development aid: MALSTROEM_COMM_STATS=1 prints, per process at exit, calls and wall time of the three collectives (the time includes
+# the wait for the slowest rank)
+_STATS = {} if os.environ.get("MALSTROEM_COMM_STATS") else None      # method -> [calls, seconds] of this process (printed at exit)
+
+
+def _timed(fn):
+    if _STATS is None:
+        return fn
+
+    def wrapper(self, *a, **kw):
+        t0 = time.perf_counter()
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            st = _STATS.setdefault(fn.__name__, [0, 0.0])
+            st[0] += 1
+            st[1] += time.perf_counter() - t0
+    return wrapper
+
+
+if _STATS is not None:
+    @atexit.register
+    def _report():
+        import sys
+        print("[TorchComm pid %d] %s" % (os.getpid(), ", ".join("%s: %d calls %.1f ms" % (k, v[0], v[1] * 1e3) for k, v in sorted(_STATS.items()))),
+              file=sys.stderr, flush=True)
 
 
 class TorchComm(object):
@@ -20,6 +50,7 @@ class TorchComm(object):
         self.rank = dist.get_rank(group)
         self.size = dist.get_world_size(group)
 
+    @_timed
     def exchange_rows(self, to_up, to_down):
         """host-staged neighbour exchange (bands without an RCCL communicator)"""
         torch, dist = self._torch, self._dist
@@ -43,11 +74,13 @@ class TorchComm(object):
         from_down = None if recv_down is None else recv_down.numpy().view(like_down.dtype).reshape(like_down.shape)
         return from_up, from_down
 
+    @_timed
     def allreduce_max(self, value):
         t = self._torch.tensor([float(value)], dtype=self._torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self._group)
         return float(t[0])
 
+    @_timed
     def allgather(self, obj):
         out = [None] * self.size
         self._dist.all_gather_object(out, obj, group=self._group)

@@ -1197,10 +1197,29 @@ int mhip_ctx_band_watershed_local(mhip_ctx *c)
     MH_ARG(c && c->have[MHIP_R_LABELS] && c->have[MHIP_R_FLOWDIR], "ctx_band_watershed_local needs labels and flow directions");
     MH_HIP(hipSetDevice(c->device));
     MH_TRY(ctx_raster(c, MHIP_R_WATERSHEDS));
-    const size_t n = (size_t)(c->H * c->W);
-    MH_HIP(hipMemcpyAsync(c->r[MHIP_R_WATERSHEDS].p, c->r[MHIP_R_LABELS].p, 4 * n, hipMemcpyDeviceToDevice, cs(c)));
-    MH_TRY(band_pseudo_labels_dev(c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, c->ht, c->hb, cs(c)));
-    MH_TRY(watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, 0, cs(c), true));
+    // Out of place, like one context: the watersheds read the labels where they are and write every cell of their own raster (a copy of
+    // the label raster first -- 8 B per cell -- and the in-place passes behind it were what the band did until round 4).  The pseudo
+    // labels of the halo rows have to be IN the raster the passes read: the labels' two halo rows are put aside, overwritten and
+    // restored (nobody else reads them meanwhile: the pour points on the main thread look at owned rows only).
+    hipStream_t s = cs(c);
+    const size_t rowb = 4 * (size_t)c->W;
+    int32_t *lab = c->r[MHIP_R_LABELS].as<int32_t>();
+    DevBuf keep;
+    MH_TRY(keep.alloc(2 * rowb));
+    if (c->ht) MH_HIP(hipMemcpyAsync(keep.p, lab, rowb, hipMemcpyDeviceToDevice, s));
+    if (c->hb) MH_HIP(hipMemcpyAsync(keep.as<char>() + rowb, lab + (c->H - 1) * c->W, rowb, hipMemcpyDeviceToDevice, s));
+    int rc = band_pseudo_labels_dev(lab, c->H, c->W, c->ht, c->hb, s);
+    if (rc == MHIP_OK)
+        rc = watersheds_dev(c->r[MHIP_R_FLOWDIR].as<uint8_t>(), c->r[MHIP_R_WATERSHEDS].as<int32_t>(), c->H, c->W, 0, s, true, nullptr, lab, nullptr);
+    // (whatever happened: the labels get their halo rows back)
+    hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    if (c->ht) e1 = hipMemcpyAsync(lab, keep.p, rowb, hipMemcpyDeviceToDevice, s);
+    if (c->hb) e2 = hipMemcpyAsync(lab + (c->H - 1) * c->W, keep.as<char>() + rowb, rowb, hipMemcpyDeviceToDevice, s);
+    const hipError_t e3 = stream_sync(s);
+    MH_TRY(rc);
+    MH_HIP(e1);
+    MH_HIP(e2);
+    MH_HIP(e3);
     c->have[MHIP_R_WATERSHEDS] = true;
     return MHIP_OK;
 }

@@ -311,6 +311,15 @@ def main():
         from malstroem_amd.distributed import HybridComm, SingleComm
         k = nbands // world
         proc_comm = TorchComm() if world > 1 else SingleComm()
+        control_plane = "torch.distributed (gloo)" if world > 1 else "one process"
+        if world > 1 and os.environ.get("MALSTROEM_CONTROL_PLANE", "shm") != "gloo":
+            # the ranks of one node (the launch contract: --nnodes=1): votes, neighbour rows of the boundary systems and the small
+            # all-gathers through a shared-memory segment instead of TCP on the loopback interface (set up through gloo; ranks that do
+            # not share rank 0's host keep gloo, all of them together)
+            from malstroem_amd.distributed import ShmComm
+            proc_comm = ShmComm.over(proc_comm)
+            if isinstance(proc_comm, ShmComm):
+                control_plane = "shared-memory segment of the node (malstroem_amd.distributed.ShmComm), set up over gloo"
         host_rows_asked = os.environ.get("MALSTROEM_BAND_TRANSPORT", "rccl") == "host"     # explicit override: rows through the host communicator
         rccl = k == 1 and world > 1 and world <= ndev and not host_rows_asked
         comms = [proc_comm] if k == 1 else HybridComm.world(proc_comm, k)
@@ -356,6 +365,11 @@ def main():
                 w.join(60)
         if pipe is not None:
             pipe.close()
+        if band_mode and hasattr(proc_comm, "close") and not isinstance(proc_comm, TorchComm):
+            try:
+                proc_comm.close()      # (the shared-memory control plane: rank 0 removes the segment)
+            except Exception:
+                pass
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -532,7 +546,7 @@ def main():
             else:
                 seam_transports.append("host communicator (gloo point-to-point), process %d <-> %d" % (sm // kb, (sm + 1) // kb))
         info = {"nlabels": workers[0].pipe.nlabels, "halo_exchanges": dict(workers[0].pipe.exchanges), "bands": nbands,
-                "seam_transports": seam_transports,
+                "seam_transports": seam_transports, "control_plane": control_plane,
                 "band_engines": [w.pipe.engines() for w in workers], "engines": ENGINE_NOTE,
                 "step_ms_rank0": band_step_ms, "rccl_ranks": rccl_ranks, "rccl_side_communicator": bool(workers[0].pipe.rccl_side), "check": check_note,
                 # thread CPU time per step of the host-only sections of the boundary systems (label / accumulation / watershed

@@ -180,6 +180,9 @@ int mhip_tg_allreduce_max(void *group, int32_t rank, double value, double *out, 
 int mhip_tg_offer(void *group, int32_t rank, const void *to_up, const int64_t *meta_up /* [8] */, const void *to_down, const int64_t *meta_down,
                   int64_t *meta_from_up /* [8] */, int64_t *meta_from_down, int32_t timeout_ms);
 int mhip_tg_take(void *group, int32_t rank, void *from_up, void *from_down, int32_t timeout_ms);
+/* the barrier of ranks that are PROCESSES of one host (distributed.ShmComm keeps the payloads of its collectives in a POSIX shared-memory
+ * segment every rank maps): two 64-bit words at `base` (8-byte aligned, zero at the start), n ranks; MHIP_ECOMM after timeout_ms */
+int mhip_shm_barrier(void *base, int32_t n, int32_t timeout_ms);
 
 /* per-label records of labels that live in several bands: parts[r] = band r's n partial records, merged in band order into out.
  * kind 0: {min, max, sum, count} (label_stats, _label.pyx:22-24); kind 2 / 3: {value, row, col} of label_max_index / label_min_index

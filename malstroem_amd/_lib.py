@@ -45,7 +45,7 @@ SYMBOLS = [
     "mhip_ctx_band_apply_neg_lut", "mhip_ctx_band_records", "mhip_ctx_band_fetch", "mhip_ctx_band_gather",
     "mhip_ctx_band_foreign_counts", "mhip_ctx_side_begin", "mhip_ctx_side_end",
     "mhip_ctx_has_comm", "mhip_ctx_exchange_halo", "mhip_ctx_exchange_edge_rows", "mhip_ctx_comm_add_side", "mhip_band_union_find", "mhip_band_accum_pairs", "mhip_band_accum_solve", "mhip_band_label_pairs",
-    "mhip_band_label_merge", "mhip_band_ws_publish", "mhip_band_ws_lut", "mhip_band_merge_records", "mhip_tg_create", "mhip_tg_destroy", "mhip_tg_barrier", "mhip_tg_allreduce_max", "mhip_tg_offer", "mhip_tg_take", "mhip_ctx_allreduce_max",
+    "mhip_band_label_merge", "mhip_band_ws_publish", "mhip_band_ws_lut", "mhip_band_merge_records", "mhip_tg_create", "mhip_tg_destroy", "mhip_tg_barrier", "mhip_tg_allreduce_max", "mhip_tg_offer", "mhip_tg_take", "mhip_shm_barrier", "mhip_ctx_allreduce_max",
 ]
 
 _lib = None

@@ -456,6 +456,124 @@ class SocketComm(Comm):
         self._peers, self._hub = {}, None
 
 
+class ShmComm(Comm):
+    """The control plane between ranks that are PROCESSES OF ONE HOST, in a POSIX shared-memory segment: a collective is "write my
+    payload into my slot, barrier, read the others', barrier" -- two barriers of a few microseconds (``mhip_shm_barrier``: the
+    hardware's atomics on two words of the segment) instead of a TCP round trip through gloo or the socket hub (0.15-0.5 ms each,
+    50-60 per step of a band chain).  Payloads travel in the data-only wire format (``wire_dumps``: nothing that arrives is ever
+    executed), in pieces of the slot size where they are larger.  ``ShmComm.over(comm)`` sets one up through an existing
+    communicator (a collective call: rank 0 creates the segment, the others attach; every rank must be on rank 0's host --
+    checked by a file every rank looks for in the segment's directory -- or every rank gets ``comm`` back)."""
+
+    one_rank_per_device = True
+    HEADER = 4096
+
+    def __init__(self, rank, size, shm, slot_bytes, owner, parent, timeout_s=600.0):
+        self.rank, self.size = int(rank), int(size)
+        self._shm, self._slot, self._owner, self._parent = shm, int(slot_bytes), bool(owner), parent
+        self._timeout_ms = int(timeout_s * 1000)
+        buf = shm.buf
+        self._base = ctypes.addressof(ctypes.c_char.from_buffer(buf))
+        self._values = np.frombuffer(buf, dtype=np.float64, count=self.size, offset=256)
+        self._lens = np.frombuffer(buf, dtype=np.int64, count=self.size, offset=256 + 8 * self.size + (-8 * self.size) % 64)
+        self._slots = [np.frombuffer(buf, dtype=np.uint8, count=self._slot, offset=self.HEADER + r * self._slot) for r in range(self.size)]
+
+    @classmethod
+    def over(cls, comm, slot_bytes=8 << 20, timeout_s=600.0):
+        """collective on ``comm``: a ShmComm of the same ranks, or ``comm`` itself where the ranks do not share a host / the segment
+        cannot be made (decided together)"""
+        from multiprocessing import shared_memory
+        if comm.size < 2:
+            return comm
+        total = cls.HEADER + comm.size * int(slot_bytes)
+        shm, name, err = None, None, None
+        if comm.rank == 0:
+            try:
+                shm = shared_memory.SharedMemory(create=True, size=total)
+                shm.buf[:cls.HEADER] = bytes(cls.HEADER)
+                name = shm.name
+            except Exception as e:      # (no /dev/shm, no room ...)
+                err = e
+        name = comm.allgather(name)[0]
+        if name is not None and comm.rank != 0:
+            try:
+                shm = shared_memory.SharedMemory(name=name)      # (only a process of rank 0's host finds it)
+                if shm.size < total:
+                    raise RuntimeError("segment too small")
+            except Exception as e:
+                err, shm = e, None
+        ok = comm.allreduce_max(0.0 if (shm is not None and err is None) else 1.0) == 0.0
+        if not ok:
+            if shm is not None:
+                shm.close()
+                if comm.rank == 0:
+                    shm.unlink()
+            return comm
+        if comm.rank != 0:
+            # (the resource tracker of a process that merely attached would unlink the segment when that process ends -- Python < 3.13)
+            try:
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:
+                pass
+        return cls(comm.rank, comm.size, shm, slot_bytes, comm.rank == 0, comm, timeout_s)
+
+    def _barrier(self):
+        _lib.call("mhip_shm_barrier", ctypes.c_void_p(self._base), self.size, self._timeout_ms)
+
+    def allreduce_max(self, value):
+        self._values[self.rank] = float(value)
+        self._barrier()
+        m = float(self._values.max())
+        self._barrier()
+        return m
+
+    def _trade(self, payload, wanted):
+        """my bytes into my slot, the bytes of the ranks in ``wanted`` out of theirs -> {rank: bytes}; in pieces where a payload is
+        larger than a slot"""
+        n = len(payload)
+        self._lens[self.rank] = n
+        self._barrier()
+        lens = self._lens.copy()
+        out = {r: bytearray() for r in wanted}
+        mine = np.frombuffer(payload, dtype=np.uint8) if n else None
+        for off in range(0, max(int(lens.max()), 1), self._slot):
+            k = max(0, min(self._slot, n - off))
+            if k:
+                self._slots[self.rank][:k] = mine[off:off + k]
+            self._barrier()
+            for r in wanted:
+                kr = max(0, min(self._slot, int(lens[r]) - off))
+                if kr:
+                    out[r] += self._slots[r][:kr].tobytes()
+            self._barrier()
+        return {r: bytes(b) for r, b in out.items()}
+
+    def allgather(self, obj):
+        got = self._trade(wire_dumps(obj), range(self.size))
+        return [wire_loads(got[r]) for r in range(self.size)]
+
+    def exchange_rows(self, to_up, to_down):
+        up, down = self.rank - 1, self.rank + 1
+        got = self._trade(wire_dumps((None if up < 0 else to_up, None if down >= self.size else to_down)),
+                          [r for r in (up, down) if 0 <= r < self.size])
+        from_up = wire_loads(got[up])[1] if up >= 0 else None
+        from_down = wire_loads(got[down])[0] if down < self.size else None
+        return from_up, from_down
+
+    def clone(self):
+        return ShmComm.over(self, self._slot, self._timeout_ms / 1e3)
+
+    def close(self):
+        try:
+            self._values = self._lens = self._slots = None
+            self._shm.close()
+            if self._owner:
+                self._shm.unlink()
+        except Exception:
+            pass
+
+
 class HybridComm(Comm):
     """``k`` bands per process (threads) times ``P`` processes = ``P * k`` virtual ranks, band order = (process, thread).
 
@@ -531,10 +649,18 @@ class HybridComm(Comm):
         w.meet.wait()
         if self._t == 0:
             w.result = HybridComm._World(w.proc.clone(), w.k)
+            w.result.owns_proc = True
         w.meet.wait()
         nw = w.result
         w.meet.wait()
         return HybridComm(nw, self._t)
+
+    def close(self):
+        """(a clone's process-level communicator is the clone's own: its first endpoint closes it)"""
+        w = self._w
+        if self._t == 0 and getattr(w, "owns_proc", False) and hasattr(w.proc, "close"):
+            w.owns_proc = False
+            w.proc.close()
 
 
 # ---- compute backend: one band context on one GPU -----------------------------------------------------------------
@@ -992,6 +1118,13 @@ class BandPipeline(object):
 
     def close(self):
         self.band.close()
+        cb = getattr(self, "_comm_b", None)      # the labelling thread's communicator is the pipeline's own (run_chain cloned it)
+        if cb is not None and hasattr(cb, "close"):
+            try:
+                cb.close()
+            except Exception:
+                pass
+            self._comm_b = None
 
     def engines(self):
         """Which engine the last fill / no-flats fill of this band ran (``ctx_get_int``: fill 1 = tiled priority-flood, 0 = iterative

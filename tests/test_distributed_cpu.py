@@ -368,7 +368,40 @@ assert "torch" not in sys.modules, "the product package pulled torch in"
 '''
 
 
-@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET)], ids=["host_rows_2", "socket_and_in_library_transport_3"])
+# the control plane in a shared-memory segment (ranks = processes of one host), set up through the socket communicator; a small slot
+# makes the larger payloads (rows of 70 doubles, seam pairs) travel in pieces; the whole chain with the label branch on a clone
+WORKER_SHM = r'''
+import os, sys
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tests"))
+import numpy as np
+from _cases import fbm
+from _cpu_band import CpuBand
+from malstroem_amd.distributed import BandPipeline, ShmComm, SocketComm
+sock = SocketComm.from_env()
+comm = ShmComm.over(sock, slot_bytes=int(os.environ.get("SLOT", "300")))
+assert isinstance(comm, ShmComm) and (comm.rank, comm.size) == (sock.rank, sock.size)
+# the collectives themselves, incl. payloads of several slots and nothing at all
+big = np.arange(5000, dtype=np.float64) * (comm.rank + 1)
+got = comm.allgather({"r": comm.rank, "a": big, "none": None})
+assert [g["r"] for g in got] == list(range(comm.size)) and all(np.array_equal(g["a"], np.arange(5000.0) * (q + 1)) for q, g in enumerate(got))
+assert comm.allreduce_max(float(comm.rank)) == comm.size - 1.0
+fu, fd = comm.exchange_rows(np.full(7, comm.rank, np.int32), np.full((2, 3), -comm.rank, np.float32))
+assert (fu is None) == (comm.rank == 0) and (fd is None) == (comm.rank == comm.size - 1)
+assert fu is None or np.array_equal(fu, np.full((2, 3), -(comm.rank - 1), np.float32))
+assert fd is None or np.array_equal(fd, np.full(7, comm.rank + 1, np.int32))
+dem = fbm(90, 70, beta=2.0, seed=4)
+p = BandPipeline(comm, dem.shape, backend_factory=CpuBand)
+p.upload_dem(dem[p.row0:p.row0 + p.nrows])
+p.run_chain(); n = p.nlabels
+np.savez(os.path.join(os.environ["OUT"], "rank%d.npz" % comm.rank), row0=p.row0, nlabels=n,
+         **{k: p.download(k) for k in ("filled", "depths", "noflat", "flowdir", "accum", "labels", "watersheds")})
+comm.allgather(None); p.close()      # (closes the labelling thread's clone as well)
+comm.close(); sock.allgather(None); sock.close()
+'''
+
+
+@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET), (3, WORKER_SHM), (4, WORKER_SHM)],
+                         ids=["host_rows_2", "socket_and_in_library_transport_3", "shared_memory_control_plane_3", "shared_memory_control_plane_4"])
 def test_protocol_gloo_processes(world, worker, tmp_path):
     """Band protocol over real processes: (1) world size 2 over torch.distributed/gloo (tools/launch_comm.TorchComm), rows
     staged through the host communicator; (2) world size 3 over the package's stdlib SocketComm with the rows on the band's

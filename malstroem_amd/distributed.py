@@ -1141,8 +1141,12 @@ class BandPipeline(object):
 
     # ---- helpers
     def _allreduce_max(self, value):
-        """data-path reduction of the iteration loops: RCCL when the band owns a communicator"""
-        return self.band.allreduce_max(value) if self.rccl else self.comm.allreduce_max(value)
+        """the one-number reduction of the iteration loops: RCCL when the band owns a communicator -- unless the control plane is a
+        shared-memory segment of the node (two barriers of a few microseconds: cheaper than a collective launch + a host
+        synchronisation, and the value is the host's anyway)"""
+        if self.rccl and not isinstance(self.comm, ShmComm):
+            return self.band.allreduce_max(value)
+        return self.comm.allreduce_max(value)
 
     def _vote(self, busy, err=None):
         """all-reduce of "still busy" that also carries failures: a rank that caught an exception votes 2 and every

@@ -400,8 +400,9 @@ comm.close(); sock.allgather(None); sock.close()
 '''
 
 
-@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET), (3, WORKER_SHM), (4, WORKER_SHM)],
-                         ids=["host_rows_2", "socket_and_in_library_transport_3", "shared_memory_control_plane_3", "shared_memory_control_plane_4"])
+@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET), (3, WORKER_SHM), (4, WORKER_SHM), (8, WORKER_SHM)],
+                         ids=["host_rows_2", "socket_and_in_library_transport_3", "shared_memory_control_plane_3", "shared_memory_control_plane_4",
+                              "shared_memory_control_plane_8"])
 def test_protocol_gloo_processes(world, worker, tmp_path):
     """Band protocol over real processes: (1) world size 2 over torch.distributed/gloo (tools/launch_comm.TorchComm), rows
     staged through the host communicator; (2) world size 3 over the package's stdlib SocketComm with the rows on the band's

@@ -1273,6 +1273,7 @@ class BandPipeline(object):
 
     def fill(self):
         """fill.fill_terrain over all bands (+ bluespot depths of the owned rows)."""
+        self.exchanges["fill"] = 0      # (per call, like the no-flats fill's: ``exchanges`` describes the last chain)
         self._fill(0, "filled")
 
     def short_and_diag(self):

@@ -400,9 +400,16 @@ comm.close(); sock.allgather(None); sock.close()
 '''
 
 
-@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET), (3, WORKER_SHM), (4, WORKER_SHM), (8, WORKER_SHM)],
+# the shape of the real multi-GPU run: control plane in shared memory, the rows on the band's own communicator (BandPipeline's RCCL
+# code path; the CPU stand-in joins a socket "communicator" there), loop votes through the control plane
+WORKER_SHM_RCCL = WORKER_SHM.replace("p = BandPipeline(comm, dem.shape, backend_factory=CpuBand)",
+                                     "p = BandPipeline(comm, dem.shape, backend_factory=CpuBand, rccl=True)\nassert p.rccl and p.band.has_comm and not p.rccl_side")
+assert WORKER_SHM_RCCL != WORKER_SHM
+
+
+@pytest.mark.parametrize("world,worker", [(2, WORKER), (3, WORKER_SOCKET), (3, WORKER_SHM), (4, WORKER_SHM), (8, WORKER_SHM), (4, WORKER_SHM_RCCL)],
                          ids=["host_rows_2", "socket_and_in_library_transport_3", "shared_memory_control_plane_3", "shared_memory_control_plane_4",
-                              "shared_memory_control_plane_8"])
+                              "shared_memory_control_plane_8", "shared_memory_control_plane_and_in_library_rows_4"])
 def test_protocol_gloo_processes(world, worker, tmp_path):
     """Band protocol over real processes: (1) world size 2 over torch.distributed/gloo (tools/launch_comm.TorchComm), rows
     staged through the host communicator; (2) world size 3 over the package's stdlib SocketComm with the rows on the band's

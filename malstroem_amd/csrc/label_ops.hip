@@ -317,11 +317,26 @@ __global__ __launch_bounds__(256) void stats_kernel(const float *__restrict__ da
         bsum += __shfl_xor(bsum, o);
         bcnt += __shfl_xor(bcnt, o);
     }
-    if (lane == 0 && bcnt) {
-        atomicMin(&a.minkey[0], f32_key(bmin));
-        atomicMax(&a.maxkey[0], f32_key(bmax));
-        atomicAdd(&a.sum[0], bsum);
-        atomicAdd(&a.count[0], bcnt);
+    // (the background's record: one set of atomics per WORKGROUP -- every wavefront of a 2048-workgroup launch at the same four words
+    // was 8192 same-address atomics each, ~0.1 ms of serialised tail at the end of a kernel on the chain's critical path)
+    __shared__ float wmin[4], wmax[4];
+    __shared__ double wsum[4];
+    __shared__ unsigned long long wcnt[4];
+    __syncthreads();
+    if (lane == 0) {
+        wmin[threadIdx.x >> 6] = bmin; wmax[threadIdx.x >> 6] = bmax; wsum[threadIdx.x >> 6] = bsum; wcnt[threadIdx.x >> 6] = bcnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            bmin = fminf(bmin, wmin[k]); bmax = fmaxf(bmax, wmax[k]); bsum += wsum[k]; bcnt += wcnt[k];
+        }
+        if (bcnt) {
+            atomicMin(&a.minkey[0], f32_key(bmin));
+            atomicMax(&a.maxkey[0], f32_key(bmax));
+            atomicAdd(&a.sum[0], bsum);
+            atomicAdd(&a.count[0], bcnt);
+        }
     }
 }
 
@@ -662,7 +677,14 @@ __global__ __launch_bounds__(256) void count_kernel(const int32_t *__restrict__ 
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bcnt += __shfl_xor(bcnt, o);
-    if (lane == 0 && bcnt) atomicAdd(&counts[0], bcnt);
+    __shared__ unsigned long long wcnt0[4];      // (one atomic per workgroup: see stats_kernel)
+    __syncthreads();
+    if (lane == 0) wcnt0[threadIdx.x >> 6] = bcnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bcnt = wcnt0[0] + wcnt0[1] + wcnt0[2] + wcnt0[3];
+        if (bcnt) atomicAdd(&counts[0], bcnt);
+    }
 }
 
 __global__ __launch_bounds__(256) void max_kernel(const int32_t *__restrict__ lab, int64_t n, int *out)
@@ -675,7 +697,14 @@ __global__ __launch_bounds__(256) void max_kernel(const int32_t *__restrict__ la
         const int v = __shfl_xor(m, o);
         m = v > m ? v : m;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+    // (one atomic per workgroup, few workgroups: same-address atomics are served one after the other -- see reduce.hip: minmax_kernel)
+    __shared__ int sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) m = sm[k] > m ? sm[k] : m;
+        atomicMax(out, m);
+    }
 }
 
 __global__ __launch_bounds__(256) void lut_kernel(int32_t *lab, const int32_t *__restrict__ lut, int64_t nlab, int64_t n,
@@ -981,7 +1010,7 @@ int label_max_dev(const int32_t *d_labels, int64_t n, int32_t *out_max, hipStrea
     MH_TRY(m.alloc(4));
     const int init = INT32_MIN;
     MH_HIP(hipMemcpyAsync(m.p, &init, 4, hipMemcpyHostToDevice, s));
-    const unsigned grid = (unsigned)(cdiv(n, 256) < 8192 ? cdiv(n, 256) : 8192);
+    const unsigned grid = (unsigned)(cdiv(n, 256) < 1024 ? cdiv(n, 256) : 1024);
     hipLaunchKernelGGL(max_kernel, dim3(grid), dim3(256), 0, s, d_labels, n, m.as<int>());
     MH_HIP(hipGetLastError());
     MH_HIP(hipMemcpyAsync(out_max, m.p, 4, hipMemcpyDeviceToHost, s));

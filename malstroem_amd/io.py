@@ -266,6 +266,18 @@ def _write_ifd(fh, big, shape, dtype, predictor, tile, offsets, counts, transfor
         fh.write(struct.pack("<I", ifd))
 
 
+_POOL = None
+
+
+def _deflate_pool():
+    """a few threads for the deflate of a tile row's tiles (one pool per process, made on first use)"""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix="deflate")
+    return _POOL
+
+
 def _encode_tile(tile, predictor, itemsize, zlevel):
     if predictor == 2:
         u = tile.view(np.dtype("<u%d" % itemsize))
@@ -359,8 +371,11 @@ class BandRasterWriter(object):
                         pending[:own1 - g0, :W] = rows(g0 - row0, own1 - g0)
                     if g1 > own1:                                     # the tail of my last tile row lives in the next band
                         pending[own1 - g0:g1 - g0, :W] = from_down[:g1 - own1]
-                    for bx in range(across):
-                        data = _encode_tile(np.ascontiguousarray(pending[:, bx * T:(bx + 1) * T]), predictor, dtype.itemsize, self.zlevel)
+                    tiles = [np.ascontiguousarray(pending[:, bx * T:(bx + 1) * T]) for bx in range(across)]
+                    isz, zl = dtype.itemsize, self.zlevel
+                    raws = list(_deflate_pool().map(lambda t: _encode_tile(t, predictor, isz, zl), tiles)) if across >= 4 else \
+                        [_encode_tile(t, predictor, isz, zl) for t in tiles]
+                    for bx, data in enumerate(raws):
                         assert len(data) <= slot
                         os.pwrite(fd, data, 16 + (k * across + bx) * slot)
                         counts[(k - k0) * across + bx] = len(data)
@@ -433,14 +448,15 @@ class RasterWriter(object):
         T = self.TILE
         if rows_valid < T:
             self._pending[rows_valid:] = 0
-        for bx in range(self._across):
-            tile = np.ascontiguousarray(self._pending[:, bx * T:(bx + 1) * T])
-            if self._predictor == 2:
-                u = tile.view(np.dtype("<u%d" % self._dtype.itemsize))
-                d = u.copy()
-                d[:, 1:] = u[:, 1:] - u[:, :-1]
-                tile = d
-            raw = zlib.compress(tile.tobytes(), int(self.options.get('zlevel', 6)))
+        # the tiles of a tile row are deflated side by side (zlib works without the GIL): the seven rasters of `complete` on a 4096^2
+        # terrain spent 4 s in zlib one tile after the other; the file is the same, tile after tile in raster order
+        zl, isz, pred = int(self.options.get('zlevel', 6)), self._dtype.itemsize, self._predictor
+        tiles = [np.ascontiguousarray(self._pending[:, bx * T:(bx + 1) * T]) for bx in range(self._across)]
+        if self._across >= 4:
+            raws = list(_deflate_pool().map(lambda t: _encode_tile(t, pred, isz, zl), tiles))
+        else:
+            raws = [_encode_tile(t, pred, isz, zl) for t in tiles]
+        for raw in raws:
             self._offsets.append(self._fh.tell())
             self._counts.append(len(raw))
             self._fh.write(raw)
@@ -519,8 +535,14 @@ class VectorWriter(object):
         d = os.path.dirname(path)
         if d and not os.path.isdir(d):
             os.makedirs(d)
+        # feature by feature through json.dumps -- the C encoder; json.dump(obj, fh) walks the whole collection in the pure-Python
+        # chunk iterator: 29 of the 40 s of `complete` on a 4096^2 terrain with 238 000 bluespots.  The bytes are the ones json.dump wrote.
         with open(path, "w") as fh:
-            json.dump(dict(type="FeatureCollection", name=self.layername, features=feats), fh, default=_json_scalar)
+            fh.write('{"type": "FeatureCollection", "name": %s, "features": [' % json.dumps(self.layername))
+            for k in range(0, len(feats), 4096):
+                chunk = ", ".join(json.dumps(g, default=_json_scalar) for g in feats[k:k + 4096])
+                fh.write((", " if k else "") + chunk)
+            fh.write("]}")
 
     def close(self):
         pass
